@@ -1,0 +1,104 @@
+"""ctypes loader for oracle/_build/libekf_oracle.so.  TEST INFRASTRUCTURE ONLY (see ekf_oracle.h).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libekf_oracle.so")
+
+NEW, OLD, IGNORE = 1, 2, 3
+
+_dp = ctypes.POINTER(ctypes.c_double)
+_ip = ctypes.POINTER(ctypes.c_int)
+
+
+def build(force=False):
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(os.path.join(_HERE, "ekf_oracle.c")):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = ctypes.CDLL(build())
+        L.ekf_oracle_propagate.argtypes = [ctypes.c_int, _dp, _dp, ctypes.c_double, ctypes.c_double, _dp,
+                                           ctypes.c_double, _dp, _dp, ctypes.c_int]
+        L.ekf_oracle_propagate.restype = None
+        L.ekf_oracle_update.argtypes = [ctypes.c_int, _dp, _dp, ctypes.c_int, _dp, _dp, ctypes.c_int, ctypes.c_int,
+                                        ctypes.c_double, _dp, _dp, _ip, _ip, _ip, _dp, ctypes.c_int]
+        L.ekf_oracle_update.restype = None
+        L.ekf_oracle_compass.argtypes = [ctypes.c_int, _dp, _dp, ctypes.c_double, ctypes.c_double, ctypes.c_int]
+        L.ekf_oracle_compass.restype = None
+        L.ekf_oracle_make_Q.argtypes = [ctypes.c_double, ctypes.c_double, ctypes.c_double, _dp]
+        L.ekf_oracle_make_Q.restype = None
+        L.ekf_oracle_make_measurement.argtypes = [ctypes.c_double, ctypes.c_double, _dp, _dp]
+        L.ekf_oracle_make_measurement.restype = None
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp)
+
+
+def make_Q(v, sigma_v=0.01, sigma_w=0.04):
+    Q = np.zeros(4)
+    lib().ekf_oracle_make_Q(v, sigma_v, sigma_w, _p(Q))
+    return Q.reshape(2, 2)
+
+
+def make_measurement(fx_mm, fy_mm):
+    z = np.zeros(2)
+    R = np.zeros(4)
+    lib().ekf_oracle_make_measurement(fx_mm, fy_mm, _p(z), _p(R))
+    return z, R.reshape(2, 2).T.copy()  # column-major -> matrix
+
+
+def propagate(x, P, v, w, Q, dt, faithful=False):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    P = np.ascontiguousarray(P, dtype=np.float64)
+    Q = np.ascontiguousarray(Q, dtype=np.float64).reshape(4)
+    n = x.size
+    xo = np.empty(n)
+    Po = np.empty((n, n))
+    lib().ekf_oracle_propagate(n, _p(x), _p(P), v, w, _p(Q), dt, _p(xo), _p(Po), int(faithful))
+    return xo, Po
+
+
+def update(x, P, z_chunk, R_chunk, gamma_max=50, gamma_min=10, cond_limit=80.0, faithful=False):
+    """z_chunk (2, n_z), R_chunk (2, 2 n_z) as matrices; passed column-major like Eigen's data()."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    P = np.ascontiguousarray(P, dtype=np.float64)
+    z = np.asfortranarray(np.asarray(z_chunk, dtype=np.float64).reshape(2, -1))
+    R = np.asfortranarray(np.asarray(R_chunk, dtype=np.float64).reshape(2, -1))
+    n, n_z = x.size, z.shape[1]
+    cap = n + 2 * n_z
+    xo = np.empty(cap)
+    Po = np.empty(cap * cap)
+    n_out = ctypes.c_int(0)
+    dec = np.zeros(n_z, dtype=np.int32)
+    mat = np.zeros(n_z, dtype=np.int32)
+    mah = np.zeros(n_z)
+    zf = z.ravel(order="F").copy()
+    Rf = R.ravel(order="F").copy()
+    lib().ekf_oracle_update(n, _p(x), _p(P), n_z, _p(zf), _p(Rf), int(gamma_max), int(gamma_min), float(cond_limit),
+                            _p(xo), _p(Po), ctypes.byref(n_out), dec.ctypes.data_as(_ip), mat.ctypes.data_as(_ip),
+                            _p(mah), int(faithful))
+    m = n_out.value
+    return xo[:m].copy(), Po[:m * m].reshape(m, m).copy(), dec.tolist(), mat.tolist(), mah.tolist()
+
+
+def compass(x, P, z, R, faithful=False):
+    x = np.array(x, dtype=np.float64)
+    P = np.array(P, dtype=np.float64, order="C")
+    lib().ekf_oracle_compass(x.size, _p(x), _p(P), float(z), float(R), int(faithful))
+    return x, P
