@@ -1,0 +1,162 @@
+/*
+ * ekfslam_c.h -- C ABI of the MI355X-native EKF-SLAM core (libekfslam_hip.so).
+ *
+ * Drop-in boundary for the one hot path of kentsommer/2D-EKF-SLAM: the Propagate + Update loop
+ * behind odometry/kalmanfilter.h.  Plain pointers and sizes only; no C++/torch types.
+ * Each entry point cites the reference interface it replaces (paths relative to the reference).
+ *
+ * A handle owns `batch` independent filters (batch = 1 for the reference's single filter), all
+ * resident in the HBM of one device and driven through one HIP stream.  Host buffers passed in are
+ * caller-owned and are only read/written during the call.  A handle is not thread-safe; distinct
+ * handles are independent.
+ *
+ * Layout conventions (match Eigen's data() so the reference's matrices can be passed as they are):
+ *   x        : n = 3 + 2*N doubles [x_R, y_R, phi, L1x, L1y, ...]          (Update.cpp:106)
+ *   P        : n x n, column-major with leading dimension ld (P is symmetric, exported bitwise
+ *              symmetric)                                                   (kalmanfilter.h:38)
+ *   z_chunk  : 2 x n_z column-major -> measurement j is z[2*j + r]          (Update.cpp:85)
+ *   R_chunk  : 2 x 2n_z column-major -> R_j(r,c) is R[4*j + 2*c + r]        (Update.cpp:86)
+ * For batched calls every per-filter argument gains a leading [batch] dimension.
+ *
+ * Every function returns an int status (the reference has no error channel at all:
+ * kalmanfilter.h:29-32 are void).  Device work is asynchronous unless a function's comment says it
+ * synchronises.
+ */
+#ifndef EKFSLAM_C_H
+#define EKFSLAM_C_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EKF_OK 0
+#define EKF_ERR_BAD_ARG (-1)
+#define EKF_ERR_CAPACITY (-2)  /* a New landmark did not fit capacity_landmarks (sticky until ekf_set_state) */
+#define EKF_ERR_HIP (-3)       /* HIP runtime error, see ekf_last_error() */
+#define EKF_ERR_NO_DEVICE (-4) /* no usable gfx950 device: the product path has no CPU fallback */
+#define EKF_ERR_STATE (-5)     /* call not valid in the handle's current state */
+
+/* Gate decisions, as printed by Update.cpp:154,183,191 ("New " / "Old " / "Ignore "). */
+#define EKF_DECISION_NEW 1
+#define EKF_DECISION_OLD 2
+#define EKF_DECISION_IGNORE 3
+
+typedef struct ekf_batch *ekf_handle;
+
+/* Tunables; defaults equal the reference's literals. */
+typedef struct ekf_params {
+    double sigma_v;     /* 0.01  kalmanfilter.cpp:28 */
+    double sigma_w;     /* 0.04  kalmanfilter.cpp:29 */
+    double gamma_max;   /* 50    kalmanfilter.cpp:67 (int there) */
+    double gamma_min;   /* 10    kalmanfilter.cpp:68 (int there) */
+    double cond_limit;  /* 80    Update.cpp:131 */
+    int max_pending;    /* rank-2 updates deferred before one dense pass over P_LL; 1 = a dense
+                           pass per measurement as the reference does (Update.cpp:188).  1..8 */
+    int log_capacity;   /* decision-log entries kept per filter (ring) */
+} ekf_params;
+
+typedef struct ekf_decision {
+    int decision;    /* EKF_DECISION_* */
+    int matched;     /* the reference's Opt_i: 0-based state index 2*i+1 of the arg-min landmark, 0 if none (Update.cpp:101,143) */
+    double mahal;    /* the reference's Mahal_dist (Update.cpp:136,142); 999999999999 if none */
+} ekf_decision;
+
+typedef struct ekf_stats {
+    double nis_sum;   /* sum of accepted (Old) Mahalanobis distances = NIS, 2 dof */
+    double nees_sum;  /* sum of e^T P_RR^-1 e at every ekf_record_truth / scripted truth, 3 dof */
+    long long nis_count;
+    long long nees_count;
+    long long n_new, n_old, n_ignore;
+} ekf_stats;
+
+const char *ekf_last_error(void);
+void ekf_default_params(ekf_params *p);
+
+/* KalmanFilter::KalmanFilter, kalmanfilter.cpp:4-12: x = 0_3, P = 0_3x3, no landmarks.
+ * capacity_landmarks bounds N; all device memory is allocated here, none later. */
+int ekf_create(ekf_handle *out, int capacity_landmarks, int device_id, const ekf_params *params);
+int ekf_batch_create(ekf_handle *out, int batch, int capacity_landmarks, int device_id, const ekf_params *params);
+int ekf_destroy(ekf_handle h);
+int ekf_batch_size(ekf_handle h);
+int ekf_capacity(ekf_handle h);
+
+/* ---- single-filter calls (batch must be 1) ------------------------------------------------ */
+
+/* The arithmetic half of KalmanFilter::doPropagation, kalmanfilter.cpp:26-44: v in m/s, w in
+ * rad/s (the ARIA reads and unit conversions of :17-26 stay with the caller),
+ * Q = (v*v) * diag(sigma_v, sigma_w)^2, then Propagate. */
+int ekf_propagate(ekf_handle h, double v_mps, double w_radps, double dt);
+/* KalmanFilter::Propagate, Propagate.cpp:15-75 / kalmanfilter.h:40: Q is 2x2 column-major. */
+int ekf_propagate_q(ekf_handle h, double v, double w, const double Q[4], double dt);
+/* KalmanFilter::doUpdate -> Update, kalmanfilter.cpp:64-90 / Update.cpp:22-204, with Gamma and
+ * the condition limit taken from params.  decisions_out[n_z] may be NULL; when it is not, the call
+ * synchronises. */
+int ekf_update(ekf_handle h, const double *z_chunk, const double *R_chunk, int n_z, ekf_decision *decisions_out);
+/* KalmanFilter::doUpdateCompass, kalmanfilter.cpp:96-130. */
+int ekf_update_compass(ekf_handle h, double z, double R);
+/* The public mirrors X, Y, Phi, Num_Landmarks of kalmanfilter.h:24-27 (synchronises). */
+int ekf_get_pose(ekf_handle h, double pose_out[3]);
+int ekf_num_landmarks(ekf_handle h);  /* >= 0, or a negative status */
+
+/* ---- batched calls: arrays carry a leading [batch] dimension -------------------------------- */
+
+int ekf_batch_propagate(ekf_handle h, const double *v, const double *w, const double *dt);
+int ekf_batch_propagate_q(ekf_handle h, const double *v, const double *w, const double *Q /*[batch][4]*/, const double *dt);
+/* z [batch][n_z][2], R [batch][n_z][4], valid [batch][n_z] (NULL = all valid) selects which
+ * filters actually receive measurement j; decisions_out [batch][n_z] or NULL. */
+int ekf_batch_update(ekf_handle h, const double *z, const double *R, const unsigned char *valid, int n_z, ekf_decision *decisions_out);
+int ekf_batch_update_compass(ekf_handle h, const double *z, const double *R, const unsigned char *valid);
+int ekf_batch_get_pose(ekf_handle h, double *pose_out /*[batch][3]*/);
+int ekf_batch_num_landmarks(ekf_handle h, int *n_out /*[batch]*/);
+
+/* ---- state injection / extraction (tests, checkpoint/resume); both synchronise -------------- */
+
+/* Dense export of filter `index`: x_out[n], P_out n x n with leading dimension ld >= n.  Pass
+ * x_out = P_out = NULL to query the state size; returns n (>= 3) or a negative status. */
+int ekf_get_state(ekf_handle h, int index, double *x_out, double *P_out, int ld);
+/* Replace filter `index`'s state: n = 3 + 2*N, P must be symmetric. Clears a sticky capacity error. */
+int ekf_set_state(ekf_handle h, int index, const double *x, const double *P, int ld, int n);
+/* Copy filter 0's state into every other filter of the batch (device-side). */
+int ekf_broadcast_state(ekf_handle h);
+
+/* ---- device-resident step scripts (benchmarks, Monte-Carlo runs) ------------------------------
+ * A script is `steps` steps; step s of filter b is
+ *     Propagate(ctrl[s][b] = v, w, dt)  with Q from params as ekf_propagate does,
+ *     then M sequential single-measurement Updates z[s][m][b], R[s][m][b]  (slam.cpp:150-171),
+ *     then, when truth != NULL, one NEES sample against truth[s][b] = (x, y, phi).
+ * valid[s][m][b] (NULL = all) masks measurements.  Inputs are copied to HBM by ekf_script_load;
+ * ekf_script_run only enqueues kernels (no host->device traffic, no synchronisation). */
+int ekf_script_load(ekf_handle h, int steps, int M, const double *ctrl, const double *z, const double *R,
+                    const unsigned char *valid, const double *truth);
+/* use_graph != 0 replays the steps through captured HIP graphs. */
+int ekf_script_run(ekf_handle h, int first_step, int n_steps, int use_graph);
+
+/* ---- synchronisation, timing, diagnostics ---------------------------------------------------- */
+
+int ekf_sync(ekf_handle h);  /* waits for the stream, returns a sticky error (EKF_ERR_CAPACITY) if any filter raised one */
+/* Flush deferred rank-2 updates into P_LL now (asynchronous). */
+int ekf_flush(ekf_handle h);
+/* hipEvent pair on the handle's stream. stop synchronises and returns elapsed milliseconds. */
+int ekf_timer_start(ekf_handle h);
+int ekf_timer_stop(ekf_handle h, double *ms_out);
+/* Per-launch timing of the dense P_LL pass (the dominant kernel): when enabled every launch is
+ * bracketed by hipEvents on the handle's stream. ekf_flush_profile_read synchronises. */
+int ekf_flush_profile(ekf_handle h, int enable);
+int ekf_flush_profile_read(ekf_handle h, long long *launches_out, double *total_ms_out);
+/* The last `count` decision-log entries of filter `index`, oldest first (synchronises). Returns the number written. */
+int ekf_get_decisions(ekf_handle h, int index, ekf_decision *out, int count);
+int ekf_get_stats(ekf_handle h, ekf_stats *out /*[batch]*/);
+int ekf_reset_stats(ekf_handle h);
+/* One NEES sample against a ground-truth pose, truth [batch][3]. */
+int ekf_record_truth(ekf_handle h, const double *truth);
+/* The HIP stream (hipStream_t) the handle launches on, for callers that want to order their own work. */
+void *ekf_stream(ekf_handle h);
+/* Bytes of HBM held by the handle. */
+size_t ekf_device_bytes(ekf_handle h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
