@@ -1,0 +1,288 @@
+"""GPU parity tests: the HIP path, called through the C ABI (include/ekfslam_c.h), against the CPU
+oracle on the same inputs.  Tolerance: north_star's 1e-6 relative on x and P (helpers.py makes it
+well defined); association decisions and matched indices must be identical.  Run with -m gpu."""
+import numpy as np
+import pytest
+
+from helpers import assert_bitwise_symmetric, assert_state_close
+from test_oracle import COMP, PROP, UPD, load_golden, split_update_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+def R_blocks(R_chunk, n_z):
+    return np.stack([R_chunk[:, 2 * j:2 * j + 2] for j in range(n_z)]).reshape(1, n_z, 2, 2)
+
+
+@pytest.mark.parametrize("max_pending", [1, 4])
+def test_golden_sequences(pkg, max_pending):
+    """Every committed golden sequence (KA1..KA8, chunks, lifecycles), state compared after every op."""
+    for s in load_golden():
+        f = pkg.FilterBatch(1, 16, max_pending=max_pending)
+        f.set_state(s["x0"], s["P0"])
+        for k, op in enumerate(s["ops"]):
+            kind = int(op["kind"])
+            if kind == PROP:
+                v, w, dt = op["inp"][0:3]
+                Q = np.array([[op["inp"][3], op["inp"][5]], [op["inp"][4], op["inp"][6]]])
+                f.propagate_q(v, w, Q, dt)
+            elif kind == UPD:
+                z, R = split_update_inputs(op["inp"])
+                n_z = z.shape[1]
+                dec = f.update(z.T.reshape(1, n_z, 2), R_blocks(R, n_z))[0]
+                assert [d[0] for d in dec] == [int(d) for d in op["dec"][:, 0]], (s["name"], k, dec, op["dec"])
+                assert [d[1] for d in dec] == [int(d) for d in op["dec"][:, 1]], (s["name"], k, dec, op["dec"])
+                assert np.allclose([d[2] for d in dec], op["dec"][:, 2], rtol=1e-6, atol=1e-9), (s["name"], k)
+            else:
+                f.update_compass(op["inp"][0], op["inp"][1])
+            xg, Pg = f.get_state()
+            assert_state_close(xg, Pg, op["x"], op["P"], "%s op %d" % (s["name"], k))
+            assert_bitwise_symmetric(Pg)
+        f.close()
+
+
+@pytest.mark.parametrize("max_pending", [1, 3, 4])
+def test_lifecycle_n50_lockstep(pkg, oc, max_pending):
+    """Config 1: from x = 0_3, P = 0 (kalmanfilter.cpp:10-11), N grows towards 50; New/Old/Ignore all
+    occur; the KalmanFilter mirror is driven exactly as slam.cpp:130-171 drives the reference."""
+    script = pkg.scenarios.lifecycle_script(steps=400, compass_every=11)
+    kf = pkg.KalmanFilter(capacity_landmarks=64, max_pending=max_pending)
+    x, P = np.zeros(3), np.zeros((3, 3))
+    hist = {1: 0, 2: 0, 3: 0}
+    for i, st in enumerate(script):
+        rot_deg = st["w"] * 180.0 / 3.141592654
+        kf.doPropagation(st["dt"], st["v"] * 1000.0, rot_deg)
+        v, w = (st["v"] * 1000.0) / 1000.0, rot_deg * 3.141592654 / 180.0
+        x, P = oc.propagate(x, P, v, w, oc.make_Q(v), st["dt"])
+        if st["compass"] is not None:
+            kf.doUpdateCompass(st["compass"], 0.0005)
+            x, P = oc.compass(x, P, st["compass"], 0.0005)
+        for fx, fy in st["feats_mm"]:
+            z, R = oc.make_measurement(fx, fy)
+            kf.doUpdate(z.reshape(2, 1), R)
+            x, P, dec, mat, mah = oc.update(x, P, z.reshape(2, 1), R)
+            g = kf.last_decisions[0]
+            assert (g[0], g[1]) == (dec[0], mat[0]), (i, g, dec, mat, mah)
+            hist[dec[0]] += 1
+        assert kf.Num_Landmarks == (x.size - 3) // 2
+        assert abs(kf.X - x[0]) < 1e-9 and abs(kf.Y - x[1]) < 1e-9 and abs(kf.Phi - x[2]) < 1e-9
+        if i % 50 == 49:
+            xg, Pg = kf.state()
+            assert_state_close(xg, Pg, x, P, "step %d" % i)
+    xg, Pg = kf.state()
+    assert_state_close(xg, Pg, x, P, "final")
+    assert_bitwise_symmetric(Pg)
+    assert hist[1] >= 15 and hist[2] >= 300, hist
+
+
+def run_oracle_script(oc, x, P, sc, steps, M):
+    decs = []
+    for s in range(steps):
+        v, w, dt = sc["ctrl"][s]
+        x, P = oc.propagate(x, P, v, w, oc.make_Q(v), dt)
+        for m in range(M):
+            x, P, dec, mat, _ = oc.update(x, P, sc["z"][s, m].reshape(2, 1), sc["R"][s, m].reshape(2, 2, order="F"))
+            decs.append((dec[0], mat[0]))
+    return x, P, decs
+
+
+def load_script(f, sc, B=1):
+    ctrl = sc["ctrl"][:, None, :].repeat(B, axis=1)
+    z = sc["z"][:, :, None, :].repeat(B, axis=2)
+    R = sc["R"][:, :, None, :].repeat(B, axis=2)
+    truth = sc["truth"][:, None, :].repeat(B, axis=1)
+    f.script_load(ctrl, z, R, truth=truth)
+
+
+@pytest.mark.parametrize("N,steps,max_pending,graph", [(256, 12, 4, False), (256, 12, 4, True), (256, 12, 1, False),
+                                                       (256, 9, 3, True), (1024, 4, 4, False)])
+def test_steady_script_vs_oracle(pkg, oc, N, steps, max_pending, graph):
+    """Configs 2/4 shape: injected state, scripted steps of 1 propagate + 4 Old updates, no host traffic."""
+    M = 4
+    x0, P0 = pkg.scenarios.injected_state(N, seed=20260002)
+    sc = pkg.scenarios.steady_script(x0, steps=steps, M=M, seed=7)
+    f = pkg.FilterBatch(1, N, max_pending=max_pending)
+    f.set_state(x0, P0)
+    load_script(f, sc)
+    f.script_run(0, steps, use_graph=graph)
+    f.sync()
+    xg, Pg = f.get_state()
+    xo, Po, decs = run_oracle_script(oc, x0, P0, sc, steps, M)
+    gdec = f.decisions(0, steps * M)
+    assert [(d[0], d[1]) for d in gdec] == decs
+    assert all(d[0] == pkg.ekfslam.OLD for d in gdec)
+    assert [d[1] for d in gdec] == [3 + 2 * int(t) for t in sc["target"].ravel()]
+    assert_state_close(xg, Pg, xo, Po, "N=%d" % N)
+    assert_bitwise_symmetric(Pg)
+    st = f.stats()[0]
+    assert st["n_old"] == steps * M and st["nis_count"] == steps * M and st["nees_count"] == steps
+    assert st["nees_sum"] >= 0 and np.isfinite(st["nees_sum"])
+    f.close()
+
+
+def test_n4096_one_step_vs_oracle(pkg, oc):
+    """Config 3 size (dense P = 8195 x 8195 fp64, 537 MB): one full step against the oracle."""
+    N, M = 4096, 4
+    x0, P0 = pkg.scenarios.injected_state(N, seed=20260003)
+    sc = pkg.scenarios.steady_script(x0, steps=1, M=M, seed=8)
+    f = pkg.FilterBatch(1, N, max_pending=4)
+    f.set_state(x0, P0)
+    load_script(f, sc)
+    f.script_run(0, 1)
+    f.sync()
+    xg, Pg = f.get_state()
+    xo, Po, decs = run_oracle_script(oc, x0, P0, sc, 1, M)
+    assert [(d[0], d[1]) for d in f.decisions(0, M)] == decs
+    assert_state_close(xg, Pg, xo, Po, "N=4096")
+    assert_bitwise_symmetric(Pg)
+    f.close()
+
+
+def test_size_independent_properties_n4096(pkg):
+    """Full-size checks that need no oracle: eager (a dense pass per measurement, as Update.cpp:188
+    does) and deferred (one dense pass per step) agree; graph replay is bit-identical to plain
+    launches; P stays symmetric with a shrinking trace."""
+    N, M, steps = 4096, 4, 8
+    x0, P0 = pkg.scenarios.injected_state(N, seed=20260003)
+    sc = pkg.scenarios.steady_script(x0, steps=steps, M=M, seed=9)
+    outs = []
+    for max_pending, graph in [(1, False), (4, False), (4, True)]:
+        f = pkg.FilterBatch(1, N, max_pending=max_pending)
+        f.set_state(x0, P0)
+        load_script(f, sc)
+        f.script_run(0, steps, use_graph=graph)
+        f.sync()
+        outs.append(f.get_state() + (f.decisions(0, steps * M),))
+        f.close()
+    (xe, Pe, de), (xd, Pd, dd), (xq, Pq, dq) = outs
+    key = lambda ds: [(d[0], d[1]) for d in ds]
+    assert key(de) == key(dd) and dd == dq
+    assert np.allclose([d[2] for d in de], [d[2] for d in dd], rtol=1e-9, atol=1e-12)
+    assert all(d[0] == pkg.ekfslam.OLD for d in de)
+    assert [d[1] for d in de] == [3 + 2 * int(t) for t in sc["target"].ravel()]
+    assert np.array_equal(xd, xq) and np.array_equal(Pd, Pq)
+    assert np.abs(xe - xd).max() <= 1e-12 * np.abs(xe).max()
+    assert np.abs(Pe - Pd).max() <= 1e-12 * np.abs(Pe).max()
+    assert_bitwise_symmetric(Pd)
+    assert np.all(np.diag(Pd) > 0)
+    assert np.trace(Pd) < np.trace(P0) + 1e-3  # process noise is tiny here; updates remove information
+
+
+def test_batch_lockstep_with_masks(pkg, oc):
+    """B independent filters behind one handle (config 4's shape, small): different maps, different
+    measurement counts per filter (valid masks), compared filter by filter."""
+    B, N = 5, 48
+    f = pkg.FilterBatch(B, N + 8, max_pending=4)
+    xs, Ps, scs = [], [], []
+    for b in range(B):
+        x0, P0 = pkg.scenarios.injected_state(N, seed=100 + b, extent=15.0)
+        f.set_state(x0, P0, index=b)
+        xs.append(x0), Ps.append(P0)
+        scs.append(pkg.scenarios.steady_script(x0, steps=6, M=3, seed=200 + b, min_separation=0.8))
+    rng = np.random.default_rng(5)
+    for s in range(6):
+        ctrl = np.stack([sc["ctrl"][s] for sc in scs])
+        f.propagate(ctrl[:, 0], ctrl[:, 1], ctrl[:, 2])
+        valid = rng.random((B, 3)) > 0.25
+        z = np.stack([sc["z"][s] for sc in scs])
+        R = np.stack([sc["R"][s].reshape(3, 2, 2).transpose(0, 2, 1) for sc in scs])
+        gdec = f.update(z, R, valid=valid)
+        if s % 2 == 1:
+            f.update_compass(np.array([x[2] for x in xs]) + 0.01, 0.0005, valid=valid[:, 0])
+        for b in range(B):
+            v, w, dt = ctrl[b]
+            xs[b], Ps[b] = oc.propagate(xs[b], Ps[b], v, w, oc.make_Q(v), dt)
+            zs = [j for j in range(3) if valid[b, j]]
+            if zs:
+                zc = np.stack([z[b, j] for j in zs], axis=1)
+                Rc = np.concatenate([R[b, j] for j in zs], axis=1)
+                xs[b], Ps[b], dec, mat, _ = oc.update(xs[b], Ps[b], zc, Rc)
+    # the oracle above applied each filter's valid measurements as ONE chunk; the GPU got them as a
+    # chunk with holes -- identical as long as no New happened inside a chunk (Update.cpp:26); assert that
+    for b in range(B):
+        xg, Pg = f.get_state(b)
+        assert xg.size == xs[b].size
+        assert_state_close(xg, Pg, xs[b], Ps[b], "filter %d" % b)
+    f.close()
+
+
+def test_batch_compass_and_update_order(pkg, oc):
+    B, N = 3, 20
+    f = pkg.FilterBatch(B, N + 4)
+    xs, Ps = [], []
+    for b in range(B):
+        x0, P0 = pkg.scenarios.injected_state(N, seed=300 + b, extent=10.0)
+        f.set_state(x0, P0, index=b)
+        xs.append(x0), Ps.append(P0)
+    zc = np.array([0.31, 0.29, 6.5])
+    f.update_compass(zc, 0.0005)
+    f.propagate(0.3, 0.05, 0.05)
+    for b in range(B):
+        xs[b], Ps[b] = oc.compass(xs[b], Ps[b], zc[b], 0.0005)
+        xs[b], Ps[b] = oc.propagate(xs[b], Ps[b], 0.3, 0.05, oc.make_Q(0.3), 0.05)
+        xg, Pg = f.get_state(b)
+        assert_state_close(xg, Pg, xs[b], Ps[b], "filter %d" % b)
+    poses = f.poses()
+    assert np.allclose(poses, np.stack([x[0:3] for x in xs]), rtol=0, atol=1e-12)
+    f.close()
+
+
+def test_set_get_roundtrip_bitwise(pkg):
+    for N in (1, 31, 32, 33, 100):
+        x0, P0 = pkg.scenarios.injected_state(N, seed=N)
+        f = pkg.FilterBatch(1, 128)
+        f.set_state(x0, P0)
+        xg, Pg = f.get_state()
+        assert np.array_equal(xg, x0) and np.array_equal(Pg, P0)
+        f.close()
+
+
+def test_empty_and_edge_inputs(pkg, oc):
+    kf = pkg.KalmanFilter(capacity_landmarks=4)
+    # compass and propagate on the empty map, n = 3
+    kf.doPropagation(0.1, 300.0, 5.0)
+    kf.doUpdateCompass(0.02, 0.0005)
+    x, P = oc.propagate(np.zeros(3), np.zeros((3, 3)), 0.3, 5.0 * 3.141592654 / 180.0, oc.make_Q(0.3), 0.1)
+    x, P = oc.compass(x, P, 0.02, 0.0005)
+    xg, Pg = kf.state()
+    assert_state_close(xg, Pg, x, P, "empty map")
+    # an empty chunk is a no-op
+    kf._f.update(np.zeros((1, 0, 2)), np.zeros((1, 0, 2, 2)))
+    xg2, Pg2 = kf.state()
+    assert np.array_equal(xg, xg2) and np.array_equal(Pg, Pg2)
+    # v = 0 => Q = 0 (kalmanfilter.cpp:37)
+    kf.doPropagation(0.1, 0.0, 0.0)
+    x, P = oc.propagate(x, P, 0.0, 0.0, oc.make_Q(0.0), 0.1)
+    xg, Pg = kf.state()
+    assert_state_close(xg, Pg, x, P, "v=0")
+
+
+def test_capacity_overflow_is_reported(pkg):
+    kf = pkg.KalmanFilter(capacity_landmarks=2)
+    kf.doPropagation(0.1, 300.0, 0.0)
+    for k, (fx, fy) in enumerate([(2000.0, 0.0), (0.0, 3000.0), (-2500.0, 500.0)]):
+        z, R = pkg.scenarios.measurement_from_feature_mm(fx, fy)
+        if k < 2:
+            kf.doUpdate(z.reshape(2, 1), R)
+        else:
+            kf._f.update(z.reshape(1, 1, 2), R.reshape(1, 1, 2, 2), want_decisions=False)
+    assert kf._f.num_landmarks()[0] == 2
+    with pytest.raises(pkg.EkfError) as ei:
+        kf._f.sync()
+    assert ei.value.code == pkg.ekfslam.ERR_CAPACITY
+    # state injection clears the sticky error
+    x, P = kf.state()
+    kf.set_state(x, P)
+    kf._f.sync()
+
+
+def test_bad_arguments(pkg):
+    f = pkg.FilterBatch(2, 8)
+    L = f.L
+    assert L.ekf_propagate(f.h, 0.1, 0.1, 0.1) == pkg.ekfslam.ERR_BAD_ARG  # single-filter call on a batch
+    assert L.ekf_get_state(f.h, 5, None, None, 0) == pkg.ekfslam.ERR_BAD_ARG
+    assert L.ekf_script_run(f.h, 0, 1, 0) == pkg.ekfslam.ERR_STATE
+    x0, P0 = pkg.scenarios.injected_state(20, seed=1)
+    with pytest.raises(pkg.EkfError):
+        f.set_state(x0, P0)  # larger than capacity
+    f.close()
