@@ -43,11 +43,21 @@ struct ekf_batch {
     EkfDev dv;
     ekf_params params;
     int device;
-    hipStream_t stream;
+    hipStream_t s_chain;  // k_chain launches (high priority: short, latency-critical)
+    hipStream_t s_flush;  // the dense pass streams through HBM underneath
+    hipEvent_t ev_chain;  // "the chain has finished writing the set being closed"
+    hipEvent_t ev_flush[2];  // "the dense pass that consumed set s has finished"
+    bool flush_valid[2];
+    hipEvent_t ev_join;
     size_t device_bytes;
+    int chain_threads;
     // host-side tracking
-    int n_lm_hi;   // upper bound on max_b n_lm[b]
-    int pending;   // deferred rank-2 slots in use
+    int n_lm_hi;    // upper bound on max_b n_lm[b]
+    int cur_set;    // slot set being filled
+    int pending;    // slots used in cur_set
+    int buf_in;     // Bm buffer the NEXT dense pass reads
+    bool inflight;  // a dense pass may still be running: the chain reads its input buffer + its slot set
+    int prev_count; // slots in the set that pass is consuming
     // immediate-mode input ring (host-mapped pinned)
     double *ring_h;
     double *ring_d;
@@ -118,7 +128,10 @@ extern "C" int ekf_batch_create(ekf_handle *out, int batch, int capacity_landmar
     if (h->params.log_capacity < 16) h->params.log_capacity = 16;
     h->device = device_id;
     h->device_bytes = 0;
-    HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    int prio_lo = 0, prio_hi = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+    HIP_TRY(hipStreamCreateWithPriority(&h->s_chain, hipStreamNonBlocking, prio_hi));
+    HIP_TRY(hipStreamCreateWithPriority(&h->s_flush, hipStreamNonBlocking, prio_lo));
 
     EkfDev &dv = h->dv;
     memset(&dv, 0, sizeof dv);
@@ -129,26 +142,27 @@ extern "C" int ekf_batch_create(ekf_handle *out, int batch, int capacity_landmar
     dv.dn = 32 * dv.T;
     dv.maxp = h->params.max_pending;
     dv.logcap = h->params.log_capacity;
-    dv.nblk_sweep = (capacity_landmarks + EKF_SWEEP_THREADS - 1) / EKF_SWEEP_THREADS;
     dv.bm_stride = (size_t)dv.T * (dv.T + 1) / 2 * 4096;
     dv.f_stride = (size_t)4 * dv.T * dv.maxp * 64;
     dv.gamma_max = h->params.gamma_max;
     dv.gamma_min = h->params.gamma_min;
     dv.cond_limit = h->params.cond_limit;
+    h->chain_threads = (capacity_landmarks + 63) / 64 * 64;
+    if (h->chain_threads > EKF_CHAIN_MAX_THREADS) h->chain_threads = EKF_CHAIN_MAX_THREADS;
     size_t B = batch;
-    hipStream_t s = h->stream;
+    hipStream_t s = h->s_chain;
     HIP_TRY(dev_alloc_zero(&dv.x, B * dv.xs, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.R, B * 3 * dv.xs, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.D, B * 3 * dv.dn, &h->device_bytes, s));
-    HIP_TRY(dev_alloc_zero(&dv.Bm, B * dv.bm_stride, &h->device_bytes, s));
-    HIP_TRY(dev_alloc_zero(&dv.F, B * dv.f_stride, &h->device_bytes, s));
+    HIP_TRY(dev_alloc_zero(&dv.Bm[0], B * dv.bm_stride, &h->device_bytes, s));
+    HIP_TRY(dev_alloc_zero(&dv.Bm[1], B * dv.bm_stride, &h->device_bytes, s));
+    HIP_TRY(dev_alloc_zero(&dv.FA, B * 2 * dv.f_stride, &h->device_bytes, s));
+    HIP_TRY(dev_alloc_zero(&dv.FB, B * 2 * dv.f_stride, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.n_lm, B, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.n_lm_sweep, B, &h->device_bytes, s));
+    HIP_TRY(dev_alloc_zero(&dv.n_lm_flush, B * 2, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.status, B, &h->device_bytes, s));
-    HIP_TRY(dev_alloc_zero(&dv.slot_active, B * dv.maxp, &h->device_bytes, s));
-    HIP_TRY(dev_alloc_zero(&dv.hdr, B, &h->device_bytes, s));
-    HIP_TRY(dev_alloc_zero(&dv.phdr, B, &h->device_bytes, s));
-    HIP_TRY(dev_alloc_zero(&dv.part, B * dv.nblk_sweep, &h->device_bytes, s));
+    HIP_TRY(dev_alloc_zero(&dv.slot_active, B * 2 * dv.maxp, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.log, B * dv.logcap, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.log_count, B, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.stats, B, &h->device_bytes, s));
@@ -157,7 +171,7 @@ extern "C" int ekf_batch_create(ekf_handle *out, int batch, int capacity_landmar
     size_t rec_bytes = B * 8 * sizeof(double);
     long ring_ops = (long)((16u << 20) / rec_bytes);
     if (ring_ops > 1024) ring_ops = 1024;
-    if (ring_ops < 32) ring_ops = 32;
+    if (ring_ops < 2 * EKF_CHAIN_MAX_OPS) ring_ops = 2 * EKF_CHAIN_MAX_OPS;
     h->ring_ops = (int)ring_ops;
     HIP_TRY(hipHostMalloc((void **)&h->ring_h, rec_bytes * h->ring_ops, hipHostMallocMapped));
     HIP_TRY(hipHostGetDevicePointer((void **)&h->ring_d, h->ring_h, 0));
@@ -165,7 +179,11 @@ extern "C" int ekf_batch_create(ekf_handle *out, int batch, int capacity_landmar
     for (int i = 0; i < 2; i++) {
         HIP_TRY(hipEventCreateWithFlags(&h->ring_ev[i], hipEventDisableTiming));
         h->ring_ev_valid[i] = false;
+        HIP_TRY(hipEventCreateWithFlags(&h->ev_flush[i], hipEventDisableTiming));
+        h->flush_valid[i] = false;
     }
+    HIP_TRY(hipEventCreateWithFlags(&h->ev_chain, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     HIP_TRY(hipEventCreate(&h->t0));
     HIP_TRY(hipEventCreate(&h->t1));
     h->prof_flush = false;
@@ -173,11 +191,15 @@ extern "C" int ekf_batch_create(ekf_handle *out, int batch, int capacity_landmar
     h->prof_launches = 0;
     h->prof_ms = 0;
     h->n_lm_hi = 0;
+    h->cur_set = 0;
     h->pending = 0;
+    h->buf_in = 0;
+    h->inflight = false;
+    h->prev_count = 0;
     h->script_d = nullptr;
     h->script_steps = h->script_M = h->script_has_truth = 0;
     h->h_int.resize(B);
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipStreamSynchronize(h->s_chain));
     *out = h;
     return EKF_OK;
 }
@@ -189,127 +211,32 @@ extern "C" int ekf_create(ekf_handle *out, int capacity_landmarks, int device_id
 extern "C" int ekf_destroy(ekf_handle h) {
     if (!h) return EKF_OK;
     hipSetDevice(h->device);
-    hipStreamSynchronize(h->stream);
+    hipStreamSynchronize(h->s_chain);
+    hipStreamSynchronize(h->s_flush);
     for (auto &g : h->graphs) hipGraphExecDestroy(g.exec);
     EkfDev &dv = h->dv;
-    hipFree(dv.x), hipFree(dv.R), hipFree(dv.D), hipFree(dv.Bm), hipFree(dv.F);
-    hipFree(dv.n_lm), hipFree(dv.n_lm_sweep), hipFree(dv.status), hipFree(dv.slot_active);
-    hipFree(dv.hdr), hipFree(dv.phdr), hipFree(dv.part), hipFree(dv.log), hipFree(dv.log_count), hipFree(dv.stats);
+    hipFree(dv.x), hipFree(dv.R), hipFree(dv.D), hipFree(dv.Bm[0]), hipFree(dv.Bm[1]), hipFree(dv.FA), hipFree(dv.FB);
+    hipFree(dv.n_lm), hipFree(dv.n_lm_sweep), hipFree(dv.n_lm_flush), hipFree(dv.status), hipFree(dv.slot_active);
+    hipFree(dv.log), hipFree(dv.log_count), hipFree(dv.stats);
     hipFree(h->cursor_d);
     if (h->script_d) hipFree(h->script_d);
     hipHostFree(h->ring_h);
-    for (int i = 0; i < 2; i++) hipEventDestroy(h->ring_ev[i]);
+    for (int i = 0; i < 2; i++) hipEventDestroy(h->ring_ev[i]), hipEventDestroy(h->ev_flush[i]);
+    hipEventDestroy(h->ev_chain), hipEventDestroy(h->ev_join);
     hipEventDestroy(h->t0), hipEventDestroy(h->t1);
     for (auto e : h->prof_pool) hipEventDestroy(e);
-    hipStreamDestroy(h->stream);
+    hipStreamDestroy(h->s_chain);
+    hipStreamDestroy(h->s_flush);
     delete h;
     return EKF_OK;
 }
 
 extern "C" int ekf_batch_size(ekf_handle h) { return h ? h->dv.B : EKF_ERR_BAD_ARG; }
 extern "C" int ekf_capacity(ekf_handle h) { return h ? h->dv.Ncap : EKF_ERR_BAD_ARG; }
-extern "C" void *ekf_stream(ekf_handle h) { return h ? (void *)h->stream : nullptr; }
+extern "C" void *ekf_stream(ekf_handle h) { return h ? (void *)h->s_chain : nullptr; }
 extern "C" size_t ekf_device_bytes(ekf_handle h) { return h ? h->device_bytes : 0; }
 
-// ---- input ring ---------------------------------------------------------------------------------
-// Returns the record index to hand to the kernels; *rec points at the B*8 doubles to fill.
-static int ring_acquire(ekf_batch *h, double **rec, int *k_out) {
-    int half = h->ring_ops / 2;
-    int pos = h->ring_pos;
-    if (pos == 0 || pos == half) {
-        // entering a half: everything launched against it one lap ago must have finished
-        int which = (pos == 0) ? 0 : 1;
-        if (h->ring_ev_valid[which]) HIP_TRY(hipEventSynchronize(h->ring_ev[which]));
-    }
-    *rec = h->ring_h + (size_t)pos * h->dv.B * 8;
-    *k_out = pos;
-    return EKF_OK;
-}
-
-static int ring_commit(ekf_batch *h) {
-    int half = h->ring_ops / 2;
-    int pos = h->ring_pos + 1;
-    if (pos == half) {
-        HIP_TRY(hipEventRecord(h->ring_ev[0], h->stream));
-        h->ring_ev_valid[0] = true;
-    } else if (pos == 2 * half) {
-        HIP_TRY(hipEventRecord(h->ring_ev[1], h->stream));
-        h->ring_ev_valid[1] = true;
-        pos = 0;
-    }
-    h->ring_pos = pos;
-    return EKF_OK;
-}
-
-// ---- enqueue helpers (no synchronisation) -------------------------------------------------------
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
-
-static int enqueue_flush(ekf_batch *h, int n_lm_bound) {
-    if (h->pending == 0) return EKF_OK;
-    int nT_hi = (2 * n_lm_bound + 63) / 64;
-    if (nT_hi > 0) {
-        int total = nT_hi * (nT_hi + 1) / 2;
-        dim3 grid(cdiv(total, 4), h->dv.B);
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (h->prof_flush) {
-            while (h->prof_pool.size() < h->prof_used + 2) {
-                hipEvent_t e;
-                HIP_TRY(hipEventCreate(&e));
-                h->prof_pool.push_back(e);
-            }
-            e0 = h->prof_pool[h->prof_used++];
-            e1 = h->prof_pool[h->prof_used++];
-            HIP_TRY(hipEventRecord(e0, h->stream));
-        }
-        hipLaunchKernelGGL(k_flush, grid, dim3(256), 0, h->stream, h->dv, nT_hi, h->pending);
-        if (h->prof_flush) HIP_TRY(hipEventRecord(e1, h->stream));
-    }
-    h->pending = 0;
-    return EKF_OK;
-}
-
-static int slot_take(ekf_batch *h, int n_lm_bound, int *slot) {
-    if (h->pending >= h->dv.maxp) {
-        int rc = enqueue_flush(h, n_lm_bound);
-        if (rc) return rc;
-    }
-    *slot = h->pending;
-    return EKF_OK;
-}
-
-static int slot_done(ekf_batch *h, int n_lm_bound) {
-    h->pending++;
-    if (h->pending >= h->dv.maxp) return enqueue_flush(h, n_lm_bound);
-    return EKF_OK;
-}
-
-static void enqueue_propagate(ekf_batch *h, const double *in, const int *cursor, int k, int n_lm_bound) {
-    hipLaunchKernelGGL(k_prop_head, dim3(h->dv.B), dim3(64), 0, h->stream, h->dv, in, cursor, k);
-    if (n_lm_bound > 0)
-        hipLaunchKernelGGL(k_prop_cols, dim3(cdiv(2 * n_lm_bound, 256), h->dv.B), dim3(256), 0, h->stream, h->dv);
-}
-
-// one single-measurement Update (sweep -> decide -> apply); *n_lm_bound grows by one
-static int enqueue_measurement(ekf_batch *h, const double *in, const int *cursor, int k, int last_in_chunk, int *n_lm_bound, bool bound_is_capacity) {
-    int slot;
-    int rc = slot_take(h, *n_lm_bound, &slot);
-    if (rc) return rc;
-    int nblk = cdiv(*n_lm_bound, EKF_SWEEP_THREADS);
-    if (nblk > 0) hipLaunchKernelGGL(k_sweep, dim3(nblk, h->dv.B), dim3(EKF_SWEEP_THREADS), 0, h->stream, h->dv, in, cursor, k);
-    hipLaunchKernelGGL(k_decide, dim3(h->dv.B), dim3(64), 0, h->stream, h->dv, in, cursor, k, nblk, slot, last_in_chunk);
-    if (!bound_is_capacity && *n_lm_bound < h->dv.Ncap) (*n_lm_bound)++;
-    if (*n_lm_bound > 0) hipLaunchKernelGGL(k_apply, dim3(cdiv(*n_lm_bound, 256), h->dv.B), dim3(256), 0, h->stream, h->dv, slot);
-    return slot_done(h, *n_lm_bound);
-}
-
-static int enqueue_compass(ekf_batch *h, const double *in, const int *cursor, int k, int n_lm_bound) {
-    int slot;
-    int rc = slot_take(h, n_lm_bound, &slot);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_compass_head, dim3(h->dv.B), dim3(64), 0, h->stream, h->dv, in, cursor, k, slot);
-    if (n_lm_bound > 0) hipLaunchKernelGGL(k_apply, dim3(cdiv(n_lm_bound, 256), h->dv.B), dim3(256), 0, h->stream, h->dv, slot);
-    return slot_done(h, n_lm_bound);
-}
 
 static int check_launch() {
     hipError_t e = hipGetLastError();
@@ -321,9 +248,111 @@ static int check_launch() {
     return EKF_OK;
 }
 
-static int refresh_bounds(ekf_batch *h) {  // synchronises
-    HIP_TRY(hipMemcpyAsync(h->h_int.data(), h->dv.n_lm, sizeof(int) * h->dv.B, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+// ---- the two-stream pipeline -----------------------------------------------------------------------
+// Close the slot set being filled: hand it to a dense pass on s_flush (Bm[buf_in] -> Bm[buf_in^1]) and
+// let the chain continue into the other set, reading the pass's INPUT buffer plus the closed set.
+static int close_set(ekf_batch *h) {
+    if (h->pending == 0) return EKF_OK;
+    int nT_hi = (2 * h->n_lm_hi + 63) / 64;
+    HIP_TRY(hipEventRecord(h->ev_chain, h->s_chain));
+    HIP_TRY(hipStreamWaitEvent(h->s_flush, h->ev_chain, 0));
+    if (nT_hi > 0) {
+        int total = nT_hi * (nT_hi + 1) / 2;
+        dim3 grid(cdiv(total, 4), h->dv.B);
+        if (h->prof_flush) {
+            while (h->prof_pool.size() < h->prof_used + 2) {
+                hipEvent_t e;
+                HIP_TRY(hipEventCreate(&e));
+                h->prof_pool.push_back(e);
+            }
+            hipEvent_t e0 = h->prof_pool[h->prof_used++], e1 = h->prof_pool[h->prof_used++];
+            // start/stop events ride on the dispatch packet itself: no extra barrier packets
+            hipExtLaunchKernelGGL(k_flush, grid, dim3(256), 0, h->s_flush, e0, e1, 0, h->dv, nT_hi, h->cur_set, h->pending, h->buf_in);
+        } else {
+            hipLaunchKernelGGL(k_flush, grid, dim3(256), 0, h->s_flush, h->dv, nT_hi, h->cur_set, h->pending, h->buf_in);
+        }
+    }
+    HIP_TRY(hipEventRecord(h->ev_flush[h->cur_set], h->s_flush));
+    h->flush_valid[h->cur_set] = true;
+    h->prev_count = h->pending;
+    h->buf_in ^= 1;
+    h->cur_set ^= 1;
+    h->pending = 0;
+    h->inflight = true;
+    // the chain may now write set cur_set and read Bm[buf_in ^ 1]; both need the dense pass that
+    // consumed set cur_set (two closes ago) to have finished
+    if (h->flush_valid[h->cur_set]) HIP_TRY(hipStreamWaitEvent(h->s_chain, h->ev_flush[h->cur_set], 0));
+    return check_launch();
+}
+
+// Everything folded into Bm[buf_in], both streams idle.
+static int settle(ekf_batch *h) {
+    int rc = close_set(h);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(h->s_chain));
+    HIP_TRY(hipStreamSynchronize(h->s_flush));
+    h->inflight = false;
+    h->flush_valid[0] = h->flush_valid[1] = false;
+    return EKF_OK;
+}
+
+// Launch k_chain over ops [k0, k0 + nops) of `in`, cutting at slot-set boundaries.
+// consumes[i] != 0 when op i takes a slot (measurement, masked measurement, compass).
+static int launch_ops(ekf_batch *h, const double *in, const int *cursor, int k0, const unsigned char *consumes, int nops) {
+    int i = 0;
+    while (i < nops) {
+        int start = i, used = h->pending;
+        while (i < nops && i - start < EKF_CHAIN_MAX_OPS) {
+            if (consumes[i]) {
+                if (used == h->dv.maxp) break;
+                used++;
+            }
+            i++;
+        }
+        if (i == start) {  // set already full (cannot happen: sets are closed as soon as they fill)
+            int rc = close_set(h);
+            if (rc) return rc;
+            continue;
+        }
+        hipLaunchKernelGGL(k_chain, dim3(h->dv.B), dim3(h->chain_threads), 0, h->s_chain, h->dv, in, cursor, k0 + start, i - start,
+                           h->pending, h->cur_set, h->inflight ? (h->buf_in ^ 1) : h->buf_in, h->inflight ? h->prev_count : 0);
+        h->pending = used;
+        if (used == h->dv.maxp) {
+            int rc = close_set(h);
+            if (rc) return rc;
+        }
+    }
+    return check_launch();
+}
+
+static void bump_bound(ekf_batch *h, int measurements) {
+    h->n_lm_hi += measurements;
+    if (h->n_lm_hi > h->dv.Ncap) h->n_lm_hi = h->dv.Ncap;
+}
+
+// ---- input ring ---------------------------------------------------------------------------------
+// Reserve `count` consecutive records (never straddling the wrap); *rec points at the first.
+static int ring_reserve(ekf_batch *h, int count, double **rec, int *k_out) {
+    int half = h->ring_ops / 2;
+    if (count > half) return set_error(EKF_ERR_BAD_ARG, "too many operations in one call");
+    int pos = h->ring_pos;
+    int which = pos < half ? 0 : 1;
+    if (pos + count > (which + 1) * half) {  // does not fit the rest of this half: move to the next half
+        HIP_TRY(hipEventRecord(h->ring_ev[which], h->s_chain));
+        h->ring_ev_valid[which] = true;
+        which ^= 1;
+        pos = which * half;
+        if (h->ring_ev_valid[which]) HIP_TRY(hipEventSynchronize(h->ring_ev[which]));  // its readers from one lap ago
+    }
+    *rec = h->ring_h + (size_t)pos * h->dv.B * 8;
+    *k_out = pos;
+    h->ring_pos = pos + count;
+    return EKF_OK;
+}
+
+static int refresh_bounds(ekf_batch *h) {  // synchronises the chain stream
+    HIP_TRY(hipMemcpyAsync(h->h_int.data(), h->dv.n_lm, sizeof(int) * h->dv.B, hipMemcpyDeviceToHost, h->s_chain));
+    HIP_TRY(hipStreamSynchronize(h->s_chain));
     int mx = 0;
     for (int b = 0; b < h->dv.B; b++) mx = h->h_int[b] > mx ? h->h_int[b] : mx;
     h->n_lm_hi = mx;
@@ -345,18 +374,16 @@ extern "C" int ekf_batch_propagate_q(ekf_handle h, const double *v, const double
     HIP_TRY(hipSetDevice(h->device));
     double *rec;
     int k;
-    int rc = ring_acquire(h, &rec, &k);
+    int rc = ring_reserve(h, 1, &rec, &k);
     if (rc) return rc;
     for (int b = 0; b < h->dv.B; b++) {
         double *r = rec + (size_t)b * 8;
         r[0] = v[b], r[1] = w[b], r[2] = dt[b];
         r[3] = Q[4 * b], r[4] = Q[4 * b + 1], r[5] = Q[4 * b + 2], r[6] = Q[4 * b + 3];
-        r[7] = 0;
+        r[7] = OP_PROP;
     }
-    enqueue_propagate(h, h->ring_d, nullptr, k, h->n_lm_hi);
-    rc = ring_commit(h);
-    if (rc) return rc;
-    return check_launch();
+    unsigned char consumes = 0;
+    return launch_ops(h, h->ring_d, nullptr, k, &consumes, 1);
 }
 
 extern "C" int ekf_batch_propagate(ekf_handle h, const double *v, const double *w, const double *dt) {
@@ -380,30 +407,34 @@ extern "C" int ekf_propagate(ekf_handle h, double v, double w, double dt) {
 static int fetch_decisions(ekf_batch *h, int n_z, ekf_decision *out);
 
 extern "C" int ekf_batch_update(ekf_handle h, const double *z, const double *R, const unsigned char *valid, int n_z, ekf_decision *decisions_out) {
-    if (!h || !z || !R || n_z < 0) return set_error(EKF_ERR_BAD_ARG, "null argument");
+    if (!h || n_z < 0 || (n_z > 0 && (!z || !R))) return set_error(EKF_ERR_BAD_ARG, "null argument");
     HIP_TRY(hipSetDevice(h->device));
     int B = h->dv.B;
-    for (int j = 0; j < n_z; j++) {
+    int half = h->ring_ops / 2;
+    std::vector<unsigned char> consumes;
+    for (int j0 = 0; j0 < n_z; j0 += half) {  // a chunk larger than half the ring goes out in pieces
+        int cnt = n_z - j0 < half ? n_z - j0 : half;
         double *rec;
         int k;
-        int rc = ring_acquire(h, &rec, &k);
+        int rc = ring_reserve(h, cnt, &rec, &k);
         if (rc) return rc;
-        for (int b = 0; b < B; b++) {
-            double *r = rec + (size_t)b * 8;
-            const double *zz = z + ((size_t)b * n_z + j) * 2;
-            const double *RR = R + ((size_t)b * n_z + j) * 4;
-            r[0] = zz[0], r[1] = zz[1];
-            r[2] = RR[0], r[3] = RR[1], r[4] = RR[2], r[5] = RR[3];
-            r[6] = (!valid || valid[(size_t)b * n_z + j]) ? 1.0 : 0.0;
-            r[7] = 0;
+        for (int jj = 0; jj < cnt; jj++) {
+            int j = j0 + jj;
+            for (int b = 0; b < B; b++) {
+                double *r = rec + ((size_t)jj * B + b) * 8;
+                const double *zz = z + ((size_t)b * n_z + j) * 2;
+                const double *RR = R + ((size_t)b * n_z + j) * 4;
+                r[0] = zz[0], r[1] = zz[1];
+                r[2] = RR[0], r[3] = RR[1], r[4] = RR[2], r[5] = RR[3];
+                r[6] = (j == n_z - 1) ? 2.0 : 1.0;  // 2 = last measurement of the chunk (Update.cpp:26 quirk)
+                r[7] = (!valid || valid[(size_t)b * n_z + j]) ? OP_MEAS : OP_SKIP_SLOT;
+            }
         }
-        rc = enqueue_measurement(h, h->ring_d, nullptr, k, j == n_z - 1, &h->n_lm_hi, false);
-        if (rc) return rc;
-        rc = ring_commit(h);
+        consumes.assign(cnt, 1);
+        bump_bound(h, cnt);
+        rc = launch_ops(h, h->ring_d, nullptr, k, consumes.data(), cnt);
         if (rc) return rc;
     }
-    int rc = check_launch();
-    if (rc) return rc;
     if (decisions_out) return fetch_decisions(h, n_z, decisions_out);
     return EKF_OK;
 }
@@ -418,18 +449,16 @@ extern "C" int ekf_batch_update_compass(ekf_handle h, const double *z, const dou
     HIP_TRY(hipSetDevice(h->device));
     double *rec;
     int k;
-    int rc = ring_acquire(h, &rec, &k);
+    int rc = ring_reserve(h, 1, &rec, &k);
     if (rc) return rc;
     for (int b = 0; b < h->dv.B; b++) {
         double *r = rec + (size_t)b * 8;
-        r[0] = z[b], r[1] = R[b], r[2] = (!valid || valid[b]) ? 1.0 : 0.0;
-        r[3] = r[4] = r[5] = r[6] = r[7] = 0;
+        r[0] = z[b], r[1] = R[b];
+        r[2] = r[3] = r[4] = r[5] = r[6] = 0;
+        r[7] = (!valid || valid[b]) ? OP_COMPASS : OP_SKIP_SLOT;
     }
-    rc = enqueue_compass(h, h->ring_d, nullptr, k, h->n_lm_hi);
-    if (rc) return rc;
-    rc = ring_commit(h);
-    if (rc) return rc;
-    return check_launch();
+    unsigned char consumes = 1;
+    return launch_ops(h, h->ring_d, nullptr, k, &consumes, 1);
 }
 
 extern "C" int ekf_update_compass(ekf_handle h, double z, double R) {
@@ -442,25 +471,25 @@ extern "C" int ekf_record_truth(ekf_handle h, const double *truth) {
     HIP_TRY(hipSetDevice(h->device));
     double *rec;
     int k;
-    int rc = ring_acquire(h, &rec, &k);
+    int rc = ring_reserve(h, 1, &rec, &k);
     if (rc) return rc;
     for (int b = 0; b < h->dv.B; b++) {
         double *r = rec + (size_t)b * 8;
-        r[0] = truth[3 * b], r[1] = truth[3 * b + 1], r[2] = truth[3 * b + 2], r[3] = 1.0;
-        r[4] = r[5] = r[6] = r[7] = 0;
+        r[0] = truth[3 * b], r[1] = truth[3 * b + 1], r[2] = truth[3 * b + 2];
+        r[3] = r[4] = r[5] = r[6] = 0;
+        r[7] = OP_TRUTH;
     }
-    hipLaunchKernelGGL(k_nees, dim3(h->dv.B), dim3(64), 0, h->stream, h->dv, (const double *)h->ring_d, (const int *)nullptr, k);
-    rc = ring_commit(h);
-    if (rc) return rc;
-    return check_launch();
+    unsigned char consumes = 0;
+    return launch_ops(h, h->ring_d, nullptr, k, &consumes, 1);
 }
 
 // ---- synchronising accessors ------------------------------------------------------------------------
 extern "C" int ekf_sync(ekf_handle h) {
     if (!h) return set_error(EKF_ERR_BAD_ARG, "null handle");
     HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(hipMemcpyAsync(h->h_int.data(), h->dv.status, sizeof(int) * h->dv.B, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpyAsync(h->h_int.data(), h->dv.status, sizeof(int) * h->dv.B, hipMemcpyDeviceToHost, h->s_chain));
+    HIP_TRY(hipStreamSynchronize(h->s_chain));
+    HIP_TRY(hipStreamSynchronize(h->s_flush));
     for (int b = 0; b < h->dv.B; b++)
         if (h->h_int[b] != 0) return set_error(h->h_int[b], "a New landmark did not fit capacity_landmarks");
     return EKF_OK;
@@ -469,19 +498,15 @@ extern "C" int ekf_sync(ekf_handle h) {
 extern "C" int ekf_flush(ekf_handle h) {
     if (!h) return set_error(EKF_ERR_BAD_ARG, "null handle");
     HIP_TRY(hipSetDevice(h->device));
-    int rc = enqueue_flush(h, h->n_lm_hi);
-    if (rc) return rc;
-    return check_launch();
+    return close_set(h);
 }
 
 extern "C" int ekf_batch_get_pose(ekf_handle h, double *pose_out) {
     if (!h || !pose_out) return set_error(EKF_ERR_BAD_ARG, "null argument");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipMemcpy2DAsync(pose_out, 3 * sizeof(double), h->dv.x, (size_t)h->dv.xs * sizeof(double), 3 * sizeof(double), h->dv.B,
-                             hipMemcpyDeviceToHost, h->stream));
-    int rc = refresh_bounds(h);
-    if (rc) return rc;
-    return EKF_OK;
+                             hipMemcpyDeviceToHost, h->s_chain));
+    return refresh_bounds(h);
 }
 
 extern "C" int ekf_get_pose(ekf_handle h, double pose_out[3]) {
@@ -506,19 +531,21 @@ extern "C" int ekf_num_landmarks(ekf_handle h) {
 }
 
 static int fetch_decisions(ekf_batch *h, int n_z, ekf_decision *out) {
-    // [batch][n_z], the last n_z log entries of every filter
+    // [batch][n_z]: the last entries of every filter's log.  Masked measurements leave no entry, so a
+    // filter with fewer real entries gets zeroed records in front.
     int B = h->dv.B;
     std::vector<long long> cnt(B);
-    HIP_TRY(hipMemcpyAsync(cnt.data(), h->dv.log_count, sizeof(long long) * B, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpyAsync(cnt.data(), h->dv.log_count, sizeof(long long) * B, hipMemcpyDeviceToHost, h->s_chain));
+    HIP_TRY(hipStreamSynchronize(h->s_chain));
     for (int b = 0; b < B; b++) {
-        for (int j = 0; j < n_z; j++) {
-            long long idx = cnt[b] - n_z + j;
+        long long have = cnt[b] < n_z ? cnt[b] : n_z;
+        for (int j = 0; j < n_z - have; j++) {
             ekf_decision *dst = out + (size_t)b * n_z + j;
-            if (idx < 0) {
-                dst->decision = 0, dst->matched = 0, dst->mahal = 0;
-                continue;
-            }
+            dst->decision = 0, dst->matched = 0, dst->mahal = 0;
+        }
+        for (long long j = 0; j < have; j++) {
+            long long idx = cnt[b] - have + j;
+            ekf_decision *dst = out + (size_t)b * n_z + (n_z - have + j);
             HIP_TRY(hipMemcpy(dst, h->dv.log + (size_t)b * h->dv.logcap + (idx % h->dv.logcap), sizeof(ekf_decision), hipMemcpyDeviceToHost));
         }
     }
@@ -529,8 +556,8 @@ extern "C" int ekf_get_decisions(ekf_handle h, int index, ekf_decision *out, int
     if (!h || !out || index < 0 || index >= h->dv.B || count < 0) return set_error(EKF_ERR_BAD_ARG, "bad argument");
     HIP_TRY(hipSetDevice(h->device));
     long long cnt;
-    HIP_TRY(hipMemcpyAsync(&cnt, h->dv.log_count + index, sizeof cnt, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpyAsync(&cnt, h->dv.log_count + index, sizeof cnt, hipMemcpyDeviceToHost, h->s_chain));
+    HIP_TRY(hipStreamSynchronize(h->s_chain));
     long long avail = cnt < h->dv.logcap ? cnt : h->dv.logcap;
     long long n = count < avail ? count : avail;
     std::vector<ekf_decision> ring(h->dv.logcap);
@@ -542,15 +569,15 @@ extern "C" int ekf_get_decisions(ekf_handle h, int index, ekf_decision *out, int
 extern "C" int ekf_get_stats(ekf_handle h, ekf_stats *out) {
     if (!h || !out) return set_error(EKF_ERR_BAD_ARG, "null argument");
     HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(hipMemcpyAsync(out, h->dv.stats, sizeof(ekf_stats) * h->dv.B, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpyAsync(out, h->dv.stats, sizeof(ekf_stats) * h->dv.B, hipMemcpyDeviceToHost, h->s_chain));
+    HIP_TRY(hipStreamSynchronize(h->s_chain));
     return EKF_OK;
 }
 
 extern "C" int ekf_reset_stats(ekf_handle h) {
     if (!h) return set_error(EKF_ERR_BAD_ARG, "null handle");
     HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(hipMemsetAsync(h->dv.stats, 0, sizeof(ekf_stats) * h->dv.B, h->stream));
+    HIP_TRY(hipMemsetAsync(h->dv.stats, 0, sizeof(ekf_stats) * h->dv.B, h->s_chain));
     return EKF_OK;
 }
 
@@ -563,17 +590,17 @@ extern "C" int ekf_get_state(ekf_handle h, int index, double *x_out, double *P_o
     int n = 3 + 2 * h->h_int[index];
     if (!x_out && !P_out) return n;
     if (!x_out || !P_out || ld < n) return set_error(EKF_ERR_BAD_ARG, "bad output buffers");
-    rc = enqueue_flush(h, h->n_lm_hi);
+    rc = settle(h);
     if (rc) return rc;
     double *stage = nullptr;  // transient staging: dense n x n + x
     HIP_TRY(hipMalloc((void **)&stage, ((size_t)n * n + n) * sizeof(double)));
     double *xd = stage + (size_t)n * n;
-    hipLaunchKernelGGL(k_export, dim3(cdiv(n, 256), n), dim3(256), 0, h->stream, h->dv, index, xd, stage, n, n);
-    hipError_t e = hipMemcpyAsync(x_out, xd, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream);
+    hipLaunchKernelGGL(k_export, dim3(cdiv(n, 256), n), dim3(256), 0, h->s_chain, h->dv, index, h->buf_in, xd, stage, n, n);
+    hipError_t e = hipMemcpyAsync(x_out, xd, sizeof(double) * n, hipMemcpyDeviceToHost, h->s_chain);
     if (e == hipSuccess)
         e = hipMemcpy2DAsync(P_out, (size_t)ld * sizeof(double), stage, (size_t)n * sizeof(double), (size_t)n * sizeof(double), n,
-                             hipMemcpyDeviceToHost, h->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+                             hipMemcpyDeviceToHost, h->s_chain);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->s_chain);
     hipFree(stage);
     if (e != hipSuccess) return set_error(EKF_ERR_HIP, hipGetErrorString(e));
     return n;
@@ -584,26 +611,28 @@ extern "C" int ekf_set_state(ekf_handle h, int index, const double *x, const dou
     int N = (n - 3) / 2;
     if (N > h->dv.Ncap) return set_error(EKF_ERR_CAPACITY, "state larger than capacity_landmarks");
     HIP_TRY(hipSetDevice(h->device));
-    int rc = enqueue_flush(h, h->n_lm_hi);
+    int rc = settle(h);
     if (rc) return rc;
     EkfDev &dv = h->dv;
+    hipStream_t s = h->s_chain;
     double *stage = nullptr;
     HIP_TRY(hipMalloc((void **)&stage, ((size_t)n * n + n) * sizeof(double)));
     double *xd = stage + (size_t)n * n;
-    hipError_t e = hipMemcpyAsync(xd, x, sizeof(double) * n, hipMemcpyHostToDevice, h->stream);
+    hipError_t e = hipMemcpyAsync(xd, x, sizeof(double) * n, hipMemcpyHostToDevice, s);
     if (e == hipSuccess)
         e = hipMemcpy2DAsync(stage, (size_t)n * sizeof(double), P, (size_t)ld * sizeof(double), (size_t)n * sizeof(double), n,
-                             hipMemcpyHostToDevice, h->stream);
+                             hipMemcpyHostToDevice, s);
     size_t b = index;
-    if (e == hipSuccess) e = hipMemsetAsync(dv.x + b * dv.xs, 0, sizeof(double) * dv.xs, h->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(dv.R + b * 3 * dv.xs, 0, sizeof(double) * 3 * dv.xs, h->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(dv.D + b * 3 * dv.dn, 0, sizeof(double) * 3 * dv.dn, h->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(dv.Bm + b * dv.bm_stride, 0, sizeof(double) * dv.bm_stride, h->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(dv.F + b * dv.f_stride, 0, sizeof(double) * dv.f_stride, h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(dv.x + b * dv.xs, 0, sizeof(double) * dv.xs, s);
+    if (e == hipSuccess) e = hipMemsetAsync(dv.R + b * 3 * dv.xs, 0, sizeof(double) * 3 * dv.xs, s);
+    if (e == hipSuccess) e = hipMemsetAsync(dv.D + b * 3 * dv.dn, 0, sizeof(double) * 3 * dv.dn, s);
+    for (int q = 0; q < 2 && e == hipSuccess; q++) e = hipMemsetAsync(dv.Bm[q] + b * dv.bm_stride, 0, sizeof(double) * dv.bm_stride, s);
+    if (e == hipSuccess) e = hipMemsetAsync(dv.FA + b * 2 * dv.f_stride, 0, sizeof(double) * 2 * dv.f_stride, s);
+    if (e == hipSuccess) e = hipMemsetAsync(dv.FB + b * 2 * dv.f_stride, 0, sizeof(double) * 2 * dv.f_stride, s);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_import, dim3(cdiv(n, 256), n), dim3(256), 0, h->stream, dv, index, (const double *)xd, (const double *)stage, n, n);
-        hipLaunchKernelGGL(k_set_meta, dim3(1), dim3(64), 0, h->stream, dv, index, N);
-        e = hipStreamSynchronize(h->stream);
+        hipLaunchKernelGGL(k_import, dim3(cdiv(n, 256), n), dim3(256), 0, s, dv, index, h->buf_in, (const double *)xd, (const double *)stage, n, n);
+        hipLaunchKernelGGL(k_set_meta, dim3(1), dim3(64), 0, s, dv, index, N);
+        e = hipStreamSynchronize(s);
     }
     hipFree(stage);
     if (e != hipSuccess) return set_error(EKF_ERR_HIP, hipGetErrorString(e));
@@ -614,18 +643,23 @@ extern "C" int ekf_set_state(ekf_handle h, int index, const double *x, const dou
 extern "C" int ekf_broadcast_state(ekf_handle h) {
     if (!h) return set_error(EKF_ERR_BAD_ARG, "null handle");
     HIP_TRY(hipSetDevice(h->device));
-    int rc = enqueue_flush(h, h->n_lm_hi);
+    int rc = settle(h);
     if (rc) return rc;
     EkfDev &dv = h->dv;
+    hipStream_t s = h->s_chain;
     for (int b = 1; b < dv.B; b++) {
-        HIP_TRY(hipMemcpyAsync(dv.x + (size_t)b * dv.xs, dv.x, sizeof(double) * dv.xs, hipMemcpyDeviceToDevice, h->stream));
-        HIP_TRY(hipMemcpyAsync(dv.R + (size_t)b * 3 * dv.xs, dv.R, sizeof(double) * 3 * dv.xs, hipMemcpyDeviceToDevice, h->stream));
-        HIP_TRY(hipMemcpyAsync(dv.D + (size_t)b * 3 * dv.dn, dv.D, sizeof(double) * 3 * dv.dn, hipMemcpyDeviceToDevice, h->stream));
-        HIP_TRY(hipMemcpyAsync(dv.Bm + (size_t)b * dv.bm_stride, dv.Bm, sizeof(double) * dv.bm_stride, hipMemcpyDeviceToDevice, h->stream));
-        HIP_TRY(hipMemcpyAsync(dv.F + (size_t)b * dv.f_stride, dv.F, sizeof(double) * dv.f_stride, hipMemcpyDeviceToDevice, h->stream));
-        HIP_TRY(hipMemcpyAsync(dv.n_lm + b, dv.n_lm, sizeof(int), hipMemcpyDeviceToDevice, h->stream));
-        HIP_TRY(hipMemcpyAsync(dv.n_lm_sweep + b, dv.n_lm_sweep, sizeof(int), hipMemcpyDeviceToDevice, h->stream));
-        HIP_TRY(hipMemcpyAsync(dv.status + b, dv.status, sizeof(int), hipMemcpyDeviceToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(dv.x + (size_t)b * dv.xs, dv.x, sizeof(double) * dv.xs, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipMemcpyAsync(dv.R + (size_t)b * 3 * dv.xs, dv.R, sizeof(double) * 3 * dv.xs, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipMemcpyAsync(dv.D + (size_t)b * 3 * dv.dn, dv.D, sizeof(double) * 3 * dv.dn, hipMemcpyDeviceToDevice, s));
+        for (int q = 0; q < 2; q++)
+            HIP_TRY(hipMemcpyAsync(dv.Bm[q] + (size_t)b * dv.bm_stride, dv.Bm[q], sizeof(double) * dv.bm_stride, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipMemcpyAsync(dv.FA + (size_t)b * 2 * dv.f_stride, dv.FA, sizeof(double) * 2 * dv.f_stride, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipMemcpyAsync(dv.FB + (size_t)b * 2 * dv.f_stride, dv.FB, sizeof(double) * 2 * dv.f_stride, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipMemcpyAsync(dv.slot_active + (size_t)b * 2 * dv.maxp, dv.slot_active, sizeof(int) * 2 * dv.maxp, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipMemcpyAsync(dv.n_lm + b, dv.n_lm, sizeof(int), hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipMemcpyAsync(dv.n_lm_sweep + b, dv.n_lm_sweep, sizeof(int), hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipMemcpyAsync(dv.n_lm_flush + 2 * (size_t)b, dv.n_lm_flush, 2 * sizeof(int), hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipMemcpyAsync(dv.status + b, dv.status, sizeof(int), hipMemcpyDeviceToDevice, s));
     }
     return refresh_bounds(h);
 }
@@ -637,7 +671,8 @@ extern "C" int ekf_script_load(ekf_handle h, int steps, int M, const double *ctr
                                const unsigned char *valid, const double *truth) {
     if (!h || steps < 1 || M < 0 || !ctrl || (M > 0 && (!z || !R))) return set_error(EKF_ERR_BAD_ARG, "bad argument");
     HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipStreamSynchronize(h->s_chain));
+    HIP_TRY(hipStreamSynchronize(h->s_flush));
     for (auto &g : h->graphs) hipGraphExecDestroy(g.exec);
     h->graphs.clear();
     if (h->script_d) {
@@ -659,6 +694,7 @@ extern "C" int ekf_script_load(ekf_handle h, int steps, int M, const double *ctr
             double Q[4];
             make_Q(h->params, c[0], Q);
             r[0] = c[0], r[1] = c[1], r[2] = c[2], r[3] = Q[0], r[4] = Q[1], r[5] = Q[2], r[6] = Q[3];
+            r[7] = OP_PROP;
         }
         for (int m = 0; m < M; m++)
             for (int b = 0; b < B; b++) {
@@ -666,13 +702,15 @@ extern "C" int ekf_script_load(ekf_handle h, int steps, int M, const double *ctr
                 const double *zz = z + (((size_t)s * M + m) * B + b) * 2;
                 const double *RR = R + (((size_t)s * M + m) * B + b) * 4;
                 r[0] = zz[0], r[1] = zz[1], r[2] = RR[0], r[3] = RR[1], r[4] = RR[2], r[5] = RR[3];
-                r[6] = (!valid || valid[((size_t)s * M + m) * B + b]) ? 1.0 : 0.0;
+                r[6] = 2.0;  // every scripted measurement is its own doUpdate call (slam.cpp:150-171)
+                r[7] = (!valid || valid[((size_t)s * M + m) * B + b]) ? OP_MEAS : OP_SKIP_SLOT;
             }
         if (truth)
             for (int b = 0; b < B; b++) {
                 double *r = base + ((size_t)(1 + M) * B + b) * 8;
                 const double *t = truth + ((size_t)s * B + b) * 3;
-                r[0] = t[0], r[1] = t[1], r[2] = t[2], r[3] = 1.0;
+                r[0] = t[0], r[1] = t[1], r[2] = t[2];
+                r[7] = OP_TRUTH;
             }
     }
     HIP_TRY(hipMalloc((void **)&h->script_d, count * sizeof(double)));
@@ -680,26 +718,23 @@ extern "C" int ekf_script_load(ekf_handle h, int steps, int M, const double *ctr
     return EKF_OK;
 }
 
-// enqueue one scripted step; op index = (cursor ? *cursor : 0) + k0 + ...
-static int enqueue_script_step(ekf_batch *h, const int *cursor, int k0, int *n_lm_bound, bool bound_is_capacity) {
-    int M = h->script_M;
-    enqueue_propagate(h, h->script_d, cursor, k0, *n_lm_bound);
-    for (int m = 0; m < M; m++) {
-        int rc = enqueue_measurement(h, h->script_d, cursor, k0 + 1 + m, 1, n_lm_bound, bound_is_capacity);
-        if (rc) return rc;
-    }
-    if (h->script_has_truth)
-        hipLaunchKernelGGL(k_nees, dim3(h->dv.B), dim3(64), 0, h->stream, h->dv, (const double *)h->script_d, cursor, k0 + 1 + M);
-    return EKF_OK;
+// enqueue scripted steps [s0, s0 + ns): op index = (cursor ? *cursor : 0) + k
+static int enqueue_script_steps(ekf_batch *h, const int *cursor, int k_first, int ns) {
+    int ops = ops_per_step(h), M = h->script_M;
+    std::vector<unsigned char> consumes((size_t)ns * ops, 0);
+    for (int q = 0; q < ns; q++)
+        for (int m = 0; m < M; m++) consumes[(size_t)q * ops + 1 + m] = 1;
+    return launch_ops(h, h->script_d, cursor, k_first, consumes.data(), ns * ops);
 }
 
 static int graph_block_steps(const ekf_batch *h) {
-    // smallest S >= 4 with (S * M) % maxp == 0 so the pending count returns to 0 at graph end
+    // smallest S >= 8 whose slot count is an even multiple of maxp, so that a graph ends with an
+    // empty slot set and with cur_set / buf_in back where they started
     int M = h->script_M, maxp = h->dv.maxp;
     if (M == 0) return 8;
-    for (int S = 4; S <= 4 * maxp + 4; S++)
-        if ((S * M) % maxp == 0) return S;
-    return maxp;
+    for (int S = 8; S <= 8 + 4 * maxp; S++)
+        if ((S * M) % (2 * maxp) == 0) return S;
+    return 2 * maxp;
 }
 
 extern "C" int ekf_script_run(ekf_handle h, int first_step, int n_steps, int use_graph) {
@@ -709,28 +744,37 @@ extern "C" int ekf_script_run(ekf_handle h, int first_step, int n_steps, int use
     int ops = ops_per_step(h);
     int s = first_step, end = first_step + n_steps;
     if (use_graph) {
-        // graphs bake grid sizes: size every grid for the capacity, and start from an empty pending set
-        int rc = enqueue_flush(h, h->n_lm_hi);
-        if (rc) return rc;
         int S = graph_block_steps(h);
         if (end - s >= S) {
+            // a graph starts from the settled state (its predecessor in the stream has fully finished)
+            int rc = close_set(h);
+            if (rc) return rc;
+            HIP_TRY(hipEventRecord(h->ev_join, h->s_flush));
+            HIP_TRY(hipStreamWaitEvent(h->s_chain, h->ev_join, 0));
             GraphEntry *ge = nullptr;
             for (auto &g : h->graphs)
                 if (g.steps == S && g.M == h->script_M && g.has_truth == h->script_has_truth) ge = &g;
+            int save_set = h->cur_set, save_buf = h->buf_in;
             if (!ge) {
                 hipGraph_t graph;
-                HIP_TRY(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-                int bound = h->dv.Ncap;
-                int rc2 = EKF_OK;
                 bool prof_saved = h->prof_flush;
-                h->prof_flush = false;  // event pairs are not captured into graphs
-                for (int q = 0; q < S && rc2 == EKF_OK; q++) rc2 = enqueue_script_step(h, h->cursor_d, q * ops, &bound, true);
-                hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, h->stream, h->cursor_d, S * ops);
-                hipError_t e = hipStreamEndCapture(h->stream, &graph);
+                int hi_saved = h->n_lm_hi;
+                h->prof_flush = false;    // event pairs are not captured into graphs
+                h->n_lm_hi = h->dv.Ncap;  // graphs bake grid sizes: size the dense pass for the capacity
+                h->inflight = false;
+                h->flush_valid[0] = h->flush_valid[1] = false;
+                HIP_TRY(hipStreamBeginCapture(h->s_chain, hipStreamCaptureModeThreadLocal));
+                int rc2 = enqueue_script_steps(h, h->cursor_d, 0, S);
+                if (rc2 == EKF_OK && h->pending != 0) rc2 = set_error(EKF_ERR_STATE, "graph block does not end on an empty slot set");
+                hipError_t e1 = hipEventRecord(h->ev_join, h->s_flush);
+                hipError_t e2 = hipStreamWaitEvent(h->s_chain, h->ev_join, 0);
+                hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, h->s_chain, h->cursor_d, S * ops);
+                hipError_t e = hipStreamEndCapture(h->s_chain, &graph);
                 h->prof_flush = prof_saved;
+                h->n_lm_hi = hi_saved;
                 if (rc2) return rc2;
-                if (e != hipSuccess) return set_error(EKF_ERR_HIP, hipGetErrorString(e));
-                if (h->pending != 0) return set_error(EKF_ERR_STATE, "graph block does not return to an empty pending set");
+                if (e1 != hipSuccess || e2 != hipSuccess || e != hipSuccess) return set_error(EKF_ERR_HIP, "graph capture failed");
+                if (h->cur_set != save_set || h->buf_in != save_buf) return set_error(EKF_ERR_STATE, "graph block does not restore the ping-pong state");
                 GraphEntry g;
                 g.steps = S, g.M = h->script_M, g.has_truth = h->script_has_truth;
                 HIP_TRY(hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0));
@@ -739,20 +783,22 @@ extern "C" int ekf_script_run(ekf_handle h, int first_step, int n_steps, int use
                 ge = &h->graphs.back();
             }
             int start_op = s * ops;
-            HIP_TRY(hipMemcpyAsync(h->cursor_d, &start_op, sizeof(int), hipMemcpyHostToDevice, h->stream));
-            HIP_TRY(hipStreamSynchronize(h->stream));  // start_op is a stack variable
+            HIP_TRY(hipMemcpyAsync(h->cursor_d, &start_op, sizeof(int), hipMemcpyHostToDevice, h->s_chain));
+            HIP_TRY(hipStreamSynchronize(h->s_chain));  // start_op is a stack variable
             while (end - s >= S) {
-                HIP_TRY(hipGraphLaunch(ge->exec, h->stream));
+                HIP_TRY(hipGraphLaunch(ge->exec, h->s_chain));
                 s += S;
             }
-            if (h->n_lm_hi < h->dv.Ncap) {
-                // landmarks may have been appended inside the graphs; the bound is unknown until a sync
-                h->n_lm_hi = h->dv.Ncap;
-            }
+            // whatever follows in s_chain runs after the whole graph, dense passes included
+            h->inflight = false;
+            h->flush_valid[0] = h->flush_valid[1] = false;
+            h->pending = 0;
+            h->n_lm_hi = h->dv.Ncap;  // landmarks may have been appended inside the graphs; unknown until a sync
         }
     }
-    for (; s < end; s++) {
-        int rc = enqueue_script_step(h, nullptr, s * ops, &h->n_lm_hi, false);
+    if (s < end) {
+        bump_bound(h, (end - s) * h->script_M);
+        int rc = enqueue_script_steps(h, nullptr, s * ops, end - s);
         if (rc) return rc;
     }
     return check_launch();
@@ -762,14 +808,17 @@ extern "C" int ekf_script_run(ekf_handle h, int first_step, int n_steps, int use
 extern "C" int ekf_timer_start(ekf_handle h) {
     if (!h) return set_error(EKF_ERR_BAD_ARG, "null handle");
     HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(hipEventRecord(h->t0, h->stream));
+    HIP_TRY(hipEventRecord(h->t0, h->s_chain));
     return EKF_OK;
 }
 
 extern "C" int ekf_timer_stop(ekf_handle h, double *ms_out) {
     if (!h || !ms_out) return set_error(EKF_ERR_BAD_ARG, "null argument");
     HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(hipEventRecord(h->t1, h->stream));
+    // t1 comes after both streams: the chain stream waits for the dense passes launched so far
+    HIP_TRY(hipEventRecord(h->ev_join, h->s_flush));
+    HIP_TRY(hipStreamWaitEvent(h->s_chain, h->ev_join, 0));
+    HIP_TRY(hipEventRecord(h->t1, h->s_chain));
     HIP_TRY(hipEventSynchronize(h->t1));
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, h->t0, h->t1));
@@ -786,7 +835,8 @@ extern "C" int ekf_flush_profile(ekf_handle h, int enable) {
 extern "C" int ekf_flush_profile_read(ekf_handle h, long long *launches_out, double *total_ms_out) {
     if (!h) return set_error(EKF_ERR_BAD_ARG, "null handle");
     HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipStreamSynchronize(h->s_chain));
+    HIP_TRY(hipStreamSynchronize(h->s_flush));
     for (size_t i = 0; i + 1 < h->prof_used; i += 2) {
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, h->prof_pool[i], h->prof_pool[i + 1]));

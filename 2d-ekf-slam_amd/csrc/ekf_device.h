@@ -2,69 +2,54 @@
 //
 // One handle = B independent filters.  For filter b, every element of the (3+2N)^2 covariance has
 // exactly ONE authoritative home (DESIGN.md "Data layout"):
-//   rows/cols 0..2 (robot)            -> R  [b][3][xs]      kept current after every operation
-//   the 2x2 block of landmark l       -> D  [b][3][dn]      (xx, xy, yy) kept current
-//   every other P_LL entry (i' <= j') -> Bm [b][tiles]      64x64 tiles of the upper triangle,
+//   rows/cols 0..2 (robot)            -> R  [b][3][xs]      kept current by the chain kernel
+//   the 2x2 block of landmark l       -> D  [b][3][dn]      (xx, xy, yy) kept current by the chain kernel
+//   every other P_LL entry (i' <= j') -> Bm [buf][b][tiles] 64x64 tiles of the upper triangle,
 //                                                           MFMA-fragment-major inside a tile,
-//                                                           brought current by the dense pass
-// P_LL indices are "landmark space": i' = i - 3.  Rank-2 updates that have been applied to x, R, D
-// but not yet to Bm are held as fragments in F [b][rb16][slot][k][r16], k = (t0, t1, k0, k1) where
-// T = K S (Update.cpp:188) -- the A/B operand layout of v_mfma_f64_16x16x4_f64.
+//                                                           written ONLY by the dense pass (k_flush)
+// P_LL indices are "landmark space": i' = i - 3.
+//
+// Everything the chain kernel decides that changes P_LL is recorded as a rank-4 "slot"
+//       P_LL(i', j') += sum_k FA[i'][k] * FB[j'][k]          (i' <= j', different landmarks)
+// in fragment arrays FA/FB [b][set][rb16][slot][k][r16] -- exactly the A/B operand layout of
+// v_mfma_f64_16x16x4_f64.  An Old-landmark update (Update.cpp:188,193-194) is the slot
+// FA = -0.5 [T | K], FB = [K | T] with T = K S; a New landmark (Update.cpp:169-177) is the slot
+// FA = [P_xL | 0], FB = unit rows at the new landmark.  The dense pass applies a whole set of slots
+// in one read of Bm[in] and one write of Bm[out]; two slot sets and two Bm buffers let the chain
+// kernel of the next step run while the dense pass of this step streams through HBM.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "../../include/ekfslam_c.h"
 
 #define EKF_INF 999999999999.0 /* kalmanfilter.h:17 */
 #define EKF_MAX_PENDING 8
-#define EKF_SWEEP_THREADS 256
+#define EKF_CHAIN_MAX_THREADS 512
+#define EKF_CHAIN_MAX_OPS 64 /* operations per k_chain launch */
 
+// op records: 8 doubles per (op, filter); r[7] is the type
+enum { OP_NOP = 0, OP_PROP = 1, OP_MEAS = 2, OP_COMPASS = 3, OP_TRUTH = 4, OP_SKIP_SLOT = 5 };
+// header decisions (internal)
 enum { HDR_NONE = 0, HDR_NEW = 1, HDR_OLD = 2, HDR_IGNORE = 3, HDR_COMPASS = 4, HDR_NEW_NOFIT = 5 };
-
-struct MeasHdr {  // written by k_decide / k_compass_head, read by k_apply
-    int decision;
-    int lm;  // 0-based landmark id: matched (OLD) or appended (NEW)
-    int pad0, pad1;
-    double HRt[6];   // H_R^T, 3x2 row-major              (Update.cpp:112-114 / 163-166)
-    double C[4];     // rotation C, row-major; H_Li = C^T (Update.cpp:90,95)
-    double Sinv[4];  // row-major
-    double S[4];     // row-major, symmetric              (Update.cpp:122-124)
-    double res[2];   //                                   (Update.cpp:111)
-    double KR[6];    // rows 0..2 of K, 3x2 row-major     (Update.cpp:186)
-    double TR[6];    // rows 0..2 of K*S
-    double invS;     // compass: 1/S                      (kalmanfilter.cpp:118)
-    double pad2;
-};
-
-struct PropHdr {  // Phi_R = [[1,0,a],[0,1,b],[0,0,1]]   (Propagate.cpp:42-44)
-    double a, b;
-};
-
-struct SweepPartial {  // one per sweep block: best candidate of that block
-    double d;          // Mahalanobis distance, EKF_INF when the block has no candidate
-    int lm;            // 0-based landmark id, -1 when none
-    int pad;
-    double res[2];
-    double S[3];       // S00, S01, S11 after symmetrisation
-    double hcol[2];    // third column of H_R
-};
 
 struct EkfDev {
     int B, Ncap;
     int xs;    // stride of x and of each R row (doubles), multiple of 64, >= 3 + 2*Ncap
     int dn;    // stride of each D component, = 32*T
     int T;     // 64x64 tiles per side of P_LL
-    int maxp;  // pending slots allocated
+    int maxp;  // slots per set
     int logcap;
-    int nblk_sweep;  // partial records per filter
-    size_t bm_stride;  // doubles per filter in Bm: T(T+1)/2 * 4096
-    size_t f_stride;   // doubles per filter in F : 4T * maxp * 64
-    double *x, *R, *D, *Bm, *F;
-    int *n_lm, *n_lm_sweep, *status, *slot_active;
-    MeasHdr *hdr;
-    PropHdr *phdr;
-    SweepPartial *part;
+    int pad;
+    size_t bm_stride;  // doubles per filter in one Bm buffer: T(T+1)/2 * 4096
+    size_t f_stride;   // doubles per (filter, set) in FA / FB: 4T * maxp * 64
+    double *x, *R, *D;
+    double *Bm[2];
+    double *FA, *FB;   // [B][2][f_stride]
+    int *n_lm, *n_lm_sweep, *status;
+    int *n_lm_flush;   // [B][2]: landmark count when set s was last written (sizes its dense pass)
+    int *slot_active;  // [B][2][maxp]
     ekf_decision *log;
     long long *log_count;
     ekf_stats *stats;
@@ -87,7 +72,7 @@ __host__ __device__ inline size_t bm_offset(int T, int ip, int jp) {
     return t * 4096 + (size_t)chain * 256 + (size_t)(r >> 1) * 128 + (size_t)(g * 16 + c) * 2 + (r & 1);
 }
 
-// Offset (doubles) of fragment entry (row i', slot m, component k) inside one filter's F.
+// Offset (doubles) of fragment entry (row i', slot m, component k) inside one (filter, set) of FA/FB.
 __host__ __device__ inline size_t f_offset(int maxp, int ip, int m, int k) {
     return (((size_t)(ip >> 4) * maxp + m) * 4 + k) * 16 + (ip & 15);
 }

@@ -1,0 +1,70 @@
+"""Monte-Carlo sharding of independent filter instances across GPUs.
+
+Filters never exchange data, so the data path has no collective: global filter g lives on rank
+g // filters_per_rank.  The one collective is an all-gather of the per-filter summary statistics
+(time-averaged NIS and NEES, [filters_per_rank, 2] fp64 = a few KB per rank) at the end of a run;
+with the `nccl` backend that is RCCL over xGMI, with `gloo` it runs on CPU (tests).
+"""
+import numpy as np
+
+
+def shard_range(total_filters, rank, world):
+    """Contiguous block partition; the first (total % world) ranks hold one extra filter."""
+    base, extra = divmod(total_filters, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def filter_seed(base_seed, global_index):
+    return int(base_seed) + int(global_index)
+
+
+def summarise(stats):
+    """ekf_stats dicts -> [n, 2] array of (mean NIS, mean NEES) per filter (NaN when no samples)."""
+    out = np.full((len(stats), 2), np.nan)
+    for i, s in enumerate(stats):
+        if s["nis_count"]:
+            out[i, 0] = s["nis_sum"] / s["nis_count"]
+        if s["nees_count"]:
+            out[i, 1] = s["nees_sum"] / s["nees_count"]
+    return out
+
+
+def gather_stats(local, device=None):
+    """All-gather [n_local, 2] summaries into [world * n_local, 2], ordered by global filter index.
+    Every rank must pass the same n_local (pad with NaN rows otherwise).  Without an initialised
+    process group this is the identity."""
+    import torch
+    import torch.distributed as dist
+
+    local = np.ascontiguousarray(local, dtype=np.float64)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return local.copy()
+    world = dist.get_world_size()
+    t = torch.from_numpy(local)
+    if device is not None:
+        t = t.to(device)
+    out = torch.empty((world * local.shape[0], local.shape[1]), dtype=torch.float64, device=t.device)
+    dist.all_gather_into_tensor(out, t)
+    return out.cpu().numpy()
+
+
+def consistency_report(summary, nis_samples_per_filter, nees_samples_per_filter, alpha=0.05):
+    """Chi-square consistency check of the gathered averages: with k filters of m samples each, the
+    sum of all NIS samples is chi2 with 2*k*m dof (NEES: 3*k*m) if the filter is consistent."""
+    from scipy.stats import chi2
+
+    rep = {}
+    for col, name, dof, m in ((0, "nis", 2, nis_samples_per_filter), (1, "nees", 3, nees_samples_per_filter)):
+        vals = summary[:, col]
+        vals = vals[np.isfinite(vals)]
+        k = vals.size
+        if k == 0 or m <= 0:
+            rep[name] = None
+            continue
+        total_dof = dof * k * m
+        mean = float(vals.mean())
+        lo = chi2.ppf(alpha / 2, total_dof) / (k * m)
+        hi = chi2.ppf(1 - alpha / 2, total_dof) / (k * m)
+        rep[name] = dict(mean=mean, dof=dof, filters=int(k), lower=float(lo), upper=float(hi), consistent=bool(lo <= mean <= hi))
+    return rep

@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""EKF steps/sec (propagate + full update) on MI355X -- the metric of BASELINE.json.
+
+One step = 1 Propagate + M sequential single-measurement Updates (n_z = 1 each, as slam.cpp:150-171
+issues them), all taking the Old branch on a map of N landmarks already in the state.
+Default workload: config 3 of BASELINE.json -- one filter, N = 4096 (dense P 8195 x 8195 fp64,
+537 MB), M = 4 -- because that is where the north_star quotes its target and the only size whose P
+does not fit the 256 MB Infinity Cache.  Inputs (state, the whole step script) are resident in HBM
+before the timed region; the timed region is kernel launches only.
+
+Multi-GPU: one process per GPU (torch.distributed, backend nccl = RCCL).  Filters are independent
+Monte-Carlo instances, so ranks share nothing on the data path (weak scaling: every rank runs the
+same workload with its own seed); the single collective is the all-gather of per-filter NIS/NEES
+summaries at the end of the timed region.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+WORKLOADS = {
+    # name: (N landmarks, batch per GPU, default steps, default warmup, seed)   -- BASELINE.json configs
+    "n4096": (4096, 1, 50, 5, 20260003),     # config 3
+    "n1024": (1024, 1, 200, 10, 20260002),   # config 2
+    "batch256": (256, 256, 200, 10, 20260004),  # config 4 (config 5 = the same at --gpus 8)
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", default="n4096", choices=sorted(WORKLOADS))
+    ap.add_argument("--M", type=int, default=4, help="measurements per step")
+    ap.add_argument("--max-pending", type=int, default=4, help="rank-2 updates deferred per dense pass (1 = a dense pass per measurement)")
+    ap.add_argument("--graph", type=int, default=1, help="replay steps through HIP graphs")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-flush-profile", action="store_true", help="do not bracket the dense pass with hipEvents")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+
+    import numpy as np
+    import torch  # imported before the HIP library so that one HIP runtime (torch's) serves both
+
+    import __graft_entry__ as ge
+    pkg = ge.load_package()
+    mc = pkg.montecarlo
+
+    N, B, d_steps, d_warm, seed = WORKLOADS[args.workload]
+    K = args.steps if args.steps is not None else d_steps
+    W = args.warmup if args.warmup is not None else d_warm
+    M = args.M
+
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    # ---- inputs: built on the host, then moved to HBM (untimed) ------------------------------------
+    lo, hi = mc.shard_range(B * world, rank, world)
+    f = pkg.FilterBatch(B, N, device=local_rank, max_pending=args.max_pending, log_capacity=max(4096, (K + W) * M))
+    scripts = []
+    for b, g in enumerate(range(lo, hi)):
+        x0, P0 = pkg.scenarios.injected_state(N, seed=mc.filter_seed(seed, g))
+        f.set_state(x0, P0, index=b)
+        scripts.append(pkg.scenarios.steady_script(x0, steps=W + K, M=M, seed=mc.filter_seed(seed + 7919, g)))
+        del P0
+    ctrl = np.stack([s["ctrl"] for s in scripts], axis=1)
+    z = np.stack([s["z"] for s in scripts], axis=2)
+    Rz = np.stack([s["R"] for s in scripts], axis=2)
+    truth = np.stack([s["truth"] for s in scripts], axis=1)
+    f.script_load(ctrl, z, Rz, truth=truth)
+
+    # ---- warm-up (untimed) ---------------------------------------------------------------------------
+    f.script_run(0, W, use_graph=bool(args.graph))
+    f.sync()
+    f.reset_stats()
+    f.flush_profile(not args.no_flush_profile)
+    f.flush_profile_read()
+
+    # ---- timed region: exactly K steps ------------------------------------------------------------------
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    f.timer_start()
+    f.script_run(W, K, use_graph=bool(args.graph))
+    dev_ms = f.timer_stop()  # hipEvents on the handle's own stream
+    summary = mc.summarise(f.stats())
+    gathered = mc.gather_stats(summary, device=torch.device("cuda", local_rank))  # the one RCCL collective
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if dist is not None:
+        te = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+
+    # ---- checks outside the timed region --------------------------------------------------------------
+    f.sync()
+    launches, flush_ms = f.flush_profile_read()
+    for b in range(B if B <= 4 else 4):
+        dec = f.decisions(b, K * M)
+        want = [3 + 2 * int(t) for t in scripts[b]["target"][W:].ravel()]
+        assert len(dec) == K * M and all(d[0] == pkg.ekfslam.OLD for d in dec), "filter %d left the Old branch" % b
+        assert [d[1] for d in dec] == want, "filter %d matched an unintended landmark" % b
+    st = f.stats()
+    assert all(s["n_old"] == K * M and s["n_new"] == 0 and s["n_ignore"] == 0 for s in st)
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    total_filter_steps = B * world * K
+    value = total_filter_steps / elapsed
+    nT = (2 * N + 63) // 64
+    tiles = nT * (nT + 1) // 2
+    bytes_per_launch = B * tiles * 4096 * 8 * 2  # every stored P_LL element read once and written once
+    roofline = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                "kernel": "k_flush", "bytes_per_launch": bytes_per_launch, "launches": int(launches), "avg_launch_us": None}
+    if launches:
+        avg_s = flush_ms / 1e3 / launches
+        roofline["avg_launch_us"] = avg_s * 1e6
+        roofline["achieved"] = bytes_per_launch / avg_s / 1e9
+        roofline["frac"] = roofline["achieved"] / HBM_PEAK_GBS
+    tfile = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
+    if os.path.exists(tfile):
+        roofline["traffic"] = json.load(open(tfile)).get("hbm_bytes_per_launch")
+
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(pkg, N, M, seed)
+
+    rep = mc.consistency_report(gathered, K * M, K)
+    line = {
+        "metric": "EKF steps/sec (propagate+full update) at N landmarks",
+        "value": value,
+        "unit": "steps/s",
+        "n_gpus": world,
+        "steps": K,
+        "warmup": W,
+        "ms_per_step": elapsed / K * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": "%s: %d filter(s)/GPU, N=%d landmarks (n=%d, dense P %.1f MB fp64), M=%d Old updates/step, max_pending=%d, graph=%d"
+                               % (args.workload, B, N, 3 + 2 * N, (3 + 2 * N) ** 2 * 8 / 1e6, M, args.max_pending, args.graph),
+                   "N": N, "filters_per_gpu": B, "M": M, "max_pending": args.max_pending},
+        "device_ms_per_step": dev_ms / K,
+        "roofline": roofline,
+        "cpu_baseline": cpu,
+        "consistency": rep,
+    }
+    print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(pkg, N, M, seed):
+    """The oracle's faithful-dense path (same dense O(n^2) passes as the reference, 1 thread: the
+    reference's Makefile:2 has no OpenMP) timed on this host on a bounded sample of the same workload."""
+    import numpy as np
+
+    from oracle import oracle_c as oc
+
+    sample_steps = {4096: 1, 1024: 8, 256: 60}.get(N, 2)
+    x, P = pkg.scenarios.injected_state(N, seed=seed)
+    sc = pkg.scenarios.steady_script(x, steps=sample_steps, M=M, seed=seed + 7919)
+    oc.build()
+    t0 = time.perf_counter()
+    for s in range(sample_steps):
+        v, w, dt = sc["ctrl"][s]
+        x, P = oc.propagate(x, P, v, w, oc.make_Q(v), dt, faithful=True)
+        for m in range(M):
+            x, P, dec, _, _ = oc.update(x, P, sc["z"][s, m].reshape(2, 1), sc["R"][s, m].reshape(2, 2, order="F"), faithful=True)
+            assert dec == [oc.OLD]
+    t = time.perf_counter() - t0
+    return {"value": sample_steps / t, "unit": "steps/s", "cores": 1, "kind": "port",
+            "sample": "%d step(s) of the same workload (1 Propagate + %d Old Updates each) at N=%d, faithful-dense oracle, %.1f s" % (sample_steps, M, N, t),
+            "host_cpus": os.cpu_count()}
+
+
+if __name__ == "__main__":
+    main()

@@ -187,16 +187,20 @@ def test_batch_lockstep_with_masks(pkg, oc):
         z = np.stack([sc["z"][s] for sc in scs])
         R = np.stack([sc["R"][s].reshape(3, 2, 2).transpose(0, 2, 1) for sc in scs])
         gdec = f.update(z, R, valid=valid)
+        zc = np.array([x[2] for x in xs]) + 0.01 + 0.003 * s  # compass reading near the heading BEFORE this step
         if s % 2 == 1:
-            f.update_compass(np.array([x[2] for x in xs]) + 0.01, 0.0005, valid=valid[:, 0])
+            f.update_compass(zc, 0.0005, valid=valid[:, 0])
         for b in range(B):
             v, w, dt = ctrl[b]
             xs[b], Ps[b] = oc.propagate(xs[b], Ps[b], v, w, oc.make_Q(v), dt)
             zs = [j for j in range(3) if valid[b, j]]
             if zs:
-                zc = np.stack([z[b, j] for j in zs], axis=1)
+                zc_ = np.stack([z[b, j] for j in zs], axis=1)
                 Rc = np.concatenate([R[b, j] for j in zs], axis=1)
-                xs[b], Ps[b], dec, mat, _ = oc.update(xs[b], Ps[b], zc, Rc)
+                xs[b], Ps[b], dec, mat, _ = oc.update(xs[b], Ps[b], zc_, Rc)
+                assert oc.NEW not in dec[:-1]
+            if s % 2 == 1 and valid[b, 0]:
+                xs[b], Ps[b] = oc.compass(xs[b], Ps[b], zc[b], 0.0005)
     # the oracle above applied each filter's valid measurements as ONE chunk; the GPU got them as a
     # chunk with holes -- identical as long as no New happened inside a chunk (Update.cpp:26); assert that
     for b in range(B):
