@@ -43,12 +43,8 @@ struct ekf_batch {
     EkfDev dv;
     ekf_params params;
     int device;
-    hipStream_t s_chain;  // k_chain launches (high priority: short, latency-critical)
-    hipStream_t s_flush;  // the dense pass streams through HBM underneath
-    hipEvent_t ev_chain;  // "the chain has finished writing the set being closed"
-    hipEvent_t ev_flush[2];  // "the dense pass that consumed set s has finished"
-    bool flush_valid[2];
-    hipEvent_t ev_join;
+    hipStream_t s_chain;  // the one stream: chain kernels and dense passes alternate on it
+    int chain_wgs;        // k_chain workgroups per filter
     size_t device_bytes;
     int chain_threads;
     // host-side tracking
@@ -56,8 +52,7 @@ struct ekf_batch {
     int cur_set;    // slot set being filled
     int pending;    // slots used in cur_set
     int buf_in;     // Bm buffer the NEXT dense pass reads
-    bool inflight;  // a dense pass may still be running: the chain reads its input buffer + its slot set
-    int prev_count; // slots in the set that pass is consuming
+    bool dbg_skip_flush;  // EKF_DEBUG_SKIP_FLUSH=1: timing experiments only, results are wrong
     // immediate-mode input ring (host-mapped pinned)
     double *ring_h;
     double *ring_d;
@@ -128,10 +123,7 @@ extern "C" int ekf_batch_create(ekf_handle *out, int batch, int capacity_landmar
     if (h->params.log_capacity < 16) h->params.log_capacity = 16;
     h->device = device_id;
     h->device_bytes = 0;
-    int prio_lo = 0, prio_hi = 0;
-    HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-    HIP_TRY(hipStreamCreateWithPriority(&h->s_chain, hipStreamNonBlocking, prio_hi));
-    HIP_TRY(hipStreamCreateWithPriority(&h->s_flush, hipStreamNonBlocking, prio_lo));
+    HIP_TRY(hipStreamCreateWithFlags(&h->s_chain, hipStreamNonBlocking));
 
     EkfDev &dv = h->dv;
     memset(&dv, 0, sizeof dv);
@@ -143,11 +135,24 @@ extern "C" int ekf_batch_create(ekf_handle *out, int batch, int capacity_landmar
     dv.maxp = h->params.max_pending;
     dv.logcap = h->params.log_capacity;
     dv.bm_stride = (size_t)dv.T * (dv.T + 1) / 2 * 4096;
-    dv.f_stride = (size_t)4 * dv.T * dv.maxp * 64;
+    dv.rows = 64 * dv.T;
+    dv.f_stride = (size_t)dv.maxp * dv.rows * 4;
     dv.gamma_max = h->params.gamma_max;
     dv.gamma_min = h->params.gamma_min;
     dv.cond_limit = h->params.cond_limit;
-    h->chain_threads = (capacity_landmarks + 63) / 64 * 64;
+    // k_chain geometry: about one landmark per thread, at most 32 workgroups per filter, and few
+    // enough workgroups in total (<= 256) that all of them are resident at once: the cross-workgroup
+    // barrier needs every workgroup of a filter running
+    int G = (capacity_landmarks + EKF_CHAIN_MAX_THREADS - 1) / EKF_CHAIN_MAX_THREADS;
+    if (G > EKF_CHAIN_MAX_WGS) G = EKF_CHAIN_MAX_WGS;
+    if (G * batch > 256) G = 256 / batch;
+    if (G < 1) G = 1;
+    if (getenv("EKF_CHAIN_WGS")) G = atoi(getenv("EKF_CHAIN_WGS")) > 0 ? atoi(getenv("EKF_CHAIN_WGS")) : G;
+    if (G > EKF_CHAIN_MAX_WGS) G = EKF_CHAIN_MAX_WGS;
+    h->chain_wgs = G;
+    dv.gmax = G;
+    dv.lpw = (capacity_landmarks + G - 1) / G;
+    h->chain_threads = (dv.lpw + 63) / 64 * 64;
     if (h->chain_threads > EKF_CHAIN_MAX_THREADS) h->chain_threads = EKF_CHAIN_MAX_THREADS;
     size_t B = batch;
     hipStream_t s = h->s_chain;
@@ -163,6 +168,8 @@ extern "C" int ekf_batch_create(ekf_handle *out, int batch, int capacity_landmar
     HIP_TRY(dev_alloc_zero(&dv.n_lm_flush, B * 2, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.status, B, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.slot_active, B * 2 * dv.maxp, &h->device_bytes, s));
+    HIP_TRY(dev_alloc_zero(&dv.bar, B * 2, &h->device_bytes, s));
+    HIP_TRY(dev_alloc_zero(&dv.part, B * 2 * dv.gmax * 24, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.log, B * dv.logcap, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.log_count, B, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.stats, B, &h->device_bytes, s));
@@ -179,11 +186,7 @@ extern "C" int ekf_batch_create(ekf_handle *out, int batch, int capacity_landmar
     for (int i = 0; i < 2; i++) {
         HIP_TRY(hipEventCreateWithFlags(&h->ring_ev[i], hipEventDisableTiming));
         h->ring_ev_valid[i] = false;
-        HIP_TRY(hipEventCreateWithFlags(&h->ev_flush[i], hipEventDisableTiming));
-        h->flush_valid[i] = false;
     }
-    HIP_TRY(hipEventCreateWithFlags(&h->ev_chain, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     HIP_TRY(hipEventCreate(&h->t0));
     HIP_TRY(hipEventCreate(&h->t1));
     h->prof_flush = false;
@@ -194,8 +197,7 @@ extern "C" int ekf_batch_create(ekf_handle *out, int batch, int capacity_landmar
     h->cur_set = 0;
     h->pending = 0;
     h->buf_in = 0;
-    h->inflight = false;
-    h->prev_count = 0;
+    h->dbg_skip_flush = getenv("EKF_DEBUG_SKIP_FLUSH") && atoi(getenv("EKF_DEBUG_SKIP_FLUSH")) != 0;
     h->script_d = nullptr;
     h->script_steps = h->script_M = h->script_has_truth = 0;
     h->h_int.resize(B);
@@ -212,21 +214,19 @@ extern "C" int ekf_destroy(ekf_handle h) {
     if (!h) return EKF_OK;
     hipSetDevice(h->device);
     hipStreamSynchronize(h->s_chain);
-    hipStreamSynchronize(h->s_flush);
     for (auto &g : h->graphs) hipGraphExecDestroy(g.exec);
     EkfDev &dv = h->dv;
     hipFree(dv.x), hipFree(dv.R), hipFree(dv.D), hipFree(dv.Bm[0]), hipFree(dv.Bm[1]), hipFree(dv.FA), hipFree(dv.FB);
     hipFree(dv.n_lm), hipFree(dv.n_lm_sweep), hipFree(dv.n_lm_flush), hipFree(dv.status), hipFree(dv.slot_active);
+    hipFree(dv.bar), hipFree(dv.part);
     hipFree(dv.log), hipFree(dv.log_count), hipFree(dv.stats);
     hipFree(h->cursor_d);
     if (h->script_d) hipFree(h->script_d);
     hipHostFree(h->ring_h);
-    for (int i = 0; i < 2; i++) hipEventDestroy(h->ring_ev[i]), hipEventDestroy(h->ev_flush[i]);
-    hipEventDestroy(h->ev_chain), hipEventDestroy(h->ev_join);
+    for (int i = 0; i < 2; i++) hipEventDestroy(h->ring_ev[i]);
     hipEventDestroy(h->t0), hipEventDestroy(h->t1);
     for (auto e : h->prof_pool) hipEventDestroy(e);
     hipStreamDestroy(h->s_chain);
-    hipStreamDestroy(h->s_flush);
     delete h;
     return EKF_OK;
 }
@@ -248,15 +248,14 @@ static int check_launch() {
     return EKF_OK;
 }
 
-// ---- the two-stream pipeline -----------------------------------------------------------------------
-// Close the slot set being filled: hand it to a dense pass on s_flush (Bm[buf_in] -> Bm[buf_in^1]) and
-// let the chain continue into the other set, reading the pass's INPUT buffer plus the closed set.
+// ---- chain / dense-pass alternation ------------------------------------------------------------------
+// Close the slot set being filled: one dense pass folds it, Bm[buf_in] -> Bm[buf_in ^ 1], in stream
+// order after the chain kernels that wrote the set.  The chain continues into the other set and
+// reads the pass's output buffer.
 static int close_set(ekf_batch *h) {
     if (h->pending == 0) return EKF_OK;
     int nT_hi = (2 * h->n_lm_hi + 63) / 64;
-    HIP_TRY(hipEventRecord(h->ev_chain, h->s_chain));
-    HIP_TRY(hipStreamWaitEvent(h->s_flush, h->ev_chain, 0));
-    if (nT_hi > 0) {
+    if (nT_hi > 0 && !h->dbg_skip_flush) {
         int total = nT_hi * (nT_hi + 1) / 2;
         dim3 grid(cdiv(total, 4), h->dv.B);
         if (h->prof_flush) {
@@ -267,32 +266,22 @@ static int close_set(ekf_batch *h) {
             }
             hipEvent_t e0 = h->prof_pool[h->prof_used++], e1 = h->prof_pool[h->prof_used++];
             // start/stop events ride on the dispatch packet itself: no extra barrier packets
-            hipExtLaunchKernelGGL(k_flush, grid, dim3(256), 0, h->s_flush, e0, e1, 0, h->dv, nT_hi, h->cur_set, h->pending, h->buf_in);
+            hipExtLaunchKernelGGL(k_flush, grid, dim3(256), 0, h->s_chain, e0, e1, 0, h->dv, nT_hi, h->cur_set, h->pending, h->buf_in);
         } else {
-            hipLaunchKernelGGL(k_flush, grid, dim3(256), 0, h->s_flush, h->dv, nT_hi, h->cur_set, h->pending, h->buf_in);
+            hipLaunchKernelGGL(k_flush, grid, dim3(256), 0, h->s_chain, h->dv, nT_hi, h->cur_set, h->pending, h->buf_in);
         }
     }
-    HIP_TRY(hipEventRecord(h->ev_flush[h->cur_set], h->s_flush));
-    h->flush_valid[h->cur_set] = true;
-    h->prev_count = h->pending;
     h->buf_in ^= 1;
     h->cur_set ^= 1;
     h->pending = 0;
-    h->inflight = true;
-    // the chain may now write set cur_set and read Bm[buf_in ^ 1]; both need the dense pass that
-    // consumed set cur_set (two closes ago) to have finished
-    if (h->flush_valid[h->cur_set]) HIP_TRY(hipStreamWaitEvent(h->s_chain, h->ev_flush[h->cur_set], 0));
     return check_launch();
 }
 
-// Everything folded into Bm[buf_in], both streams idle.
+// Everything folded into Bm[buf_in], stream idle.
 static int settle(ekf_batch *h) {
     int rc = close_set(h);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(h->s_chain));
-    HIP_TRY(hipStreamSynchronize(h->s_flush));
-    h->inflight = false;
-    h->flush_valid[0] = h->flush_valid[1] = false;
     return EKF_OK;
 }
 
@@ -314,8 +303,8 @@ static int launch_ops(ekf_batch *h, const double *in, const int *cursor, int k0,
             if (rc) return rc;
             continue;
         }
-        hipLaunchKernelGGL(k_chain, dim3(h->dv.B), dim3(h->chain_threads), 0, h->s_chain, h->dv, in, cursor, k0 + start, i - start,
-                           h->pending, h->cur_set, h->inflight ? (h->buf_in ^ 1) : h->buf_in, h->inflight ? h->prev_count : 0);
+        hipLaunchKernelGGL(k_chain, dim3(h->chain_wgs, h->dv.B), dim3(h->chain_threads), 0, h->s_chain, h->dv, in, cursor, k0 + start,
+                           i - start, h->pending, h->cur_set, h->buf_in, 0);
         h->pending = used;
         if (used == h->dv.maxp) {
             int rc = close_set(h);
@@ -489,7 +478,6 @@ extern "C" int ekf_sync(ekf_handle h) {
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipMemcpyAsync(h->h_int.data(), h->dv.status, sizeof(int) * h->dv.B, hipMemcpyDeviceToHost, h->s_chain));
     HIP_TRY(hipStreamSynchronize(h->s_chain));
-    HIP_TRY(hipStreamSynchronize(h->s_flush));
     for (int b = 0; b < h->dv.B; b++)
         if (h->h_int[b] != 0) return set_error(h->h_int[b], "a New landmark did not fit capacity_landmarks");
     return EKF_OK;
@@ -672,7 +660,6 @@ extern "C" int ekf_script_load(ekf_handle h, int steps, int M, const double *ctr
     if (!h || steps < 1 || M < 0 || !ctrl || (M > 0 && (!z || !R))) return set_error(EKF_ERR_BAD_ARG, "bad argument");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->s_chain));
-    HIP_TRY(hipStreamSynchronize(h->s_flush));
     for (auto &g : h->graphs) hipGraphExecDestroy(g.exec);
     h->graphs.clear();
     if (h->script_d) {
@@ -749,8 +736,6 @@ extern "C" int ekf_script_run(ekf_handle h, int first_step, int n_steps, int use
             // a graph starts from the settled state (its predecessor in the stream has fully finished)
             int rc = close_set(h);
             if (rc) return rc;
-            HIP_TRY(hipEventRecord(h->ev_join, h->s_flush));
-            HIP_TRY(hipStreamWaitEvent(h->s_chain, h->ev_join, 0));
             GraphEntry *ge = nullptr;
             for (auto &g : h->graphs)
                 if (g.steps == S && g.M == h->script_M && g.has_truth == h->script_has_truth) ge = &g;
@@ -761,19 +746,15 @@ extern "C" int ekf_script_run(ekf_handle h, int first_step, int n_steps, int use
                 int hi_saved = h->n_lm_hi;
                 h->prof_flush = false;    // event pairs are not captured into graphs
                 h->n_lm_hi = h->dv.Ncap;  // graphs bake grid sizes: size the dense pass for the capacity
-                h->inflight = false;
-                h->flush_valid[0] = h->flush_valid[1] = false;
                 HIP_TRY(hipStreamBeginCapture(h->s_chain, hipStreamCaptureModeThreadLocal));
                 int rc2 = enqueue_script_steps(h, h->cursor_d, 0, S);
                 if (rc2 == EKF_OK && h->pending != 0) rc2 = set_error(EKF_ERR_STATE, "graph block does not end on an empty slot set");
-                hipError_t e1 = hipEventRecord(h->ev_join, h->s_flush);
-                hipError_t e2 = hipStreamWaitEvent(h->s_chain, h->ev_join, 0);
                 hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, h->s_chain, h->cursor_d, S * ops);
                 hipError_t e = hipStreamEndCapture(h->s_chain, &graph);
                 h->prof_flush = prof_saved;
                 h->n_lm_hi = hi_saved;
                 if (rc2) return rc2;
-                if (e1 != hipSuccess || e2 != hipSuccess || e != hipSuccess) return set_error(EKF_ERR_HIP, "graph capture failed");
+                if (e != hipSuccess) return set_error(EKF_ERR_HIP, "graph capture failed");
                 if (h->cur_set != save_set || h->buf_in != save_buf) return set_error(EKF_ERR_STATE, "graph block does not restore the ping-pong state");
                 GraphEntry g;
                 g.steps = S, g.M = h->script_M, g.has_truth = h->script_has_truth;
@@ -789,9 +770,6 @@ extern "C" int ekf_script_run(ekf_handle h, int first_step, int n_steps, int use
                 HIP_TRY(hipGraphLaunch(ge->exec, h->s_chain));
                 s += S;
             }
-            // whatever follows in s_chain runs after the whole graph, dense passes included
-            h->inflight = false;
-            h->flush_valid[0] = h->flush_valid[1] = false;
             h->pending = 0;
             h->n_lm_hi = h->dv.Ncap;  // landmarks may have been appended inside the graphs; unknown until a sync
         }
@@ -815,9 +793,6 @@ extern "C" int ekf_timer_start(ekf_handle h) {
 extern "C" int ekf_timer_stop(ekf_handle h, double *ms_out) {
     if (!h || !ms_out) return set_error(EKF_ERR_BAD_ARG, "null argument");
     HIP_TRY(hipSetDevice(h->device));
-    // t1 comes after both streams: the chain stream waits for the dense passes launched so far
-    HIP_TRY(hipEventRecord(h->ev_join, h->s_flush));
-    HIP_TRY(hipStreamWaitEvent(h->s_chain, h->ev_join, 0));
     HIP_TRY(hipEventRecord(h->t1, h->s_chain));
     HIP_TRY(hipEventSynchronize(h->t1));
     float ms = 0;
@@ -836,7 +811,6 @@ extern "C" int ekf_flush_profile_read(ekf_handle h, long long *launches_out, dou
     if (!h) return set_error(EKF_ERR_BAD_ARG, "null handle");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->s_chain));
-    HIP_TRY(hipStreamSynchronize(h->s_flush));
     for (size_t i = 0; i + 1 < h->prof_used; i += 2) {
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, h->prof_pool[i], h->prof_pool[i + 1]));

@@ -11,8 +11,8 @@
 //
 // Everything the chain kernel decides that changes P_LL is recorded as a rank-4 "slot"
 //       P_LL(i', j') += sum_k FA[i'][k] * FB[j'][k]          (i' <= j', different landmarks)
-// in fragment arrays FA/FB [b][set][rb16][slot][k][r16] -- exactly the A/B operand layout of
-// v_mfma_f64_16x16x4_f64.  An Old-landmark update (Update.cpp:188,193-194) is the slot
+// in arrays FA/FB [b][set][slot][row i'][k]: 16 rows x 4 k = one 512-byte A (or B) operand of
+// v_mfma_f64_16x16x4_f64, and one landmark's two rows = one 64-byte line for the chain kernel.  An Old-landmark update (Update.cpp:188,193-194) is the slot
 // FA = -0.5 [T | K], FB = [K | T] with T = K S; a New landmark (Update.cpp:169-177) is the slot
 // FA = [P_xL | 0], FB = unit rows at the new landmark.  The dense pass applies a whole set of slots
 // in one read of Bm[in] and one write of Bm[out]; two slot sets and two Bm buffers let the chain
@@ -25,8 +25,9 @@
 #include "../../include/ekfslam_c.h"
 
 #define EKF_INF 999999999999.0 /* kalmanfilter.h:17 */
-#define EKF_MAX_PENDING 8
-#define EKF_CHAIN_MAX_THREADS 512
+#define EKF_MAX_PENDING 32
+#define EKF_CHAIN_MAX_THREADS 256
+#define EKF_CHAIN_MAX_WGS 32 /* workgroups sharing one filter in k_chain */
 #define EKF_CHAIN_MAX_OPS 64 /* operations per k_chain launch */
 
 // op records: 8 doubles per (op, filter); r[7] is the type
@@ -41,15 +42,19 @@ struct EkfDev {
     int T;     // 64x64 tiles per side of P_LL
     int maxp;  // slots per set
     int logcap;
-    int pad;
+    int rows;  // 64*T: rows of one slot in FA / FB
+    int lpw;   // landmarks owned by one k_chain workgroup
+    int gmax;  // k_chain workgroups per filter
     size_t bm_stride;  // doubles per filter in one Bm buffer: T(T+1)/2 * 4096
-    size_t f_stride;   // doubles per (filter, set) in FA / FB: 4T * maxp * 64
+    size_t f_stride;   // doubles per (filter, set) in FA / FB: maxp * rows * 4
     double *x, *R, *D;
     double *Bm[2];
     double *FA, *FB;   // [B][2][f_stride]
     int *n_lm, *n_lm_sweep, *status;
     int *n_lm_flush;   // [B][2]: landmark count when set s was last written (sizes its dense pass)
     int *slot_active;  // [B][2][maxp]
+    int *bar;          // [B][2]: cross-workgroup barrier arrivals, exit count
+    double *part;      // [B][2][gmax][24]: per-workgroup arg-min records, double-buffered by barrier parity
     ekf_decision *log;
     long long *log_count;
     ekf_stats *stats;
@@ -72,7 +77,7 @@ __host__ __device__ inline size_t bm_offset(int T, int ip, int jp) {
     return t * 4096 + (size_t)chain * 256 + (size_t)(r >> 1) * 128 + (size_t)(g * 16 + c) * 2 + (r & 1);
 }
 
-// Offset (doubles) of fragment entry (row i', slot m, component k) inside one (filter, set) of FA/FB.
-__host__ __device__ inline size_t f_offset(int maxp, int ip, int m, int k) {
-    return (((size_t)(ip >> 4) * maxp + m) * 4 + k) * 16 + (ip & 15);
+// Offset (doubles) of entry (row i', slot m, component k) inside one (filter, set) of FA / FB.
+__host__ __device__ inline size_t f_offset(int rows, int ip, int m, int k) {
+    return ((size_t)m * rows + ip) * 4 + k;
 }

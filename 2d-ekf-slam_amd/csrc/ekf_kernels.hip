@@ -38,7 +38,7 @@ __device__ __forceinline__ bool cand_better(double da, int ia, double db, int ib
 }
 
 struct ChainLds {
-    // robot state, authoritative while the kernel runs
+    // robot state, authoritative while the kernel runs (every workgroup of a filter holds an identical copy)
     double pose[3];
     double c, s;  // cos/sin of pose[2]
     double Prr[9];
@@ -47,8 +47,10 @@ struct ChainLds {
     // arg-min reduction
     double wd[EKF_CHAIN_MAX_THREADS / 64];
     int wi[EKF_CHAIN_MAX_THREADS / 64];
-    // data of the winning landmark, written by its owner thread
-    double w_res[2], w_S[3], w_hcol[2], w_rc[6], w_dd[3];
+    double gd;  // best Mahalanobis distance over all landmarks, EKF_INF when none
+    int gi;     // its landmark, 0x7fffffff when none
+    // data of the winning landmark: res(2) S00,S01,S11 hcol(2) P_R,Lo(6) D(3)
+    double w[16];
     // header of the branch taken
     int decision, lm;
     double HRt[6];   // H_R^T, 3x2 row-major              (Update.cpp:112-114 / 163-166)
@@ -59,30 +61,44 @@ struct ChainLds {
     double TR[6];    // rows 0..2 of K*S
     double invS;     // compass: 1/S                      (kalmanfilter.cpp:118)
     double newx[2], newrc[6], newdd[3];  // New landmark: state, P_R,new (3x2), 2x2 block
+    // slot rows of the matched landmark, [slot][side A/B][row e][k], and which slots are live
+    double lo_rows[2 * EKF_MAX_PENDING * 16];
+    int slot_on[2 * EKF_MAX_PENDING];  // [0, n_prev): the set a dense pass is consuming; then the set being filled
 };
 
-// P_LL(i', c') as it stands now, for i', c' in different landmarks: the Bm buffer the chain reads
-// plus every slot not yet folded into it.
-__device__ __forceinline__ double pll_current(const EkfDev &dv, const double *Bmr, const double *FAp, const double *FBp,
-                                              const int *act_p, int n_prev, const double *FAc, const double *FBc,
-                                              const int *act_c, int n_cur, int ip, int cp) {
-    int lo = ip < cp ? ip : cp, hi = ip < cp ? cp : ip;
-    double v = Bmr[bm_offset(dv.T, lo, hi)];
-    for (int m = 0; m < n_prev; m++) {
-        if (!act_p[m]) continue;
-        for (int k = 0; k < 4; k++) v = fma(FAp[f_offset(dv.maxp, lo, m, k)], FBp[f_offset(dv.maxp, hi, m, k)], v);
+// Barrier over the G workgroups of one filter (MI355X_MICROARCH.md "Valid forms": every storing wave
+// drains, workgroup barrier, lane-0 agent release, drained, relaxed agent add; one relaxed poll loop,
+// one agent acquire, drained, workgroup barrier, then plain loads).  bar counts arrivals
+// monotonically inside one launch; the last workgroup to leave the kernel zeroes it.  The spin is
+// bounded: on time-out the filter is marked failed instead of hanging the GPU.
+__device__ __forceinline__ void filter_barrier(int *bar, int target, int *status) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(bar, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        long spins = 0;
+        while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1L << 24)) {
+                *status = EKF_ERR_HIP;
+                break;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    for (int m = 0; m < n_cur; m++) {
-        if (!act_c[m]) continue;
-        for (int k = 0; k < 4; k++) v = fma(FAc[f_offset(dv.maxp, lo, m, k)], FBc[f_offset(dv.maxp, hi, m, k)], v);
-    }
-    return v;
+    __syncthreads();
 }
 
 // ---------------------------------------------------------------------------------------------
-// The chain kernel.  grid (B), blockDim = multiple of 64 up to 1024; thread t owns landmarks
-// t, t + blockDim, ...  (their x entries, their columns of the robot rows R, their 2x2 block D,
-// their fragment rows), so only the arg-min and the robot block need workgroup barriers.
+// The chain kernel.  grid (G, B): G workgroups share one filter, workgroup g owns landmarks
+// [g*lpw, (g+1)*lpw) -- their x entries, their columns of the robot rows R, their 2x2 block D,
+// their slot rows -- and thread t of it owns landmarks g*lpw + t, + blockDim, ...
+// Sequential dependencies of the reference become: workgroup barriers around the arg-min and the
+// robot block, plus ONE cross-workgroup barrier per measurement (the arg-min over all landmarks).
+// Every workgroup keeps an identical copy of the robot state and recomputes the gate identically;
+// only workgroup 0 writes logs, statistics, slot flags and, at the end, the robot state.
 //   in/cursor/k0/nops : the operation list
 //   slot0             : first free slot of set `set`
 //   buf_read          : Bm buffer to read P_LL columns from
@@ -90,14 +106,16 @@ __device__ __forceinline__ double pll_current(const EkfDev &dv, const double *Bm
 //                       Bm[buf_read]: its first n_prev slots are not in that buffer yet
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, const double *in, const int *cursor, int k0,
-                                                                int nops, int slot0, int set, int buf_read,
-                                                                int n_prev) {
+                                                                int nops, int slot0, int set, int buf_read, int n_prev) {
     __shared__ ChainLds L;
     __shared__ double recs[EKF_CHAIN_MAX_OPS * 8];
-    const int b = blockIdx.x;
+    const int g = blockIdx.x, G = gridDim.x;
+    const int b = blockIdx.y;
     const int tid = threadIdx.x;
     const int bd = blockDim.x;
+    const bool lead = (g == 0);
     const int xs = dv.xs;
+    const int own_lo = g * dv.lpw, own_hi = own_lo + dv.lpw;  // landmarks this workgroup owns
     double *x = dv.x + (size_t)b * xs;
     double *R0 = dv.R + (size_t)b * 3 * xs;
     double *Dx = dv.D + (size_t)b * 3 * dv.dn;
@@ -108,9 +126,13 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
     const double *FBp = dv.FB + ((size_t)b * 2 + (set ^ 1)) * dv.f_stride;
     int *act_c = dv.slot_active + ((size_t)b * 2 + set) * dv.maxp;
     const int *act_p = dv.slot_active + ((size_t)b * 2 + (set ^ 1)) * dv.maxp;
+    int *bar = dv.bar + (size_t)b * 2;
+    double *part = dv.part + (size_t)b * 2 * dv.gmax * 24;
+    int epoch = 0;  // cross-workgroup barriers passed in this launch
 
     // stage this filter's operation records in LDS (one trip to HBM / host memory for the whole list)
     for (int q = tid; q < nops * 8; q += bd) recs[q] = op_record(in, cursor, k0 + (q >> 3), dv.B, b)[q & 7];
+    for (int q = tid; q < n_prev + slot0; q += bd) L.slot_on[q] = q < n_prev ? act_p[q] : act_c[q - n_prev];
     if (tid == 0) {
         for (int i = 0; i < 3; i++) {
             L.pose[i] = x[i];
@@ -126,7 +148,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
     int slot = slot0;
     for (int op = 0; op < nops; op++) {
         const double *rec = recs + op * 8;
-        const int type = (int)rec[7];  // uniform over the workgroup
+        const int type = (int)rec[7];  // uniform over the filter's workgroups
 
         if (type == OP_PROP) {
             // ---- Propagate.cpp:15-75; rec = (v, w, dt, q00, q10, q01, q11) -------------------------
@@ -139,7 +161,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                 L.pose[1] = L.pose[1] + dt * (v * so);
                 L.pose[2] = L.pose[2] + dt * w;
                 double Phi[9] = {1, 0, -dt * v * so, 0, 1, dt * v * co, 0, 0, 1};  // :42-44
-                double G[6] = {-dt * co, 0, -dt * so, 0, 0, -dt};                 // :46-48
+                double Gm[6] = {-dt * co, 0, -dt * so, 0, 0, -dt};                // :46-48
                 double t1[9], t2[9], GQ[6], Pn[9];
                 // (Phi * P_RR) * Phi^T + (G * Q) * G^T, :53
                 for (int i = 0; i < 3; i++)
@@ -149,9 +171,9 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                     for (int j = 0; j < 3; j++)
                         t2[i * 3 + j] = t1[i * 3] * Phi[j * 3] + t1[i * 3 + 1] * Phi[j * 3 + 1] + t1[i * 3 + 2] * Phi[j * 3 + 2];
                 for (int i = 0; i < 3; i++)
-                    for (int j = 0; j < 2; j++) GQ[i * 2 + j] = G[i * 2] * Q[j] + G[i * 2 + 1] * Q[2 + j];
+                    for (int j = 0; j < 2; j++) GQ[i * 2 + j] = Gm[i * 2] * Q[j] + Gm[i * 2 + 1] * Q[2 + j];
                 for (int i = 0; i < 3; i++)
-                    for (int j = 0; j < 3; j++) Pn[i * 3 + j] = t2[i * 3 + j] + (GQ[i * 2] * G[j * 2] + GQ[i * 2 + 1] * G[j * 2 + 1]);
+                    for (int j = 0; j < 3; j++) Pn[i * 3 + j] = t2[i * 3 + j] + (GQ[i * 2] * Gm[j * 2] + GQ[i * 2 + 1] * Gm[j * 2 + 1]);
                 // 0.5 (P + P^T), :66-67 (a no-op outside this block: P enters bitwise symmetric)
                 for (int i = 0; i < 3; i++)
                     for (int j = 0; j < 3; j++) L.Prr[i * 3 + j] = 0.5 * (Pn[i * 3 + j] + Pn[j * 3 + i]);
@@ -163,8 +185,8 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
             __syncthreads();
             // P_RL <- Phi_R P_RL (:56); P_LR is the same storage
             const double a = L.a, bb = L.b;
-            const int n2 = 2 * L.n_lm;
-            for (int j = tid; j < n2; j += bd) {
+            const int hi = own_hi < L.n_lm ? own_hi : L.n_lm;
+            for (int j = 2 * own_lo + tid; j < 2 * hi; j += bd) {
                 double *Rj = R0 + 3 + j;
                 double p2 = Rj[2 * (size_t)xs];
                 Rj[0] = Rj[0] + a * p2;
@@ -176,7 +198,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
         if (type == OP_TRUTH) {
             // NEES sample e^T P_RR^-1 e against rec = (x, y, phi)
             __syncthreads();
-            if (tid == 0) {
+            if (tid == 0 && lead) {
                 double e0 = L.pose[0] - rec[0], e1 = L.pose[1] - rec[1], e2 = L.pose[2] - rec[2];
                 e2 -= 6.283185307179586 * floor((e2 + 3.141592653589793) / 6.283185307179586);
                 double a = L.Prr[0], bb = L.Prr[1], c = L.Prr[2], d = L.Prr[4], e = L.Prr[5], f = L.Prr[8];
@@ -195,7 +217,8 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
             // a masked measurement: consumes its slot, changes nothing
             __syncthreads();
             if (tid == 0) {
-                act_c[slot] = 0;
+                if (lead) act_c[slot] = 0;
+                L.slot_on[n_prev + slot] = 0;
                 if (rec[6] == 2.0) L.n_sweep = L.n_lm;
             }
             __syncthreads();
@@ -211,12 +234,13 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
             double Prr[9];
             for (int i = 0; i < 9; i++) Prr[i] = L.Prr[i];
             const int n_sweep = L.n_sweep;  // Update.cpp:26: fixed for the whole chunk
+            const int sweep_hi = own_hi < n_sweep ? own_hi : n_sweep;
 
             double best_d = EKF_INF;
             int best_i = 0x7fffffff;
-            double b_res0 = 0, b_res1 = 0, b_S00 = 0, b_S01 = 0, b_S11 = 0, b_h0 = 0, b_h1 = 0;
-            double b_rc[6] = {0, 0, 0, 0, 0, 0}, b_dd[3] = {0, 0, 0};
-            for (int lm = tid; lm < n_sweep; lm += bd) {
+            double bw[16];
+            for (int i = 0; i < 16; i++) bw[i] = 0;
+            for (int lm = own_lo + tid; lm < sweep_hi; lm += bd) {
                 int Li = 3 + 2 * lm;
                 double dp0 = x[Li] - px, dp1 = x[Li + 1] - py;
                 // z_hat = C^T dp (:109), res = z - z_hat (:111)
@@ -263,9 +287,9 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                     double d = (res0 * (S11 * res0 - S01 * res1) + res1 * (S00 * res1 - S01 * res0)) / det;  // :135-136
                     if (best_d > d) {  // :140 (false for NaN); ascending lm, so ties keep the lower index
                         best_d = d, best_i = lm;
-                        b_res0 = res0, b_res1 = res1, b_S00 = S00, b_S01 = S01, b_S11 = S11, b_h0 = h0, b_h1 = h1;
-                        for (int i = 0; i < 6; i++) b_rc[i] = A[i];
-                        b_dd[0] = dxx, b_dd[1] = dxy, b_dd[2] = dyy;
+                        bw[0] = res0, bw[1] = res1, bw[2] = S00, bw[3] = S01, bw[4] = S11, bw[5] = h0, bw[6] = h1;
+                        for (int i = 0; i < 6; i++) bw[7 + i] = A[i];
+                        bw[13] = dxx, bw[14] = dxy, bw[15] = dyy;
                     }
                 }
             }
@@ -286,28 +310,49 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
             int gi = L.wi[0];
             for (int wv = 1; wv < (bd >> 6); wv++)
                 if (cand_better(L.wd[wv], L.wi[wv], gd, gi)) gd = L.wd[wv], gi = L.wi[wv];
-            const bool have = (gi != 0x7fffffff);
-            if (have && gi == best_i) {  // this thread owns the winner
-                L.w_res[0] = b_res0, L.w_res[1] = b_res1;
-                L.w_S[0] = b_S00, L.w_S[1] = b_S01, L.w_S[2] = b_S11;
-                L.w_hcol[0] = b_h0, L.w_hcol[1] = b_h1;
-                for (int i = 0; i < 6; i++) L.w_rc[i] = b_rc[i];
-                for (int i = 0; i < 3; i++) L.w_dd[i] = b_dd[i];
-            }
+            if (gi != 0x7fffffff && gi == best_i)  // this thread owns the workgroup's winner
+                for (int i = 0; i < 16; i++) L.w[i] = bw[i];
+            if (tid == 0) L.gd = gd, L.gi = gi;
             __syncthreads();  // (2)
+            if (G > 1) {
+                // arg-min over the filter's workgroups: publish, barrier, pick (every workgroup picks the same)
+                double *mine = part + ((size_t)(epoch & 1) * dv.gmax + g) * 24;
+                if (tid < 16) mine[tid] = L.w[tid];
+                if (tid == 16) mine[16] = L.gd;
+                if (tid == 17) mine[17] = (double)L.gi;
+                filter_barrier(bar, (epoch + 1) * G, dv.status + b);
+                if (tid == 0) {
+                    double bdv = EKF_INF;
+                    int biv = 0x7fffffff, bg = -1;
+                    for (int q = 0; q < G; q++) {
+                        const double *pr = part + ((size_t)(epoch & 1) * dv.gmax + q) * 24;
+                        double d = pr[16];
+                        int i = (int)pr[17];
+                        if (i != 0x7fffffff && cand_better(d, i, bdv, biv)) bdv = d, biv = i, bg = q;
+                    }
+                    L.gd = bdv, L.gi = biv;
+                    if (bg >= 0) {
+                        const double *pr = part + ((size_t)(epoch & 1) * dv.gmax + bg) * 24;
+                        for (int i = 0; i < 16; i++) L.w[i] = pr[i];
+                    }
+                }
+                epoch++;
+                __syncthreads();
+            }
             // ---- gate + robot block, Update.cpp:152-191 ----------------------------------------------
             if (tid == 0) {
-                const double mahal = have ? gd : EKF_INF;
+                const bool have = (L.gi != 0x7fffffff);
+                const double mahal = have ? L.gd : EKF_INF;
                 int decision;
                 ekf_stats *st = dv.stats + b;
                 const int n_lm = L.n_lm;
+                int on = 0;
                 if (!have || mahal > dv.gamma_max) {  // :152
                     decision = EKF_DECISION_NEW;
-                    st->n_new++;
+                    if (lead) st->n_new++;
                     if (n_lm >= dv.Ncap) {
-                        dv.status[b] = EKF_ERR_CAPACITY;
+                        if (lead) dv.status[b] = EKF_ERR_CAPACITY;
                         L.decision = HDR_NEW_NOFIT;
-                        act_c[slot] = 0;
                     } else {
                         double nl0 = px + (c * z0 - s * z1), nl1 = py + (s * z0 + c * z1);  // :155
                         double dp0 = nl0 - px, dp1 = nl1 - py;
@@ -350,18 +395,20 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                         L.decision = HDR_NEW;
                         L.lm = n_lm;
                         L.n_lm = n_lm + 1;
-                        act_c[slot] = 1;
+                        on = 1;
                     }
                 } else if (mahal < dv.gamma_min) {  // :181
                     decision = EKF_DECISION_OLD;
-                    st->n_old++;
-                    st->nis_sum += mahal;
-                    st->nis_count++;
-                    double S00 = L.w_S[0], S01 = L.w_S[1], S11 = L.w_S[2];
+                    if (lead) {
+                        st->n_old++;
+                        st->nis_sum += mahal;
+                        st->nis_count++;
+                    }
+                    double S00 = L.w[2], S01 = L.w[3], S11 = L.w[4];
                     double det = S00 * S11 - S01 * S01;
                     double Si[4] = {S11 / det, -S01 / det, -S01 / det, S00 / det};
-                    double HRt[6] = {-c, s, -s, -c, L.w_hcol[0], L.w_hcol[1]};  // rows of H_R^T
-                    double res0 = L.w_res[0], res1 = L.w_res[1];
+                    double HRt[6] = {-c, s, -s, -c, L.w[5], L.w[6]};  // rows of H_R^T
+                    double res0 = L.w[0], res1 = L.w[1];
                     double KR[6], TR[6];
                     for (int r = 0; r < 3; r++) {  // :186 for the robot rows
                         double u0 = 0, u1 = 0;
@@ -369,7 +416,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                             u0 += Prr[r * 3 + q] * HRt[q * 2];
                             u1 += Prr[r * 3 + q] * HRt[q * 2 + 1];
                         }
-                        double p0 = L.w_rc[r * 2], p1 = L.w_rc[r * 2 + 1];
+                        double p0 = L.w[7 + r * 2], p1 = L.w[8 + r * 2];
                         double w0 = p0 * c + p1 * s, w1 = p0 * (-s) + p1 * c;  // P[:,Lo:Lo+2] H_Li^T, H_Li^T = C
                         double s0 = u0 + w0, s1 = u1 + w1;
                         KR[r * 2] = s0 * Si[0] + s1 * Si[2];
@@ -392,20 +439,23 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                     L.S[0] = S00, L.S[1] = S01, L.S[2] = S01, L.S[3] = S11;
                     L.res[0] = res0, L.res[1] = res1;
                     L.decision = HDR_OLD;
-                    L.lm = gi;
-                    act_c[slot] = 1;
+                    L.lm = L.gi;
+                    on = 1;
                 } else {
                     decision = EKF_DECISION_IGNORE;  // :191
-                    st->n_ignore++;
+                    if (lead) st->n_ignore++;
                     L.decision = HDR_IGNORE;
-                    act_c[slot] = 0;
                 }
-                long long cnt = dv.log_count[b];
-                ekf_decision *lg = dv.log + (size_t)b * dv.logcap + (cnt % dv.logcap);
-                lg->decision = decision;
-                lg->matched = have ? 3 + 2 * gi : 0;
-                lg->mahal = mahal;
-                dv.log_count[b] = cnt + 1;
+                L.slot_on[n_prev + slot] = on;
+                if (lead) {
+                    act_c[slot] = on;
+                    long long cnt = dv.log_count[b];
+                    ekf_decision *lg = dv.log + (size_t)b * dv.logcap + (cnt % dv.logcap);
+                    lg->decision = decision;
+                    lg->matched = have ? 3 + 2 * L.gi : 0;
+                    lg->mahal = mahal;
+                    dv.log_count[b] = cnt + 1;
+                }
                 if (rec[6] == 2.0) L.n_sweep = L.n_lm;  // last measurement of the chunk
             }
             __syncthreads();  // (3)
@@ -447,21 +497,25 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                 L.invS = invS;
                 L.res[0] = res, L.res[1] = 0;
                 L.decision = HDR_COMPASS;
-                act_c[slot] = 1;
+                L.slot_on[n_prev + slot] = 1;
+                if (lead) act_c[slot] = 1;
             }
             __syncthreads();
         } else {
             continue;  // OP_NOP
         }
 
-        // ---- landmark part of the branch taken: K rows, x += K res, R and D, fragment slot ---------
+        // ---- landmark part of the branch taken: K rows, x += K res, R and D, the slot ----------------
         const int decision = L.decision;
         if (decision == HDR_NEW) {
             const int ln = L.lm;
             const double c = L.c, s = L.s;  // pose is unchanged by New
-            for (int lm = tid; lm <= ln; lm += bd) {
+            const int hi = own_hi < ln + 1 ? own_hi : ln + 1;
+            for (int lm = own_lo + tid; lm < hi; lm += bd) {
                 int ip = 2 * lm, i0 = 3 + ip;
+                double *fa = FAc + f_offset(dv.rows, ip, slot, 0), *fb = FBc + f_offset(dv.rows, ip, slot, 0);
                 if (lm < ln) {
+                    double v[2][2];
                     for (int a = 0; a < 2; a++) {
                         double u0 = 0, u1 = 0;
                         for (int q = 0; q < 3; q++) {  // ((-P[i,0:3]) H_R^T) H_Li, Update.cpp:169
@@ -469,12 +523,14 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                             u0 += p * L.HRt[q * 2];
                             u1 += p * L.HRt[q * 2 + 1];
                         }
-                        FAc[f_offset(dv.maxp, ip + a, slot, 0)] = u0 * c + u1 * (-s);
-                        FAc[f_offset(dv.maxp, ip + a, slot, 1)] = u0 * s + u1 * c;
-                        FAc[f_offset(dv.maxp, ip + a, slot, 2)] = 0;
-                        FAc[f_offset(dv.maxp, ip + a, slot, 3)] = 0;
-                        for (int k = 0; k < 4; k++) FBc[f_offset(dv.maxp, ip + a, slot, k)] = 0;
+                        v[a][0] = u0 * c + u1 * (-s);
+                        v[a][1] = u0 * s + u1 * c;
                     }
+                    // slot: column pair of the new landmark = A[i] . unit rows of B
+                    *(double4_t *)fa = (double4_t){v[0][0], v[0][1], 0, 0};
+                    *(double4_t *)(fa + 4) = (double4_t){v[1][0], v[1][1], 0, 0};
+                    *(double4_t *)fb = (double4_t){0, 0, 0, 0};
+                    *(double4_t *)(fb + 4) = (double4_t){0, 0, 0, 0};
                 } else {  // the new landmark itself: state, robot columns, 2x2 block, unit B rows
                     x[i0] = L.newx[0];
                     x[i0 + 1] = L.newx[1];
@@ -485,11 +541,10 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                     Dx[lm] = L.newdd[0];
                     Dx[dv.dn + lm] = L.newdd[1];
                     Dx[2 * (size_t)dv.dn + lm] = L.newdd[2];
-                    for (int a = 0; a < 2; a++)
-                        for (int k = 0; k < 4; k++) {
-                            FAc[f_offset(dv.maxp, ip + a, slot, k)] = 0;
-                            FBc[f_offset(dv.maxp, ip + a, slot, k)] = (k == a) ? 1.0 : 0.0;
-                        }
+                    *(double4_t *)fa = (double4_t){0, 0, 0, 0};
+                    *(double4_t *)(fa + 4) = (double4_t){0, 0, 0, 0};
+                    *(double4_t *)fb = (double4_t){1, 0, 0, 0};
+                    *(double4_t *)(fb + 4) = (double4_t){0, 1, 0, 0};
                 }
             }
         } else if (decision == HDR_OLD || decision == HDR_COMPASS) {
@@ -499,26 +554,64 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
             // the rotation the header was built with: H_Li^T = C of the pose BEFORE this update.
             // L.c/L.s already hold the updated heading, so take C from H_R^T = [-C | ...]^T.
             const double c = -L.HRt[0], s = L.HRt[1];
-            for (int lm = tid; lm < n_lm; lm += bd) {
+            const int nsl = n_prev + slot;  // slots not yet folded into Bm[buf_read]
+            if (decision == HDR_OLD) {
+                // stage the matched landmark's rows of every such slot in LDS
+                for (int q = tid; q < nsl * 16; q += bd) {
+                    int sidx = q >> 4, side = (q >> 3) & 1, e = (q >> 2) & 1, k = q & 3;
+                    bool isprev = sidx < n_prev;
+                    int m = isprev ? sidx : sidx - n_prev;
+                    const double *F = side == 0 ? (isprev ? FAp : (const double *)FAc) : (isprev ? FBp : (const double *)FBc);
+                    L.lo_rows[q] = L.slot_on[sidx] ? F[f_offset(dv.rows, jo + e, m, k)] : 0.0;
+                }
+                __syncthreads();  // (4)
+            }
+            const int hi = own_hi < n_lm ? own_hi : n_lm;
+            for (int lm = own_lo + tid; lm < hi; lm += bd) {
                 int ip = 2 * lm, i0 = 3 + ip;
                 double K[2][2], Tt[2][2];
                 if (decision == HDR_OLD) {
-                    for (int a = 0; a < 2; a++) {
-                        double p20, p21;  // P[i, Lo], P[i, Lo+1]
-                        if (lm == lo) {
-                            p20 = (a == 0) ? Dx[lm] : Dx[dv.dn + lm];
-                            p21 = (a == 0) ? Dx[dv.dn + lm] : Dx[2 * (size_t)dv.dn + lm];
-                        } else {
-                            p20 = pll_current(dv, Bmr, FAp, FBp, act_p, n_prev, FAc, FBc, act_c, slot, ip + a, jo);
-                            p21 = pll_current(dv, Bmr, FAp, FBp, act_p, n_prev, FAc, FBc, act_c, slot, ip + a, jo + 1);
+                    double p[2][2];  // P[i, Lo], P[i, Lo+1] for the two rows of this landmark
+                    if (lm == lo) {
+                        p[0][0] = Dx[lm], p[0][1] = Dx[dv.dn + lm];
+                        p[1][0] = Dx[dv.dn + lm], p[1][1] = Dx[2 * (size_t)dv.dn + lm];
+                    } else {
+                        const bool below = lm < lo;  // stored as (row of the older landmark, column of the newer)
+                        for (int a = 0; a < 2; a++)
+                            for (int e = 0; e < 2; e++)
+                                p[a][e] = below ? Bmr[bm_offset(dv.T, ip + a, jo + e)] : Bmr[bm_offset(dv.T, jo + e, ip + a)];
+                        // fold the pending slots four at a time: eight independent 32-byte loads in flight.
+                        // Dead slots carry zero weights in L.lo_rows and re-read slot 0 (always valid memory).
+                        for (int s0 = 0; s0 < nsl; s0 += 4) {
+                            double4_t o0[4], o1[4];
+#pragma unroll
+                            for (int q = 0; q < 4; q++) {
+                                int sidx = (s0 + q < nsl && L.slot_on[s0 + q]) ? s0 + q : -1;
+                                bool isprev = sidx >= 0 && sidx < n_prev;
+                                int m = sidx < 0 ? 0 : (isprev ? sidx : sidx - n_prev);
+                                const double *Fown = (below ? (isprev ? FAp : (const double *)FAc) : (isprev ? FBp : (const double *)FBc)) + f_offset(dv.rows, ip, m, 0);
+                                o0[q] = *(const double4_t *)Fown;
+                                o1[q] = *(const double4_t *)(Fown + 4);
+                            }
+#pragma unroll
+                            for (int q = 0; q < 4; q++) {
+                                if (!(s0 + q < nsl && L.slot_on[s0 + q])) continue;
+                                const double *lr = L.lo_rows + (s0 + q) * 16 + (below ? 8 : 0);
+                                for (int e = 0; e < 2; e++) {
+                                    p[0][e] += o0[q].x * lr[e * 4] + o0[q].y * lr[e * 4 + 1] + o0[q].z * lr[e * 4 + 2] + o0[q].w * lr[e * 4 + 3];
+                                    p[1][e] += o1[q].x * lr[e * 4] + o1[q].y * lr[e * 4 + 1] + o1[q].z * lr[e * 4 + 2] + o1[q].w * lr[e * 4 + 3];
+                                }
+                            }
                         }
+                    }
+                    for (int a = 0; a < 2; a++) {
                         double u0 = 0, u1 = 0;
                         for (int q = 0; q < 3; q++) {  // P[i,0:3] H_R^T, Update.cpp:186
-                            double p = R0[(size_t)q * xs + i0 + a];
-                            u0 += p * L.HRt[q * 2];
-                            u1 += p * L.HRt[q * 2 + 1];
+                            double pr = R0[(size_t)q * xs + i0 + a];
+                            u0 += pr * L.HRt[q * 2];
+                            u1 += pr * L.HRt[q * 2 + 1];
                         }
-                        double w0 = p20 * c + p21 * s, w1 = p20 * (-s) + p21 * c;  // P[i,Lo:Lo+2] H_Li^T
+                        double w0 = p[a][0] * c + p[a][1] * s, w1 = p[a][0] * (-s) + p[a][1] * c;  // P[i,Lo:Lo+2] H_Li^T
                         double s0 = u0 + w0, s1 = u1 + w1;
                         K[a][0] = s0 * L.Sinv[0] + s1 * L.Sinv[2];
                         K[a][1] = s0 * L.Sinv[1] + s1 * L.Sinv[3];
@@ -543,17 +636,12 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                 Dx[lm] -= sym_u(Tt[0][0], Tt[0][1], K[0][0], K[0][1], Tt[0][0], Tt[0][1], K[0][0], K[0][1]);
                 Dx[dv.dn + lm] -= sym_u(Tt[0][0], Tt[0][1], K[0][0], K[0][1], Tt[1][0], Tt[1][1], K[1][0], K[1][1]);
                 Dx[2 * (size_t)dv.dn + lm] -= sym_u(Tt[1][0], Tt[1][1], K[1][0], K[1][1], Tt[1][0], Tt[1][1], K[1][0], K[1][1]);
-                // slot: P_LL += A B^T with A = -0.5 [T | K], B = [K | T]
-                for (int a = 0; a < 2; a++) {
-                    FAc[f_offset(dv.maxp, ip + a, slot, 0)] = -0.5 * Tt[a][0];
-                    FAc[f_offset(dv.maxp, ip + a, slot, 1)] = -0.5 * Tt[a][1];
-                    FAc[f_offset(dv.maxp, ip + a, slot, 2)] = -0.5 * K[a][0];
-                    FAc[f_offset(dv.maxp, ip + a, slot, 3)] = -0.5 * K[a][1];
-                    FBc[f_offset(dv.maxp, ip + a, slot, 0)] = K[a][0];
-                    FBc[f_offset(dv.maxp, ip + a, slot, 1)] = K[a][1];
-                    FBc[f_offset(dv.maxp, ip + a, slot, 2)] = Tt[a][0];
-                    FBc[f_offset(dv.maxp, ip + a, slot, 3)] = Tt[a][1];
-                }
+                // slot: P_LL += A B^T with A = -0.5 [T | K], B = [K | T]; one 64-byte line per landmark and side
+                double *fa = FAc + f_offset(dv.rows, ip, slot, 0), *fb = FBc + f_offset(dv.rows, ip, slot, 0);
+                *(double4_t *)fa = (double4_t){-0.5 * Tt[0][0], -0.5 * Tt[0][1], -0.5 * K[0][0], -0.5 * K[0][1]};
+                *(double4_t *)(fa + 4) = (double4_t){-0.5 * Tt[1][0], -0.5 * Tt[1][1], -0.5 * K[1][0], -0.5 * K[1][1]};
+                *(double4_t *)fb = (double4_t){K[0][0], K[0][1], Tt[0][0], Tt[0][1]};
+                *(double4_t *)(fb + 4) = (double4_t){K[1][0], K[1][1], Tt[1][0], Tt[1][1]};
             }
         }
         slot++;
@@ -561,13 +649,23 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
 
     __syncthreads();
     if (tid == 0) {
-        for (int i = 0; i < 3; i++) {
-            x[i] = L.pose[i];
-            for (int j = 0; j < 3; j++) R0[(size_t)i * xs + j] = L.Prr[i * 3 + j];
+        if (lead) {
+            for (int i = 0; i < 3; i++) {
+                x[i] = L.pose[i];
+                for (int j = 0; j < 3; j++) R0[(size_t)i * xs + j] = L.Prr[i * 3 + j];
+            }
+            dv.n_lm[b] = L.n_lm;
+            dv.n_lm_sweep[b] = L.n_sweep;
+            dv.n_lm_flush[(size_t)b * 2 + set] = L.n_lm;
         }
-        dv.n_lm[b] = L.n_lm;
-        dv.n_lm_sweep[b] = L.n_sweep;
-        dv.n_lm_flush[(size_t)b * 2 + set] = L.n_lm;
+        if (G > 1) {
+            // the last workgroup of this filter to leave re-arms the barrier for the next launch
+            int prev = __hip_atomic_fetch_add(bar + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (prev == G - 1) {
+                __hip_atomic_store(bar, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(bar + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
     }
 }
 
@@ -615,8 +713,9 @@ __global__ __launch_bounds__(256, 2) void k_flush(EkfDev dv, int nT_hi, int set,
         double av[4], bv[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            av[q] = FA[((size_t)(4 * I + q) * dv.maxp + m) * 64 + lane];
-            bv[q] = FB[((size_t)(4 * J + q) * dv.maxp + m) * 64 + lane];
+            // lane l supplies row (l & 15), k = l >> 4 of a 16-row x 4 block: 512 contiguous bytes
+            av[q] = FA[((size_t)m * dv.rows + 64 * I + 16 * q + (lane & 15)) * 4 + (lane >> 4)];
+            bv[q] = FB[((size_t)m * dv.rows + 64 * J + 16 * q + (lane & 15)) * 4 + (lane >> 4)];
         }
 #pragma unroll
         for (int rc = 0; rc < 4; rc++)

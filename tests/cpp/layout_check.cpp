@@ -1,6 +1,6 @@
 // Host-only check of the HBM index maps in ekf_device.h: bm_offset must be a bijection from the
 // stored (i', j') pairs onto [0, tiles*4096) and agree with the MFMA C/D fragment order the dense
-// pass assumes; f_offset must be a bijection onto the fragment array.
+// pass assumes; f_offset must be a bijection onto the slot array with one landmark per 64-byte line.
 #include <cstdio>
 #include <vector>
 
@@ -33,18 +33,17 @@ int main() {
                             if (bm_offset(T, row, col) != want) return printf("fragment order mismatch\n"), 1;
                         }
         }
-    const int maxp = 3;
-    std::vector<int> fh((size_t)4 * T * maxp * 64, 0);
+    const int maxp = 3, rows = 64 * T;
+    std::vector<int> fh((size_t)maxp * rows * 4, 0);
     for (int i = 0; i < n; i++)
         for (int m = 0; m < maxp; m++)
-            for (int k = 0; k < 4; k++) fh[f_offset(maxp, i, m, k)]++;
+            for (int k = 0; k < 4; k++) fh[f_offset(rows, i, m, k)]++;
     for (size_t o = 0; o < fh.size(); o++)
         if (fh[o] != 1) return printf("f_offset %zu hit %d times\n", o, fh[o]), 1;
-    // A-operand order of v_mfma_f64_16x16x4_f64: lane l reads row (l & 15), k = l >> 4 at base + l
-    for (int rb = 0; rb < 4 * T; rb++)
-        for (int m = 0; m < maxp; m++)
-            for (int l = 0; l < 64; l++)
-                if (f_offset(maxp, 16 * rb + (l & 15), m, l >> 4) != ((size_t)rb * maxp + m) * 64 + l) return printf("A-fragment order mismatch\n"), 1;
+    // one landmark's two rows of a slot are one 64-byte line; a 16-row block is 512 contiguous bytes
+    for (int m = 0; m < maxp; m++)
+        for (int i = 0; i < n; i += 2)
+            if (f_offset(rows, i + 1, m, 3) - f_offset(rows, i, m, 0) != 7 || (f_offset(rows, i, m, 0) % 8) != 0) return printf("landmark line mismatch\n"), 1;
     printf("layout ok\n");
     return 0;
 }
