@@ -52,6 +52,7 @@ struct ekf_batch {
     int cur_set;    // slot set being filled
     int pending;    // slots used in cur_set
     int buf_in;     // Bm buffer the NEXT dense pass reads
+    int flush_variant;    // EKF_FLUSH_VARIANT: 0 = one wave per 64x64 tile, 1 = one wave per 32x32 quadrant
     bool dbg_skip_flush;  // EKF_DEBUG_SKIP_FLUSH=1: timing experiments only, results are wrong
     // immediate-mode input ring (host-mapped pinned)
     double *ring_h;
@@ -136,7 +137,7 @@ extern "C" int ekf_batch_create(ekf_handle *out, int batch, int capacity_landmar
     dv.logcap = h->params.log_capacity;
     dv.bm_stride = (size_t)dv.T * (dv.T + 1) / 2 * 4096;
     dv.rows = 64 * dv.T;
-    dv.f_stride = (size_t)dv.maxp * dv.rows * 4;
+    dv.f_stride = (size_t)(dv.maxp + 1) * dv.rows * 4;
     dv.gamma_max = h->params.gamma_max;
     dv.gamma_min = h->params.gamma_min;
     dv.cond_limit = h->params.cond_limit;
@@ -160,7 +161,7 @@ extern "C" int ekf_batch_create(ekf_handle *out, int batch, int capacity_landmar
     HIP_TRY(dev_alloc_zero(&dv.R, B * 3 * dv.xs, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.D, B * 3 * dv.dn, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.Bm[0], B * dv.bm_stride, &h->device_bytes, s));
-    HIP_TRY(dev_alloc_zero(&dv.Bm[1], B * dv.bm_stride, &h->device_bytes, s));
+    dv.Bm[1] = dv.Bm[0];  // one buffer: the dense pass runs in place (k_chain keeps its two-buffer interface)
     HIP_TRY(dev_alloc_zero(&dv.FA, B * 2 * dv.f_stride, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.FB, B * 2 * dv.f_stride, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.n_lm, B, &h->device_bytes, s));
@@ -169,6 +170,7 @@ extern "C" int ekf_batch_create(ekf_handle *out, int batch, int capacity_landmar
     HIP_TRY(dev_alloc_zero(&dv.status, B, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.slot_active, B * 2 * dv.maxp, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.bar, B * 2, &h->device_bytes, s));
+    HIP_TRY(dev_alloc_zero(&dv.dbg, 16, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.part, B * 2 * dv.gmax * 24, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.log, B * dv.logcap, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.log_count, B, &h->device_bytes, s));
@@ -197,6 +199,7 @@ extern "C" int ekf_batch_create(ekf_handle *out, int batch, int capacity_landmar
     h->cur_set = 0;
     h->pending = 0;
     h->buf_in = 0;
+    h->flush_variant = getenv("EKF_FLUSH_VARIANT") ? atoi(getenv("EKF_FLUSH_VARIANT")) : 0;
     h->dbg_skip_flush = getenv("EKF_DEBUG_SKIP_FLUSH") && atoi(getenv("EKF_DEBUG_SKIP_FLUSH")) != 0;
     h->script_d = nullptr;
     h->script_steps = h->script_M = h->script_has_truth = 0;
@@ -216,9 +219,9 @@ extern "C" int ekf_destroy(ekf_handle h) {
     hipStreamSynchronize(h->s_chain);
     for (auto &g : h->graphs) hipGraphExecDestroy(g.exec);
     EkfDev &dv = h->dv;
-    hipFree(dv.x), hipFree(dv.R), hipFree(dv.D), hipFree(dv.Bm[0]), hipFree(dv.Bm[1]), hipFree(dv.FA), hipFree(dv.FB);
+    hipFree(dv.x), hipFree(dv.R), hipFree(dv.D), hipFree(dv.Bm[0]), hipFree(dv.FA), hipFree(dv.FB);
     hipFree(dv.n_lm), hipFree(dv.n_lm_sweep), hipFree(dv.n_lm_flush), hipFree(dv.status), hipFree(dv.slot_active);
-    hipFree(dv.bar), hipFree(dv.part);
+    hipFree(dv.bar), hipFree(dv.part), hipFree(dv.dbg);
     hipFree(dv.log), hipFree(dv.log_count), hipFree(dv.stats);
     hipFree(h->cursor_d);
     if (h->script_d) hipFree(h->script_d);
@@ -249,15 +252,15 @@ static int check_launch() {
 }
 
 // ---- chain / dense-pass alternation ------------------------------------------------------------------
-// Close the slot set being filled: one dense pass folds it, Bm[buf_in] -> Bm[buf_in ^ 1], in stream
-// order after the chain kernels that wrote the set.  The chain continues into the other set and
-// reads the pass's output buffer.
+// Close the slot set being filled: one dense pass folds it into Bm in place, in stream order after
+// the chain kernels that wrote the set.  The chain continues into the other set.
 static int close_set(ekf_batch *h) {
     if (h->pending == 0) return EKF_OK;
     int nT_hi = (2 * h->n_lm_hi + 63) / 64;
     if (nT_hi > 0 && !h->dbg_skip_flush) {
         int total = nT_hi * (nT_hi + 1) / 2;
-        dim3 grid(cdiv(total, 4), h->dv.B);
+        dim3 grid(h->flush_variant == 1 ? total : cdiv(total, 4), h->dv.B);
+        auto kern = h->flush_variant == 1 ? k_flush_q : k_flush;
         if (h->prof_flush) {
             while (h->prof_pool.size() < h->prof_used + 2) {
                 hipEvent_t e;
@@ -266,12 +269,11 @@ static int close_set(ekf_batch *h) {
             }
             hipEvent_t e0 = h->prof_pool[h->prof_used++], e1 = h->prof_pool[h->prof_used++];
             // start/stop events ride on the dispatch packet itself: no extra barrier packets
-            hipExtLaunchKernelGGL(k_flush, grid, dim3(256), 0, h->s_chain, e0, e1, 0, h->dv, nT_hi, h->cur_set, h->pending, h->buf_in);
+            hipExtLaunchKernelGGL(kern, grid, dim3(256), 0, h->s_chain, e0, e1, 0, h->dv, nT_hi, h->cur_set, h->pending, h->buf_in);
         } else {
-            hipLaunchKernelGGL(k_flush, grid, dim3(256), 0, h->s_chain, h->dv, nT_hi, h->cur_set, h->pending, h->buf_in);
+            hipLaunchKernelGGL(kern, grid, dim3(256), 0, h->s_chain, h->dv, nT_hi, h->cur_set, h->pending, h->buf_in);
         }
     }
-    h->buf_in ^= 1;
     h->cur_set ^= 1;
     h->pending = 0;
     return check_launch();
@@ -614,7 +616,7 @@ extern "C" int ekf_set_state(ekf_handle h, int index, const double *x, const dou
     if (e == hipSuccess) e = hipMemsetAsync(dv.x + b * dv.xs, 0, sizeof(double) * dv.xs, s);
     if (e == hipSuccess) e = hipMemsetAsync(dv.R + b * 3 * dv.xs, 0, sizeof(double) * 3 * dv.xs, s);
     if (e == hipSuccess) e = hipMemsetAsync(dv.D + b * 3 * dv.dn, 0, sizeof(double) * 3 * dv.dn, s);
-    for (int q = 0; q < 2 && e == hipSuccess; q++) e = hipMemsetAsync(dv.Bm[q] + b * dv.bm_stride, 0, sizeof(double) * dv.bm_stride, s);
+    if (e == hipSuccess) e = hipMemsetAsync(dv.Bm[0] + b * dv.bm_stride, 0, sizeof(double) * dv.bm_stride, s);
     if (e == hipSuccess) e = hipMemsetAsync(dv.FA + b * 2 * dv.f_stride, 0, sizeof(double) * 2 * dv.f_stride, s);
     if (e == hipSuccess) e = hipMemsetAsync(dv.FB + b * 2 * dv.f_stride, 0, sizeof(double) * 2 * dv.f_stride, s);
     if (e == hipSuccess) {
@@ -639,8 +641,7 @@ extern "C" int ekf_broadcast_state(ekf_handle h) {
         HIP_TRY(hipMemcpyAsync(dv.x + (size_t)b * dv.xs, dv.x, sizeof(double) * dv.xs, hipMemcpyDeviceToDevice, s));
         HIP_TRY(hipMemcpyAsync(dv.R + (size_t)b * 3 * dv.xs, dv.R, sizeof(double) * 3 * dv.xs, hipMemcpyDeviceToDevice, s));
         HIP_TRY(hipMemcpyAsync(dv.D + (size_t)b * 3 * dv.dn, dv.D, sizeof(double) * 3 * dv.dn, hipMemcpyDeviceToDevice, s));
-        for (int q = 0; q < 2; q++)
-            HIP_TRY(hipMemcpyAsync(dv.Bm[q] + (size_t)b * dv.bm_stride, dv.Bm[q], sizeof(double) * dv.bm_stride, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipMemcpyAsync(dv.Bm[0] + (size_t)b * dv.bm_stride, dv.Bm[0], sizeof(double) * dv.bm_stride, hipMemcpyDeviceToDevice, s));
         HIP_TRY(hipMemcpyAsync(dv.FA + (size_t)b * 2 * dv.f_stride, dv.FA, sizeof(double) * 2 * dv.f_stride, hipMemcpyDeviceToDevice, s));
         HIP_TRY(hipMemcpyAsync(dv.FB + (size_t)b * 2 * dv.f_stride, dv.FB, sizeof(double) * 2 * dv.f_stride, hipMemcpyDeviceToDevice, s));
         HIP_TRY(hipMemcpyAsync(dv.slot_active + (size_t)b * 2 * dv.maxp, dv.slot_active, sizeof(int) * 2 * dv.maxp, hipMemcpyDeviceToDevice, s));
@@ -780,6 +781,16 @@ extern "C" int ekf_script_run(ekf_handle h, int first_step, int n_steps, int use
         if (rc) return rc;
     }
     return check_launch();
+}
+
+// Diagnostic tick counters of EKF_CHAIN_STAMPS builds (not declared in the public header).
+extern "C" int ekf_debug_stamps(ekf_handle h, long long *out16, int reset) {
+    if (!h || !out16) return EKF_ERR_BAD_ARG;
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->s_chain));
+    HIP_TRY(hipMemcpy(out16, h->dv.dbg, 16 * sizeof(long long), hipMemcpyDeviceToHost));
+    if (reset) HIP_TRY(hipMemset(h->dv.dbg, 0, 16 * sizeof(long long)));
+    return EKF_OK;
 }
 
 // ---- timing ---------------------------------------------------------------------------------------

@@ -46,7 +46,7 @@ struct EkfDev {
     int lpw;   // landmarks owned by one k_chain workgroup
     int gmax;  // k_chain workgroups per filter
     size_t bm_stride;  // doubles per filter in one Bm buffer: T(T+1)/2 * 4096
-    size_t f_stride;   // doubles per (filter, set) in FA / FB: maxp * rows * 4
+    size_t f_stride;   // doubles per (filter, set) in FA / FB: (maxp + 1) * rows * 4; slot maxp stays all zero
     double *x, *R, *D;
     double *Bm[2];
     double *FA, *FB;   // [B][2][f_stride]
@@ -54,6 +54,7 @@ struct EkfDev {
     int *n_lm_flush;   // [B][2]: landmark count when set s was last written (sizes its dense pass)
     int *slot_active;  // [B][2][maxp]
     int *bar;          // [B][2]: cross-workgroup barrier arrivals, exit count
+    long long *dbg;    // [16] diagnostic tick counters (EKF_CHAIN_STAMPS builds)
     double *part;      // [B][2][gmax][24]: per-workgroup arg-min records, double-buffered by barrier parity
     ekf_decision *log;
     long long *log_count;

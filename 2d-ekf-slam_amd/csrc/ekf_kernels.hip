@@ -66,6 +66,21 @@ struct ChainLds {
     int slot_on[2 * EKF_MAX_PENDING];  // [0, n_prev): the set a dense pass is consuming; then the set being filled
 };
 
+// Diagnostic build (-DEKF_CHAIN_STAMPS): workgroup 0's thread 0 adds the 100 MHz wall-clock ticks each
+// segment of a measurement takes into dv.dbg[0..7]; nothing else reads that buffer.
+#ifdef EKF_CHAIN_STAMPS
+#define STAMP(slot_)                                                         \
+    do {                                                                     \
+        if (tid == 0 && g == 0 && b == 0) {                                  \
+            unsigned long long now_ = __builtin_amdgcn_s_memrealtime();      \
+            dv.dbg[slot_] += (long long)(now_ - stamp_t);                    \
+            stamp_t = now_;                                                  \
+        }                                                                    \
+    } while (0)
+#else
+#define STAMP(slot_) do { } while (0)
+#endif
+
 // Barrier over the G workgroups of one filter (MI355X_MICROARCH.md "Valid forms": every storing wave
 // drains, workgroup barrier, lane-0 agent release, drained, relaxed agent add; one relaxed poll loop,
 // one agent acquire, drained, workgroup barrier, then plain loads).  bar counts arrivals
@@ -122,13 +137,51 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
     const double *Bmr = dv.Bm[buf_read] + (size_t)b * dv.bm_stride;
     double *FAc = dv.FA + ((size_t)b * 2 + set) * dv.f_stride;
     double *FBc = dv.FB + ((size_t)b * 2 + set) * dv.f_stride;
-    const double *FAp = dv.FA + ((size_t)b * 2 + (set ^ 1)) * dv.f_stride;
-    const double *FBp = dv.FB + ((size_t)b * 2 + (set ^ 1)) * dv.f_stride;
     int *act_c = dv.slot_active + ((size_t)b * 2 + set) * dv.maxp;
     const int *act_p = dv.slot_active + ((size_t)b * 2 + (set ^ 1)) * dv.maxp;
     int *bar = dv.bar + (size_t)b * 2;
     double *part = dv.part + (size_t)b * 2 * dv.gmax * 24;
     int epoch = 0;  // cross-workgroup barriers passed in this launch
+#ifdef EKF_CHAIN_STAMPS
+    unsigned long long stamp_t = __builtin_amdgcn_s_memrealtime();
+#endif
+
+    // P[rows of lm, columns of lo] as stored in Bm[buf_read] (row index = the older landmark)
+    // slot arrays addressed as base + set offset: a 4-way pointer select would become a scratch table
+    const double *FAb = dv.FA + (size_t)b * 2 * dv.f_stride, *FBb = dv.FB + (size_t)b * 2 * dv.f_stride;
+    const size_t off_c = (size_t)set * dv.f_stride, off_p = (size_t)(set ^ 1) * dv.f_stride;
+    const int T_ = dv.T, rows_ = dv.rows;  // by-value captures: a reference to dv would push the kernel arguments to scratch
+    auto load_old_inputs = [=](int lm, int lo, double p[2][2]) {
+        const bool below = lm < lo;
+        const int ip = 2 * lm, jo = 2 * lo;
+        for (int a = 0; a < 2; a++)
+            for (int e = 0; e < 2; e++) p[a][e] = below ? Bmr[bm_offset(T_, ip + a, jo + e)] : Bmr[bm_offset(T_, jo + e, ip + a)];
+    };
+    // this landmark's rows of slots [s0, s0 + 4): eight independent 32-byte loads.  Dead or absent
+    // slots re-read slot 0 of the current set (always valid memory); fold_chunk skips them.
+    auto load_chunk = [=](int ip, bool below, int s0, int nsl, double4_t *o0, double4_t *o1) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            int sidx = (s0 + q < nsl && L.slot_on[s0 + q]) ? s0 + q : -1;
+            bool isprev = sidx >= 0 && sidx < n_prev;
+            int m = sidx < 0 ? 0 : (isprev ? sidx : sidx - n_prev);
+            // own rows come from the A side when this landmark supplies the row index, else from the B side
+            const double *Fown = (below ? FAb : FBb) + (isprev ? off_p : off_c) + f_offset(rows_, ip, m, 0);
+            o0[q] = *(const double4_t *)Fown;
+            o1[q] = *(const double4_t *)(Fown + 4);
+        }
+    };
+    auto fold_chunk = [=](bool below, int s0, int nsl, const double4_t *o0, const double4_t *o1, double p[2][2]) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (!(s0 + q < nsl && L.slot_on[s0 + q])) continue;
+            const double *lr = L.lo_rows + (s0 + q) * 16 + (below ? 8 : 0);
+            for (int e = 0; e < 2; e++) {
+                p[0][e] += o0[q].x * lr[e * 4] + o0[q].y * lr[e * 4 + 1] + o0[q].z * lr[e * 4 + 2] + o0[q].w * lr[e * 4 + 3];
+                p[1][e] += o1[q].x * lr[e * 4] + o1[q].y * lr[e * 4 + 1] + o1[q].z * lr[e * 4 + 2] + o1[q].w * lr[e * 4 + 3];
+            }
+        }
+    };
 
     // stage this filter's operation records in LDS (one trip to HBM / host memory for the whole list)
     for (int q = tid; q < nops * 8; q += bd) recs[q] = op_record(in, cursor, k0 + (q >> 3), dv.B, b)[q & 7];
@@ -138,8 +191,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
             L.pose[i] = x[i];
             for (int j = 0; j < 3; j++) L.Prr[i * 3 + j] = R0[(size_t)i * xs + j];
         }
-        L.c = cos(L.pose[2]);
-        L.s = sin(L.pose[2]);
+        sincos(L.pose[2], &L.s, &L.c);
         L.n_lm = dv.n_lm[b];
         L.n_sweep = dv.n_lm_sweep[b];
     }
@@ -149,6 +201,10 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
     for (int op = 0; op < nops; op++) {
         const double *rec = recs + op * 8;
         const int type = (int)rec[7];  // uniform over the filter's workgroups
+        // inputs of the Old branch requested ahead of the gate (measurements only)
+        double spec_p[2][2] = {{0, 0}, {0, 0}};
+        double4_t spec_o0[4], spec_o1[4];
+        int spec_lm = -1;
 
         if (type == OP_PROP) {
             // ---- Propagate.cpp:15-75; rec = (v, w, dt, q00, q10, q01, q11) -------------------------
@@ -179,8 +235,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                     for (int j = 0; j < 3; j++) L.Prr[i * 3 + j] = 0.5 * (Pn[i * 3 + j] + Pn[j * 3 + i]);
                 L.a = Phi[2];
                 L.b = Phi[5];
-                L.c = cos(L.pose[2]);
-                L.s = sin(L.pose[2]);
+                sincos(L.pose[2], &L.s, &L.c);
             }
             __syncthreads();
             // P_RL <- Phi_R P_RL (:56); P_LR is the same storage
@@ -228,6 +283,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
 
         if (type == OP_MEAS) {
             // ---- association sweep, Update.cpp:98-148; rec = (z0, z1, R00, R10, R01, R11, last) ------
+            STAMP(0);  // everything since the previous measurement ended
             const double z0 = rec[0], z1 = rec[1];
             const double Rm[4] = {rec[2], rec[4], rec[3], rec[5]};  // row-major R
             const double c = L.c, s = L.s, px = L.pose[0], py = L.pose[1];
@@ -314,6 +370,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                 for (int i = 0; i < 16; i++) L.w[i] = bw[i];
             if (tid == 0) L.gd = gd, L.gi = gi;
             __syncthreads();  // (2)
+            STAMP(1);  // sweep + workgroup arg-min
             if (G > 1) {
                 // arg-min over the filter's workgroups: publish, barrier, pick (every workgroup picks the same)
                 double *mine = part + ((size_t)(epoch & 1) * dv.gmax + g) * 24;
@@ -321,23 +378,48 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                 if (tid == 16) mine[16] = L.gd;
                 if (tid == 17) mine[17] = (double)L.gi;
                 filter_barrier(bar, (epoch + 1) * G, dv.status + b);
-                if (tid == 0) {
-                    double bdv = EKF_INF;
-                    int biv = 0x7fffffff, bg = -1;
-                    for (int q = 0; q < G; q++) {
-                        const double *pr = part + ((size_t)(epoch & 1) * dv.gmax + q) * 24;
-                        double d = pr[16];
-                        int i = (int)pr[17];
-                        if (i != 0x7fffffff && cand_better(d, i, bdv, biv)) bdv = d, biv = i, bg = q;
+                STAMP(2);  // publish + cross-workgroup barrier
+                if (tid < 64) {  // wave 0: one lane per workgroup record
+                    double d = EKF_INF;
+                    int i = 0x7fffffff, src = tid;
+                    if (tid < G) {
+                        const double *pr = part + ((size_t)(epoch & 1) * dv.gmax + tid) * 24;
+                        d = pr[16];
+                        i = (int)pr[17];
                     }
-                    L.gd = bdv, L.gi = biv;
-                    if (bg >= 0) {
-                        const double *pr = part + ((size_t)(epoch & 1) * dv.gmax + bg) * 24;
-                        for (int i = 0; i < 16; i++) L.w[i] = pr[i];
+                    for (int off = 32; off > 0; off >>= 1) {
+                        double od = __shfl_down(d, off, 64);
+                        int oi = __shfl_down(i, off, 64), os = __shfl_down(src, off, 64);
+                        if (cand_better(od, oi, d, i)) d = od, i = oi, src = os;
                     }
+                    d = __shfl(d, 0, 64), i = __shfl(i, 0, 64), src = __shfl(src, 0, 64);
+                    if (i != 0x7fffffff && tid < 16) L.w[tid] = part[((size_t)(epoch & 1) * dv.gmax + src) * 24 + tid];
+                    if (tid == 0) L.gd = d, L.gi = i;
                 }
                 epoch++;
                 __syncthreads();
+                STAMP(3);  // pick over workgroups
+            }
+            // ---- speculative loads for the Old branch: the winner is known, the gate is not yet.  Issue the
+            // matched landmark's slot rows (into LDS) and this thread's first landmark's inputs now, so that
+            // their latency runs under thread 0's gate arithmetic.  Unused when the gate says New / Ignore.
+            const int w_lo = L.gi, w_jo = 2 * w_lo;
+            const bool w_have = (w_lo != 0x7fffffff);
+            const int nsl = n_prev + slot;  // slots not yet folded into Bm[buf_read]
+            const int lm0 = own_lo + tid;
+            if (w_have) {
+                for (int q = tid; q < nsl * 16; q += bd) {
+                    int sidx = q >> 4, side = (q >> 3) & 1, e = (q >> 2) & 1, k = q & 3;
+                    bool isprev = sidx < n_prev;
+                    int m = isprev ? sidx : sidx - n_prev;
+                    const double *F = (side == 0 ? FAb : FBb) + (isprev ? off_p : off_c);
+                    L.lo_rows[q] = L.slot_on[sidx] ? F[f_offset(dv.rows, w_jo + e, m, k)] : 0.0;
+                }
+                if (lm0 < own_hi && lm0 < L.n_lm && lm0 != w_lo) {
+                    spec_lm = lm0;
+                    load_old_inputs(lm0, w_lo, spec_p);
+                    load_chunk(2 * lm0, lm0 < w_lo, 0, nsl, spec_o0, spec_o1);
+                }
             }
             // ---- gate + robot block, Update.cpp:152-191 ----------------------------------------------
             if (tid == 0) {
@@ -432,8 +514,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                             L.Prr[r * 3 + q] = nv;
                             L.Prr[q * 3 + r] = nv;
                         }
-                    L.c = cos(L.pose[2]);
-                    L.s = sin(L.pose[2]);
+                    sincos(L.pose[2], &L.s, &L.c);
                     for (int q = 0; q < 6; q++) L.HRt[q] = HRt[q], L.KR[q] = KR[q], L.TR[q] = TR[q];
                     for (int q = 0; q < 4; q++) L.Sinv[q] = Si[q];
                     L.S[0] = S00, L.S[1] = S01, L.S[2] = S01, L.S[3] = S11;
@@ -459,6 +540,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                 if (rec[6] == 2.0) L.n_sweep = L.n_lm;  // last measurement of the chunk
             }
             __syncthreads();  // (3)
+            STAMP(4);  // gate + robot block
         } else if (type == OP_COMPASS) {
             // ---- kalmanfilter.cpp:96-130; rec = (z, R) -----------------------------------------------
             __syncthreads();
@@ -487,8 +569,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                         L.Prr[r * 3 + q] = nv;
                         L.Prr[q * 3 + r] = nv;
                     }
-                L.c = cos(L.pose[2]);
-                L.s = sin(L.pose[2]);
+                sincos(L.pose[2], &L.s, &L.c);
                 for (int r = 0; r < 3; r++) {
                     L.KR[r * 2] = KR[r], L.KR[r * 2 + 1] = 0;
                     L.TR[r * 2] = TR[r], L.TR[r * 2 + 1] = 0;
@@ -554,18 +635,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
             // the rotation the header was built with: H_Li^T = C of the pose BEFORE this update.
             // L.c/L.s already hold the updated heading, so take C from H_R^T = [-C | ...]^T.
             const double c = -L.HRt[0], s = L.HRt[1];
-            const int nsl = n_prev + slot;  // slots not yet folded into Bm[buf_read]
-            if (decision == HDR_OLD) {
-                // stage the matched landmark's rows of every such slot in LDS
-                for (int q = tid; q < nsl * 16; q += bd) {
-                    int sidx = q >> 4, side = (q >> 3) & 1, e = (q >> 2) & 1, k = q & 3;
-                    bool isprev = sidx < n_prev;
-                    int m = isprev ? sidx : sidx - n_prev;
-                    const double *F = side == 0 ? (isprev ? FAp : (const double *)FAc) : (isprev ? FBp : (const double *)FBc);
-                    L.lo_rows[q] = L.slot_on[sidx] ? F[f_offset(dv.rows, jo + e, m, k)] : 0.0;
-                }
-                __syncthreads();  // (4)
-            }
+            const int nslots = (type == OP_MEAS) ? n_prev + slot : 0;
             const int hi = own_hi < n_lm ? own_hi : n_lm;
             for (int lm = own_lo + tid; lm < hi; lm += bd) {
                 int ip = 2 * lm, i0 = 3 + ip;
@@ -577,31 +647,21 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                         p[1][0] = Dx[dv.dn + lm], p[1][1] = Dx[2 * (size_t)dv.dn + lm];
                     } else {
                         const bool below = lm < lo;  // stored as (row of the older landmark, column of the newer)
-                        for (int a = 0; a < 2; a++)
-                            for (int e = 0; e < 2; e++)
-                                p[a][e] = below ? Bmr[bm_offset(dv.T, ip + a, jo + e)] : Bmr[bm_offset(dv.T, jo + e, ip + a)];
-                        // fold the pending slots four at a time: eight independent 32-byte loads in flight.
-                        // Dead slots carry zero weights in L.lo_rows and re-read slot 0 (always valid memory).
-                        for (int s0 = 0; s0 < nsl; s0 += 4) {
-                            double4_t o0[4], o1[4];
-#pragma unroll
-                            for (int q = 0; q < 4; q++) {
-                                int sidx = (s0 + q < nsl && L.slot_on[s0 + q]) ? s0 + q : -1;
-                                bool isprev = sidx >= 0 && sidx < n_prev;
-                                int m = sidx < 0 ? 0 : (isprev ? sidx : sidx - n_prev);
-                                const double *Fown = (below ? (isprev ? FAp : (const double *)FAc) : (isprev ? FBp : (const double *)FBc)) + f_offset(dv.rows, ip, m, 0);
-                                o0[q] = *(const double4_t *)Fown;
-                                o1[q] = *(const double4_t *)(Fown + 4);
+                        double4_t o0[4], o1[4];
+                        if (lm == spec_lm) {  // inputs were requested before the gate
+                            for (int a = 0; a < 2; a++)
+                                for (int e = 0; e < 2; e++) p[a][e] = spec_p[a][e];
+                            if (nslots > 0) fold_chunk(below, 0, nslots, spec_o0, spec_o1, p);
+                        } else {
+                            load_old_inputs(lm, lo, p);
+                            if (nslots > 0) {
+                                load_chunk(ip, below, 0, nslots, o0, o1);
+                                fold_chunk(below, 0, nslots, o0, o1, p);
                             }
-#pragma unroll
-                            for (int q = 0; q < 4; q++) {
-                                if (!(s0 + q < nsl && L.slot_on[s0 + q])) continue;
-                                const double *lr = L.lo_rows + (s0 + q) * 16 + (below ? 8 : 0);
-                                for (int e = 0; e < 2; e++) {
-                                    p[0][e] += o0[q].x * lr[e * 4] + o0[q].y * lr[e * 4 + 1] + o0[q].z * lr[e * 4 + 2] + o0[q].w * lr[e * 4 + 3];
-                                    p[1][e] += o1[q].x * lr[e * 4] + o1[q].y * lr[e * 4 + 1] + o1[q].z * lr[e * 4 + 2] + o1[q].w * lr[e * 4 + 3];
-                                }
-                            }
+                        }
+                        for (int s0 = 4; s0 < nslots; s0 += 4) {
+                            load_chunk(ip, below, s0, nslots, o0, o1);
+                            fold_chunk(below, s0, nslots, o0, o1, p);
                         }
                     }
                     for (int a = 0; a < 2; a++) {
@@ -644,6 +704,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                 *(double4_t *)(fb + 4) = (double4_t){K[1][0], K[1][1], Tt[1][0], Tt[1][1]};
             }
         }
+        STAMP(6);  // landmark part
         slot++;
     }
 
@@ -670,14 +731,14 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
 }
 
 // ---------------------------------------------------------------------------------------------
-// The dense pass: Bm[buf_in ^ 1] = Bm[buf_in] + sum over the active slots of `set` of A B^T, over
-// the upper-triangle tiles.  One wave per 64x64 tile (32 KiB read + 32 KiB written, each as 32
+// The dense pass: Bm[buf] += sum over the active slots of `set` of A B^T, in place, over the
+// upper-triangle tiles.  One wave per 64x64 tile (32 KiB read + 32 KiB written, each as 32
 // wave-contiguous 1 KiB accesses); the rank-(4 * slots) contraction runs on
 // v_mfma_f64_16x16x4_f64 with the tile as the C/D operand.
 // Only the first nslots slots of the set were filled.
 // grid (ceil(nT_hi (nT_hi+1)/2 / 4), B), 256 threads.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void k_flush(EkfDev dv, int nT_hi, int set, int nslots, int buf_in) {
+__global__ __launch_bounds__(256, 2) void k_flush(EkfDev dv, int nT_hi, int set, int nslots, int buf) {
     int b = blockIdx.y;
     int lane = threadIdx.x & 63;
     int u = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -695,39 +756,156 @@ __global__ __launch_bounds__(256, 2) void k_flush(EkfDev dv, int nT_hi, int set,
 
     const int *active = dv.slot_active + ((size_t)b * 2 + set) * dv.maxp;
     size_t t = (size_t)I * dv.T - ((size_t)I * (I - 1)) / 2 + (size_t)(J - I);
-    size_t toff = (size_t)b * dv.bm_stride + t * 4096 + (size_t)lane * 2;
-    const double *src = dv.Bm[buf_in] + toff;
-    double *dst = dv.Bm[buf_in ^ 1] + toff;
-    const double *FA = dv.FA + ((size_t)b * 2 + set) * dv.f_stride;
-    const double *FB = dv.FB + ((size_t)b * 2 + set) * dv.f_stride;
+    double *tp = dv.Bm[buf] + (size_t)b * dv.bm_stride + t * 4096 + (size_t)lane * 2;
+    // operand fragments: lane l supplies row (l & 15), k = l >> 4 of a 16-row x 4 block = 512 contiguous bytes
+    const double *FA = dv.FA + ((size_t)b * 2 + set) * dv.f_stride + ((size_t)64 * I + (lane & 15)) * 4 + (lane >> 4);
+    const double *FB = dv.FB + ((size_t)b * 2 + set) * dv.f_stride + ((size_t)64 * J + (lane & 15)) * 4 + (lane >> 4);
+    const size_t slot_stride = (size_t)dv.rows * 4;
 
     double4_t acc[16];
 #pragma unroll
     for (int ch = 0; ch < 16; ch++) {
-        double2_t lo = *(const double2_t *)(src + ch * 256);
-        double2_t hi = *(const double2_t *)(src + ch * 256 + 128);
+        double2_t lo = *(const double2_t *)(tp + ch * 256);
+        double2_t hi = *(const double2_t *)(tp + ch * 256 + 128);
         acc[ch] = (double4_t){lo.x, lo.y, hi.x, hi.y};
     }
-    for (int m = 0; m < nslots; m++) {
-        if (!active[m]) continue;
-        double av[4], bv[4];
+    // live slots as a bit mask, walked two per iteration with two named operand sets: the operands of
+    // the next slot are requested before the 16 MFMAs of the current one issue, and the wait in front of
+    // an MFMA block covers only its own, older loads.  Past the last live slot the walk reads slot
+    // `maxp`, which is all zeros by construction (adds exact zeros).
+    unsigned live = 0;
+    for (int m = 0; m < nslots; m++) live |= (active[m] ? 1u : 0u) << m;
+    const int zero_slot = dv.maxp;
+    double a0[4], b0[4], a1[4], b1[4];
+    int npairs = (__builtin_popcount(live) + 1) >> 1;
+    int m0 = live ? __builtin_ctz(live) : zero_slot;
+    live &= live - 1;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        a0[q] = FA[(size_t)m0 * slot_stride + q * 64];
+        b0[q] = FB[(size_t)m0 * slot_stride + q * 64];
+    }
+    for (int it = 0; it < npairs; it++) {
+        int m1 = live ? __builtin_ctz(live) : zero_slot;
+        live &= live - 1;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            // lane l supplies row (l & 15), k = l >> 4 of a 16-row x 4 block: 512 contiguous bytes
-            av[q] = FA[((size_t)m * dv.rows + 64 * I + 16 * q + (lane & 15)) * 4 + (lane >> 4)];
-            bv[q] = FB[((size_t)m * dv.rows + 64 * J + 16 * q + (lane & 15)) * 4 + (lane >> 4)];
+            a1[q] = FA[(size_t)m1 * slot_stride + q * 64];
+            b1[q] = FB[(size_t)m1 * slot_stride + q * 64];
         }
+        __builtin_amdgcn_sched_barrier(0);  // keep the requests ahead of the MFMA block they overlap
 #pragma unroll
         for (int rc = 0; rc < 4; rc++)
 #pragma unroll
             for (int cc = 0; cc < 4; cc++)
-                acc[rc * 4 + cc] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[rc], bv[cc], acc[rc * 4 + cc], 0, 0, 0);
+                acc[rc * 4 + cc] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[rc], b0[cc], acc[rc * 4 + cc], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        m0 = live ? __builtin_ctz(live) : zero_slot;
+        live &= live - 1;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            a0[q] = FA[(size_t)m0 * slot_stride + q * 64];
+            b0[q] = FB[(size_t)m0 * slot_stride + q * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int rc = 0; rc < 4; rc++)
+#pragma unroll
+            for (int cc = 0; cc < 4; cc++)
+                acc[rc * 4 + cc] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[rc], b1[cc], acc[rc * 4 + cc], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int ch = 0; ch < 16; ch++) {
-        *(double2_t *)(dst + ch * 256) = (double2_t){acc[ch].x, acc[ch].y};
-        *(double2_t *)(dst + ch * 256 + 128) = (double2_t){acc[ch].z, acc[ch].w};
+        *(double2_t *)(tp + ch * 256) = (double2_t){acc[ch].x, acc[ch].y};
+        *(double2_t *)(tp + ch * 256 + 128) = (double2_t){acc[ch].z, acc[ch].w};
     }
+}
+
+// Variant of the dense pass: one wave per 32x32 QUADRANT of a tile (4 chains, 8 KiB read + 8 KiB
+// written, 4 MFMAs per slot).  A quarter of the registers per wave, so up to 8 waves per SIMD cover
+// each other's HBM latency and MFMA time; costs twice the operand traffic from L2 per element.
+// grid (total tiles, B), 256 threads: the four waves of a workgroup take the four quadrants of one tile.
+__global__ __launch_bounds__(256, 6) void k_flush_q(EkfDev dv, int nT_hi, int set, int nslots, int buf) {
+    int b = blockIdx.y;
+    int lane = threadIdx.x & 63;
+    int quad = threadIdx.x >> 6;  // (qr, qc) = row half, column half of the tile
+    int qr = quad >> 1, qc = quad & 1;
+    int u = blockIdx.x;
+    int I = (int)(((2.0f * nT_hi + 1.0f) - sqrtf((2.0f * nT_hi + 1.0f) * (2.0f * nT_hi + 1.0f) - 8.0f * (float)u)) * 0.5f);
+    if (I < 0) I = 0;
+    if (I > nT_hi - 1) I = nT_hi - 1;
+    while (I > 0 && I * nT_hi - (I * (I - 1)) / 2 > u) I--;
+    while ((I + 1) * nT_hi - ((I + 1) * I) / 2 <= u) I++;
+    int J = I + (u - (I * nT_hi - (I * (I - 1)) / 2));
+    int nT = (2 * dv.n_lm_flush[(size_t)b * 2 + set] + 63) >> 6;
+    if (J >= nT) return;
+
+    const int *active = dv.slot_active + ((size_t)b * 2 + set) * dv.maxp;
+    size_t t = (size_t)I * dv.T - ((size_t)I * (I - 1)) / 2 + (size_t)(J - I);
+    // chains (2qr + i, 2qc + j), i, j in {0, 1}: chain id = (2qr + i) * 4 + 2qc + j
+    double *tp = dv.Bm[buf] + (size_t)b * dv.bm_stride + t * 4096 + (size_t)((2 * qr) * 4 + 2 * qc) * 256 + (size_t)lane * 2;
+    const double *FA = dv.FA + ((size_t)b * 2 + set) * dv.f_stride + ((size_t)64 * I + 32 * qr + (lane & 15)) * 4 + (lane >> 4);
+    const double *FB = dv.FB + ((size_t)b * 2 + set) * dv.f_stride + ((size_t)64 * J + 32 * qc + (lane & 15)) * 4 + (lane >> 4);
+    const size_t slot_stride = (size_t)dv.rows * 4;
+
+    double4_t acc[4];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const double *p = tp + (i * 4 + j) * 256;
+            double2_t lo = *(const double2_t *)p, hi = *(const double2_t *)(p + 128);
+            acc[i * 2 + j] = (double4_t){lo.x, lo.y, hi.x, hi.y};
+        }
+    unsigned live = 0;
+    for (int m = 0; m < nslots; m++) live |= (active[m] ? 1u : 0u) << m;
+    const int zero_slot = dv.maxp;
+    double a0[2], b0[2], a1[2], b1[2];
+    int npairs = (__builtin_popcount(live) + 1) >> 1;
+    int m0 = live ? __builtin_ctz(live) : zero_slot;
+    live &= live - 1;
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        a0[q] = FA[(size_t)m0 * slot_stride + q * 64];
+        b0[q] = FB[(size_t)m0 * slot_stride + q * 64];
+    }
+    for (int it = 0; it < npairs; it++) {
+        int m1 = live ? __builtin_ctz(live) : zero_slot;
+        live &= live - 1;
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            a1[q] = FA[(size_t)m1 * slot_stride + q * 64];
+            b1[q] = FB[(size_t)m1 * slot_stride + q * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) acc[i * 2 + j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[i], b0[j], acc[i * 2 + j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        m0 = live ? __builtin_ctz(live) : zero_slot;
+        live &= live - 1;
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            a0[q] = FA[(size_t)m0 * slot_stride + q * 64];
+            b0[q] = FB[(size_t)m0 * slot_stride + q * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) acc[i * 2 + j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[i], b1[j], acc[i * 2 + j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            double *p = tp + (i * 4 + j) * 256;
+            *(double2_t *)p = (double2_t){acc[i * 2 + j].x, acc[i * 2 + j].y};
+            *(double2_t *)(p + 128) = (double2_t){acc[i * 2 + j].z, acc[i * 2 + j].w};
+        }
 }
 
 // ---------------------------------------------------------------------------------------------

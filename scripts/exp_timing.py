@@ -17,21 +17,23 @@ def run(N, B=1, steps=40, warm=8, M=4, maxp=4, graph=False, label=""):
     f.script_run(0, warm, use_graph=graph)
     try: f.sync()
     except Exception: pass
+    f.flush_profile(not graph)
+    f.flush_profile_read()
     f.timer_start()
     f.script_run(warm, steps, use_graph=graph)
     ms = f.timer_stop()
-    print("%-28s N=%5d B=%4d maxp=%d graph=%d : %8.2f us/step  (%.0f filter-steps/s)" % (label, N, B, maxp, graph, ms / steps * 1e3, B * steps / ms * 1e3), flush=True)
+    nl, fms = f.flush_profile_read()
+    print("%-28s N=%5d B=%4d maxp=%2d graph=%d : %8.2f us/step  (%.0f filter-steps/s)  flush: %d x %.1f us" % (label, N, B, maxp, graph, ms / steps * 1e3, B * steps / ms * 1e3, nl, fms / max(nl, 1) * 1e3), flush=True)
     f.close()
 
 if __name__ == "__main__":
     lab = ("skipflush " if os.environ.get("EKF_DEBUG_SKIP_FLUSH") else "") + "G=" + os.environ.get("EKF_CHAIN_WGS", "auto")
-    for N in (256, 1024, 4096):
-        run(N, label=lab)
-    for maxp in (8, 16, 32):
-        run(4096, maxp=maxp, steps=64, label=lab)
-    run(4096, graph=True, label=lab + " graph")
-    run(4096, maxp=16, steps=64, graph=True, label=lab + " graph")
-    run(1024, graph=True, label=lab + " graph")
-    run(1024, maxp=16, steps=64, graph=True, label=lab + " graph")
-    run(256, B=256, graph=True, label=lab + " graph")
-    run(256, B=256, maxp=16, steps=64, graph=True, label=lab + " graph")
+    which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if which in ("all", "n4096"):
+        for maxp in (1, 2, 4, 8, 16, 32):
+            run(4096, maxp=maxp, steps=64, label=lab)
+    if which in ("all", "small"):
+        for maxp in (4, 16):
+            run(1024, maxp=maxp, steps=64, label=lab)
+            run(256, maxp=maxp, steps=64, label=lab)
+            run(256, B=256, maxp=maxp, steps=64, label=lab)
