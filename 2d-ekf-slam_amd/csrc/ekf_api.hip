@@ -144,7 +144,8 @@ extern "C" int ekf_batch_create(ekf_handle *out, int batch, int capacity_landmar
     // k_chain geometry: about one landmark per thread, at most 32 workgroups per filter, and few
     // enough workgroups in total (<= 256) that all of them are resident at once: the cross-workgroup
     // barrier needs every workgroup of a filter running
-    int G = (capacity_landmarks + EKF_CHAIN_MAX_THREADS - 1) / EKF_CHAIN_MAX_THREADS;
+    const int max_workers = EKF_CHAIN_MAX_THREADS - 64;
+    int G = (capacity_landmarks + max_workers - 1) / max_workers;
     if (G > EKF_CHAIN_MAX_WGS) G = EKF_CHAIN_MAX_WGS;
     if (G * batch > 256) G = 256 / batch;
     if (G < 1) G = 1;
@@ -153,8 +154,9 @@ extern "C" int ekf_batch_create(ekf_handle *out, int batch, int capacity_landmar
     h->chain_wgs = G;
     dv.gmax = G;
     dv.lpw = (capacity_landmarks + G - 1) / G;
-    h->chain_threads = (dv.lpw + 63) / 64 * 64;
-    if (h->chain_threads > EKF_CHAIN_MAX_THREADS) h->chain_threads = EKF_CHAIN_MAX_THREADS;
+    int workers = (dv.lpw + 63) / 64 * 64;
+    if (workers > max_workers) workers = max_workers;
+    h->chain_threads = 64 + workers;  // wave 0 is the control wave
     size_t B = batch;
     hipStream_t s = h->s_chain;
     HIP_TRY(dev_alloc_zero(&dv.x, B * dv.xs, &h->device_bytes, s));

@@ -26,7 +26,7 @@
 
 #define EKF_INF 999999999999.0 /* kalmanfilter.h:17 */
 #define EKF_MAX_PENDING 32
-#define EKF_CHAIN_MAX_THREADS 256
+#define EKF_CHAIN_MAX_THREADS 256 /* one control wave + up to 192 workers: one wave per SIMD, 512-VGPR budget */
 #define EKF_CHAIN_MAX_WGS 32 /* workgroups sharing one filter in k_chain */
 #define EKF_CHAIN_MAX_OPS 64 /* operations per k_chain launch */
 

@@ -109,7 +109,9 @@ __device__ __forceinline__ void filter_barrier(int *bar, int target, int *status
 // ---------------------------------------------------------------------------------------------
 // The chain kernel.  grid (G, B): G workgroups share one filter, workgroup g owns landmarks
 // [g*lpw, (g+1)*lpw) -- their x entries, their columns of the robot rows R, their 2x2 block D,
-// their slot rows -- and thread t of it owns landmarks g*lpw + t, + blockDim, ...
+// their slot rows.  Inside a workgroup wave 0 is the CONTROL wave (lane 0 runs the serial robot-block
+// arithmetic: propagate, gate, gain rows of the robot) and the other waves are WORKERS: worker w owns
+// landmarks own_lo + w, + nworkers, ...; the first of them lives in registers for the whole launch.
 // Sequential dependencies of the reference become: workgroup barriers around the arg-min and the
 // robot block, plus ONE cross-workgroup barrier per measurement (the arg-min over all landmarks).
 // Every workgroup keeps an identical copy of the robot state and recomputes the gate identically;
@@ -120,6 +122,68 @@ __device__ __forceinline__ void filter_barrier(int *bar, int target, int *status
 //   n_prev            : > 0 when the other set has been handed to a dense pass that reads
 //                       Bm[buf_read]: its first n_prev slots are not in that buffer yet
 // ---------------------------------------------------------------------------------------------
+struct LmState {  // everything the chain keeps per landmark
+    double x0, x1;   // position estimate
+    double rc[6];    // P[0:3, Li:Li+2], 3x2 row-major
+    double dxx, dxy, dyy;
+};
+
+struct SweepBest {
+    double d;
+    int lm;
+    double w[16];  // res(2) S00,S01,S11 hcol(2) P_R,Li(6) D(3)
+};
+
+// one landmark of the association sweep, Update.cpp:103-148
+__device__ __forceinline__ void sweep_one(int lm, const LmState &st, double z0, double z1, const double *Rm, double c, double s,
+                                          double px, double py, const double *Prr, double cond_limit, SweepBest &best) {
+    double dp0 = st.x0 - px, dp1 = st.x1 - py;
+    // z_hat = C^T dp (:109), res = z - z_hat (:111)
+    double res0 = z0 - (c * dp0 + s * dp1);
+    double res1 = z1 - (-s * dp0 + c * dp1);
+    // H_R = [-C^T | -C^T J dp] (:112-114)
+    double h0 = -s * dp0 + c * dp1;
+    double h1 = -c * dp0 - s * dp1;
+    double HR[6] = {-c, -s, h0, s, -c, h1};
+    double HL[4] = {c, s, -s, c};  // H_Li = C^T
+    const double *A = st.rc;       // P_RLi 3x2
+    double Pll[4] = {st.dxx, st.dxy, st.dxy, st.dyy};
+    // S = H_R P_RR H_R^T + H_Li P_LiR H_R^T + H_R P_RLi H_Li^T + H_Li P_LiLi H_Li^T + R (:122)
+    double S[4];
+    for (int i = 0; i < 2; i++)
+        for (int j = 0; j < 2; j++) {
+            double t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+            for (int q = 0; q < 3; q++) {
+                double hp = HR[i * 3] * Prr[q] + HR[i * 3 + 1] * Prr[3 + q] + HR[i * 3 + 2] * Prr[6 + q];
+                t1 += hp * HR[j * 3 + q];
+                double lp = HL[i * 2] * A[q * 2] + HL[i * 2 + 1] * A[q * 2 + 1];  // (H_Li P_LiR)[i][q], P_LiR = A^T
+                t2 += lp * HR[j * 3 + q];
+            }
+            for (int q = 0; q < 2; q++) {
+                double ha = HR[i * 3] * A[q] + HR[i * 3 + 1] * A[2 + q] + HR[i * 3 + 2] * A[4 + q];
+                t3 += ha * HL[j * 2 + q];
+                double lp = HL[i * 2] * Pll[q] + HL[i * 2 + 1] * Pll[2 + q];
+                t4 += lp * HL[j * 2 + q];
+            }
+            S[i * 2 + j] = (((t1 + t2) + t3) + t4) + Rm[i * 2 + j];
+        }
+    double S00 = S[0], S01 = 0.5 * (S[1] + S[2]), S11 = S[3];  // :123-124
+    // condition number = sigma_max / sigma_min of the symmetric 2x2 (:127-128)
+    double e = 0.5 * (S00 + S11), f = 0.5 * (S00 - S11);
+    double q = fabs(e), r = sqrt(f * f + S01 * S01);
+    double cond = (q + r) / fabs(q - r);
+    if (!(cond >= cond_limit)) {  // :131, NaN is not skipped
+        double det = S00 * S11 - S01 * S01;
+        double d = (res0 * (S11 * res0 - S01 * res1) + res1 * (S00 * res1 - S01 * res0)) / det;  // :135-136
+        if (best.d > d) {  // :140 (false for NaN); ascending lm, so ties keep the lower index
+            best.d = d, best.lm = lm;
+            best.w[0] = res0, best.w[1] = res1, best.w[2] = S00, best.w[3] = S01, best.w[4] = S11, best.w[5] = h0, best.w[6] = h1;
+            for (int i = 0; i < 6; i++) best.w[7 + i] = A[i];
+            best.w[13] = st.dxx, best.w[14] = st.dxy, best.w[15] = st.dyy;
+        }
+    }
+}
+
 __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, const double *in, const int *cursor, int k0,
                                                                 int nops, int slot0, int set, int buf_read, int n_prev) {
     __shared__ ChainLds L;
@@ -129,8 +193,11 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
     const int tid = threadIdx.x;
     const int bd = blockDim.x;
     const bool lead = (g == 0);
+    const bool worker = tid >= 64;  // wave 0 is the control wave
+    const int wtid = tid - 64, nw = bd - 64;
     const int xs = dv.xs;
     const int own_lo = g * dv.lpw, own_hi = own_lo + dv.lpw;  // landmarks this workgroup owns
+    const int lm0 = own_lo + wtid;                            // this worker's register-resident landmark
     double *x = dv.x + (size_t)b * xs;
     double *R0 = dv.R + (size_t)b * 3 * xs;
     double *Dx = dv.D + (size_t)b * 3 * dv.dn;
@@ -145,12 +212,26 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
 #ifdef EKF_CHAIN_STAMPS
     unsigned long long stamp_t = __builtin_amdgcn_s_memrealtime();
 #endif
-
-    // P[rows of lm, columns of lo] as stored in Bm[buf_read] (row index = the older landmark)
     // slot arrays addressed as base + set offset: a 4-way pointer select would become a scratch table
     const double *FAb = dv.FA + (size_t)b * 2 * dv.f_stride, *FBb = dv.FB + (size_t)b * 2 * dv.f_stride;
     const size_t off_c = (size_t)set * dv.f_stride, off_p = (size_t)(set ^ 1) * dv.f_stride;
-    const int T_ = dv.T, rows_ = dv.rows;  // by-value captures: a reference to dv would push the kernel arguments to scratch
+    const int T_ = dv.T, rows_ = dv.rows, dn_ = dv.dn;  // by-value captures: a reference to dv would push the kernel arguments to scratch
+
+    auto lm_load = [=](int lm) {
+        LmState st;
+        int Li = 3 + 2 * lm;
+        st.x0 = x[Li], st.x1 = x[Li + 1];
+        for (int i = 0; i < 3; i++) st.rc[i * 2] = R0[(size_t)i * xs + Li], st.rc[i * 2 + 1] = R0[(size_t)i * xs + Li + 1];
+        st.dxx = Dx[lm], st.dxy = Dx[dn_ + lm], st.dyy = Dx[2 * (size_t)dn_ + lm];
+        return st;
+    };
+    auto lm_store = [=](int lm, const LmState &st) {
+        int Li = 3 + 2 * lm;
+        x[Li] = st.x0, x[Li + 1] = st.x1;
+        for (int i = 0; i < 3; i++) R0[(size_t)i * xs + Li] = st.rc[i * 2], R0[(size_t)i * xs + Li + 1] = st.rc[i * 2 + 1];
+        Dx[lm] = st.dxx, Dx[dn_ + lm] = st.dxy, Dx[2 * (size_t)dn_ + lm] = st.dyy;
+    };
+    // P[rows of lm, columns of lo] as stored in Bm[buf_read] (row index = the older landmark)
     auto load_old_inputs = [=](int lm, int lo, double p[2][2]) {
         const bool below = lm < lo;
         const int ip = 2 * lm, jo = 2 * lo;
@@ -182,6 +263,86 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
             }
         }
     };
+    // Old / compass branch for one landmark: K rows, x += K res, robot rows and own block of P, the slot.
+    // p = P[rows of lm, columns of the matched landmark] (Old only).  Updates st and writes it back.
+    auto apply_gain = [=](int lm, LmState &st, bool is_old, const double p[2][2], int slot) {
+        const double c = -L.HRt[0], s = L.HRt[1];  // C of the pose the header was built with: H_R^T = [-C | ...]^T
+        const double res0 = L.res[0], res1 = L.res[1];
+        double K[2][2], Tt[2][2];
+        if (is_old) {
+            for (int a = 0; a < 2; a++) {
+                double u0 = 0, u1 = 0;
+                for (int q = 0; q < 3; q++) {  // P[i,0:3] H_R^T, Update.cpp:186
+                    double pr = st.rc[q * 2 + a];
+                    u0 += pr * L.HRt[q * 2];
+                    u1 += pr * L.HRt[q * 2 + 1];
+                }
+                double w0 = p[a][0] * c + p[a][1] * s, w1 = p[a][0] * (-s) + p[a][1] * c;  // P[i,Lo:Lo+2] H_Li^T
+                double s0 = u0 + w0, s1 = u1 + w1;
+                K[a][0] = s0 * L.Sinv[0] + s1 * L.Sinv[2];
+                K[a][1] = s0 * L.Sinv[1] + s1 * L.Sinv[3];
+                Tt[a][0] = K[a][0] * L.S[0] + K[a][1] * L.S[2];
+                Tt[a][1] = K[a][0] * L.S[1] + K[a][1] * L.S[3];
+            }
+        } else {  // K = (1/S) P[:,2], kalmanfilter.cpp:118
+            for (int a = 0; a < 2; a++) {
+                K[a][0] = L.invS * st.rc[4 + a];
+                K[a][1] = 0;
+                Tt[a][0] = L.S[0] * K[a][0];
+                Tt[a][1] = 0;
+            }
+        }
+        // x += K res (Update.cpp:187 / kalmanfilter.cpp:121)
+        st.x0 = st.x0 + (K[0][0] * res0 + K[0][1] * res1);
+        st.x1 = st.x1 + (K[1][0] * res0 + K[1][1] * res1);
+        // robot rows of P -= sym(K S K^T)
+        for (int r = 0; r < 3; r++)
+            for (int a = 0; a < 2; a++)
+                st.rc[r * 2 + a] -= sym_u(L.TR[r * 2], L.TR[r * 2 + 1], L.KR[r * 2], L.KR[r * 2 + 1], Tt[a][0], Tt[a][1], K[a][0], K[a][1]);
+        // own 2x2 block
+        st.dxx -= sym_u(Tt[0][0], Tt[0][1], K[0][0], K[0][1], Tt[0][0], Tt[0][1], K[0][0], K[0][1]);
+        st.dxy -= sym_u(Tt[0][0], Tt[0][1], K[0][0], K[0][1], Tt[1][0], Tt[1][1], K[1][0], K[1][1]);
+        st.dyy -= sym_u(Tt[1][0], Tt[1][1], K[1][0], K[1][1], Tt[1][0], Tt[1][1], K[1][0], K[1][1]);
+        lm_store(lm, st);
+        // slot: P_LL += A B^T with A = -0.5 [T | K], B = [K | T]; one 64-byte line per landmark and side
+        double *fa = FAc + f_offset(rows_, 2 * lm, slot, 0), *fb = FBc + f_offset(rows_, 2 * lm, slot, 0);
+        *(double4_t *)fa = (double4_t){-0.5 * Tt[0][0], -0.5 * Tt[0][1], -0.5 * K[0][0], -0.5 * K[0][1]};
+        *(double4_t *)(fa + 4) = (double4_t){-0.5 * Tt[1][0], -0.5 * Tt[1][1], -0.5 * K[1][0], -0.5 * K[1][1]};
+        *(double4_t *)fb = (double4_t){K[0][0], K[0][1], Tt[0][0], Tt[0][1]};
+        *(double4_t *)(fb + 4) = (double4_t){K[1][0], K[1][1], Tt[1][0], Tt[1][1]};
+    };
+    // New branch, an existing landmark lm < ln: its slot rows carry the new covariance column pair
+    auto apply_new_column = [=](int lm, const LmState &st, int slot) {
+        const double c = L.c, s = L.s;  // pose is unchanged by New
+        double v[2][2];
+        for (int a = 0; a < 2; a++) {
+            double u0 = 0, u1 = 0;
+            for (int q = 0; q < 3; q++) {  // ((-P[i,0:3]) H_R^T) H_Li, Update.cpp:169
+                double pr = -st.rc[q * 2 + a];
+                u0 += pr * L.HRt[q * 2];
+                u1 += pr * L.HRt[q * 2 + 1];
+            }
+            v[a][0] = u0 * c + u1 * (-s);
+            v[a][1] = u0 * s + u1 * c;
+        }
+        double *fa = FAc + f_offset(rows_, 2 * lm, slot, 0), *fb = FBc + f_offset(rows_, 2 * lm, slot, 0);
+        *(double4_t *)fa = (double4_t){v[0][0], v[0][1], 0, 0};
+        *(double4_t *)(fa + 4) = (double4_t){v[1][0], v[1][1], 0, 0};
+        *(double4_t *)fb = (double4_t){0, 0, 0, 0};
+        *(double4_t *)(fb + 4) = (double4_t){0, 0, 0, 0};
+    };
+    // New branch, the appended landmark itself: state from the header, unit B rows
+    auto apply_new_self = [=](int lm, LmState &st, int slot) {
+        st.x0 = L.newx[0], st.x1 = L.newx[1];
+        for (int i = 0; i < 6; i++) st.rc[i] = L.newrc[i];
+        st.dxx = L.newdd[0], st.dxy = L.newdd[1], st.dyy = L.newdd[2];
+        lm_store(lm, st);
+        double *fa = FAc + f_offset(rows_, 2 * lm, slot, 0), *fb = FBc + f_offset(rows_, 2 * lm, slot, 0);
+        *(double4_t *)fa = (double4_t){0, 0, 0, 0};
+        *(double4_t *)(fa + 4) = (double4_t){0, 0, 0, 0};
+        *(double4_t *)fb = (double4_t){1, 0, 0, 0};
+        *(double4_t *)(fb + 4) = (double4_t){0, 1, 0, 0};
+    };
 
     // stage this filter's operation records in LDS (one trip to HBM / host memory for the whole list)
     for (int q = tid; q < nops * 8; q += bd) recs[q] = op_record(in, cursor, k0 + (q >> 3), dv.B, b)[q & 7];
@@ -195,6 +356,8 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
         L.n_lm = dv.n_lm[b];
         L.n_sweep = dv.n_lm_sweep[b];
     }
+    LmState r0 = {0, 0, {0, 0, 0, 0, 0, 0}, 0, 0, 0};
+    if (worker && lm0 < own_hi && lm0 < dv.n_lm[b]) r0 = lm_load(lm0);
     __syncthreads();
 
     int slot = slot0;
@@ -204,7 +367,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
         // inputs of the Old branch requested ahead of the gate (measurements only)
         double spec_p[2][2] = {{0, 0}, {0, 0}};
         double4_t spec_o0[4], spec_o1[4];
-        int spec_lm = -1;
+        bool spec_ok = false;
 
         if (type == OP_PROP) {
             // ---- Propagate.cpp:15-75; rec = (v, w, dt, q00, q10, q01, q11) -------------------------
@@ -239,13 +402,24 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
             }
             __syncthreads();
             // P_RL <- Phi_R P_RL (:56); P_LR is the same storage
-            const double a = L.a, bb = L.b;
-            const int hi = own_hi < L.n_lm ? own_hi : L.n_lm;
-            for (int j = 2 * own_lo + tid; j < 2 * hi; j += bd) {
-                double *Rj = R0 + 3 + j;
-                double p2 = Rj[2 * (size_t)xs];
-                Rj[0] = Rj[0] + a * p2;
-                Rj[xs] = Rj[xs] + bb * p2;
+            if (worker) {
+                const double a = L.a, bb = L.b;
+                const int hi = own_hi < L.n_lm ? own_hi : L.n_lm;
+                if (lm0 < hi) {
+                    for (int e = 0; e < 2; e++) {
+                        r0.rc[e] = r0.rc[e] + a * r0.rc[4 + e];
+                        r0.rc[2 + e] = r0.rc[2 + e] + bb * r0.rc[4 + e];
+                        R0[3 + 2 * lm0 + e] = r0.rc[e];
+                        R0[(size_t)xs + 3 + 2 * lm0 + e] = r0.rc[2 + e];
+                    }
+                }
+                for (int lm = lm0 + nw; lm < hi; lm += nw)
+                    for (int e = 0; e < 2; e++) {
+                        double *Rj = R0 + 3 + 2 * lm + e;
+                        double p2 = Rj[2 * (size_t)xs];
+                        Rj[0] = Rj[0] + a * p2;
+                        Rj[xs] = Rj[xs] + bb * p2;
+                    }
             }
             continue;
         }
@@ -291,67 +465,21 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
             for (int i = 0; i < 9; i++) Prr[i] = L.Prr[i];
             const int n_sweep = L.n_sweep;  // Update.cpp:26: fixed for the whole chunk
             const int sweep_hi = own_hi < n_sweep ? own_hi : n_sweep;
+            const int n_lm_before = L.n_lm;
 
-            double best_d = EKF_INF;
-            int best_i = 0x7fffffff;
-            double bw[16];
-            for (int i = 0; i < 16; i++) bw[i] = 0;
-            for (int lm = own_lo + tid; lm < sweep_hi; lm += bd) {
-                int Li = 3 + 2 * lm;
-                double dp0 = x[Li] - px, dp1 = x[Li + 1] - py;
-                // z_hat = C^T dp (:109), res = z - z_hat (:111)
-                double res0 = z0 - (c * dp0 + s * dp1);
-                double res1 = z1 - (-s * dp0 + c * dp1);
-                // H_R = [-C^T | -C^T J dp] (:112-114)
-                double h0 = -s * dp0 + c * dp1;
-                double h1 = -c * dp0 - s * dp1;
-                double HR[6] = {-c, -s, h0, s, -c, h1};
-                double HL[4] = {c, s, -s, c};  // H_Li = C^T
-                double A[6];                   // P_RLi 3x2
-                for (int i = 0; i < 3; i++) {
-                    A[i * 2] = R0[(size_t)i * xs + Li];
-                    A[i * 2 + 1] = R0[(size_t)i * xs + Li + 1];
-                }
-                double dxx = Dx[lm], dxy = Dx[dv.dn + lm], dyy = Dx[2 * (size_t)dv.dn + lm];
-                double Pll[4] = {dxx, dxy, dxy, dyy};
-                // S = H_R P_RR H_R^T + H_Li P_LiR H_R^T + H_R P_RLi H_Li^T + H_Li P_LiLi H_Li^T + R (:122)
-                double S[4];
-                for (int i = 0; i < 2; i++)
-                    for (int j = 0; j < 2; j++) {
-                        double t1 = 0, t2 = 0, t3 = 0, t4 = 0;
-                        for (int q = 0; q < 3; q++) {
-                            double hp = HR[i * 3] * Prr[q] + HR[i * 3 + 1] * Prr[3 + q] + HR[i * 3 + 2] * Prr[6 + q];
-                            t1 += hp * HR[j * 3 + q];
-                            double lp = HL[i * 2] * A[q * 2] + HL[i * 2 + 1] * A[q * 2 + 1];  // (H_Li P_LiR)[i][q], P_LiR = A^T
-                            t2 += lp * HR[j * 3 + q];
-                        }
-                        for (int q = 0; q < 2; q++) {
-                            double ha = HR[i * 3] * A[q] + HR[i * 3 + 1] * A[2 + q] + HR[i * 3 + 2] * A[4 + q];
-                            t3 += ha * HL[j * 2 + q];
-                            double lp = HL[i * 2] * Pll[q] + HL[i * 2 + 1] * Pll[2 + q];
-                            t4 += lp * HL[j * 2 + q];
-                        }
-                        S[i * 2 + j] = (((t1 + t2) + t3) + t4) + Rm[i * 2 + j];
-                    }
-                double S00 = S[0], S01 = 0.5 * (S[1] + S[2]), S11 = S[3];  // :123-124
-                // condition number = sigma_max / sigma_min of the symmetric 2x2 (:127-128)
-                double e = 0.5 * (S00 + S11), f = 0.5 * (S00 - S11);
-                double q = fabs(e), r = sqrt(f * f + S01 * S01);
-                double cond = (q + r) / fabs(q - r);
-                if (!(cond >= dv.cond_limit)) {  // :131, NaN is not skipped
-                    double det = S00 * S11 - S01 * S01;
-                    double d = (res0 * (S11 * res0 - S01 * res1) + res1 * (S00 * res1 - S01 * res0)) / det;  // :135-136
-                    if (best_d > d) {  // :140 (false for NaN); ascending lm, so ties keep the lower index
-                        best_d = d, best_i = lm;
-                        bw[0] = res0, bw[1] = res1, bw[2] = S00, bw[3] = S01, bw[4] = S11, bw[5] = h0, bw[6] = h1;
-                        for (int i = 0; i < 6; i++) bw[7 + i] = A[i];
-                        bw[13] = dxx, bw[14] = dxy, bw[15] = dyy;
-                    }
+            SweepBest best;
+            best.d = EKF_INF, best.lm = 0x7fffffff;
+            for (int i = 0; i < 16; i++) best.w[i] = 0;
+            if (worker) {
+                if (lm0 < sweep_hi) sweep_one(lm0, r0, z0, z1, Rm, c, s, px, py, Prr, dv.cond_limit, best);
+                for (int lm = lm0 + nw; lm < sweep_hi; lm += nw) {
+                    LmState st = lm_load(lm);
+                    sweep_one(lm, st, z0, z1, Rm, c, s, px, py, Prr, dv.cond_limit, best);
                 }
             }
             // workgroup arg-min with first-index tie-break
-            double rd = best_d;
-            int ri = best_i;
+            double rd = best.d;
+            int ri = best.lm;
             for (int off = 32; off > 0; off >>= 1) {
                 double od = __shfl_down(rd, off, 64);
                 int oi = __shfl_down(ri, off, 64);
@@ -366,8 +494,8 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
             int gi = L.wi[0];
             for (int wv = 1; wv < (bd >> 6); wv++)
                 if (cand_better(L.wd[wv], L.wi[wv], gd, gi)) gd = L.wd[wv], gi = L.wi[wv];
-            if (gi != 0x7fffffff && gi == best_i)  // this thread owns the workgroup's winner
-                for (int i = 0; i < 16; i++) L.w[i] = bw[i];
+            if (gi != 0x7fffffff && gi == best.lm)  // this thread owns the workgroup's winner
+                for (int i = 0; i < 16; i++) L.w[i] = best.w[i];
             if (tid == 0) L.gd = gd, L.gi = gi;
             __syncthreads();  // (2)
             STAMP(1);  // sweep + workgroup arg-min
@@ -400,25 +528,24 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                 __syncthreads();
                 STAMP(3);  // pick over workgroups
             }
-            // ---- speculative loads for the Old branch: the winner is known, the gate is not yet.  Issue the
-            // matched landmark's slot rows (into LDS) and this thread's first landmark's inputs now, so that
-            // their latency runs under thread 0's gate arithmetic.  Unused when the gate says New / Ignore.
+            // ---- the winner is known, the gate is not yet.  Workers request everything the Old branch will
+            // need (the matched landmark's slot rows into LDS, their own P_LL entries and slot rows into
+            // registers) so that it arrives while the control wave does the gate arithmetic.  Unused when the
+            // gate says New / Ignore.
             const int w_lo = L.gi, w_jo = 2 * w_lo;
-            const bool w_have = (w_lo != 0x7fffffff);
             const int nsl = n_prev + slot;  // slots not yet folded into Bm[buf_read]
-            const int lm0 = own_lo + tid;
-            if (w_have) {
-                for (int q = tid; q < nsl * 16; q += bd) {
+            if (worker && w_lo != 0x7fffffff) {
+                for (int q = wtid; q < nsl * 16; q += nw) {
                     int sidx = q >> 4, side = (q >> 3) & 1, e = (q >> 2) & 1, k = q & 3;
                     bool isprev = sidx < n_prev;
                     int m = isprev ? sidx : sidx - n_prev;
                     const double *F = (side == 0 ? FAb : FBb) + (isprev ? off_p : off_c);
-                    L.lo_rows[q] = L.slot_on[sidx] ? F[f_offset(dv.rows, w_jo + e, m, k)] : 0.0;
+                    L.lo_rows[q] = L.slot_on[sidx] ? F[f_offset(rows_, w_jo + e, m, k)] : 0.0;
                 }
-                if (lm0 < own_hi && lm0 < L.n_lm && lm0 != w_lo) {
-                    spec_lm = lm0;
+                if (lm0 < own_hi && lm0 < n_lm_before && lm0 != w_lo) {
+                    spec_ok = true;
                     load_old_inputs(lm0, w_lo, spec_p);
-                    load_chunk(2 * lm0, lm0 < w_lo, 0, nsl, spec_o0, spec_o1);
+                    if (nsl > 0) load_chunk(2 * lm0, lm0 < w_lo, 0, nsl, spec_o0, spec_o1);
                 }
             }
             // ---- gate + robot block, Update.cpp:152-191 ----------------------------------------------
@@ -540,7 +667,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                 if (rec[6] == 2.0) L.n_sweep = L.n_lm;  // last measurement of the chunk
             }
             __syncthreads();  // (3)
-            STAMP(4);  // gate + robot block
+            STAMP(4);  // gate + robot block (workers: requests in flight)
         } else if (type == OP_COMPASS) {
             // ---- kalmanfilter.cpp:96-130; rec = (z, R) -----------------------------------------------
             __syncthreads();
@@ -577,6 +704,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                 L.S[0] = S;
                 L.invS = invS;
                 L.res[0] = res, L.res[1] = 0;
+                L.HRt[0] = -1, L.HRt[1] = 0;  // unused by the compass gain
                 L.decision = HDR_COMPASS;
                 L.slot_on[n_prev + slot] = 1;
                 if (lead) act_c[slot] = 1;
@@ -586,122 +714,62 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
             continue;  // OP_NOP
         }
 
-        // ---- landmark part of the branch taken: K rows, x += K res, R and D, the slot ----------------
+        // ---- landmark part of the branch taken ----------------------------------------------------------
         const int decision = L.decision;
-        if (decision == HDR_NEW) {
-            const int ln = L.lm;
-            const double c = L.c, s = L.s;  // pose is unchanged by New
-            const int hi = own_hi < ln + 1 ? own_hi : ln + 1;
-            for (int lm = own_lo + tid; lm < hi; lm += bd) {
-                int ip = 2 * lm, i0 = 3 + ip;
-                double *fa = FAc + f_offset(dv.rows, ip, slot, 0), *fb = FBc + f_offset(dv.rows, ip, slot, 0);
-                if (lm < ln) {
-                    double v[2][2];
-                    for (int a = 0; a < 2; a++) {
-                        double u0 = 0, u1 = 0;
-                        for (int q = 0; q < 3; q++) {  // ((-P[i,0:3]) H_R^T) H_Li, Update.cpp:169
-                            double p = -R0[(size_t)q * xs + i0 + a];
-                            u0 += p * L.HRt[q * 2];
-                            u1 += p * L.HRt[q * 2 + 1];
-                        }
-                        v[a][0] = u0 * c + u1 * (-s);
-                        v[a][1] = u0 * s + u1 * c;
-                    }
-                    // slot: column pair of the new landmark = A[i] . unit rows of B
-                    *(double4_t *)fa = (double4_t){v[0][0], v[0][1], 0, 0};
-                    *(double4_t *)(fa + 4) = (double4_t){v[1][0], v[1][1], 0, 0};
-                    *(double4_t *)fb = (double4_t){0, 0, 0, 0};
-                    *(double4_t *)(fb + 4) = (double4_t){0, 0, 0, 0};
-                } else {  // the new landmark itself: state, robot columns, 2x2 block, unit B rows
-                    x[i0] = L.newx[0];
-                    x[i0 + 1] = L.newx[1];
-                    for (int r = 0; r < 3; r++) {
-                        R0[(size_t)r * xs + i0] = L.newrc[r * 2];
-                        R0[(size_t)r * xs + i0 + 1] = L.newrc[r * 2 + 1];
-                    }
-                    Dx[lm] = L.newdd[0];
-                    Dx[dv.dn + lm] = L.newdd[1];
-                    Dx[2 * (size_t)dv.dn + lm] = L.newdd[2];
-                    *(double4_t *)fa = (double4_t){0, 0, 0, 0};
-                    *(double4_t *)(fa + 4) = (double4_t){0, 0, 0, 0};
-                    *(double4_t *)fb = (double4_t){1, 0, 0, 0};
-                    *(double4_t *)(fb + 4) = (double4_t){0, 1, 0, 0};
-                }
-            }
-        } else if (decision == HDR_OLD || decision == HDR_COMPASS) {
-            const int n_lm = L.n_lm;
-            const int lo = L.lm, jo = 2 * lo;
-            const double res0 = L.res[0], res1 = L.res[1];
-            // the rotation the header was built with: H_Li^T = C of the pose BEFORE this update.
-            // L.c/L.s already hold the updated heading, so take C from H_R^T = [-C | ...]^T.
-            const double c = -L.HRt[0], s = L.HRt[1];
-            const int nslots = (type == OP_MEAS) ? n_prev + slot : 0;
-            const int hi = own_hi < n_lm ? own_hi : n_lm;
-            for (int lm = own_lo + tid; lm < hi; lm += bd) {
-                int ip = 2 * lm, i0 = 3 + ip;
-                double K[2][2], Tt[2][2];
-                if (decision == HDR_OLD) {
-                    double p[2][2];  // P[i, Lo], P[i, Lo+1] for the two rows of this landmark
-                    if (lm == lo) {
-                        p[0][0] = Dx[lm], p[0][1] = Dx[dv.dn + lm];
-                        p[1][0] = Dx[dv.dn + lm], p[1][1] = Dx[2 * (size_t)dv.dn + lm];
+        if (worker) {
+            if (decision == HDR_NEW) {
+                const int ln = L.lm;
+                const int hi = own_hi < ln ? own_hi : ln;
+                if (lm0 < hi) apply_new_column(lm0, r0, slot);
+                else if (lm0 == ln && lm0 < own_hi) apply_new_self(lm0, r0, slot);
+                for (int lm = lm0 + nw; lm < own_hi && lm <= ln; lm += nw) {
+                    if (lm < ln) {
+                        LmState st = lm_load(lm);
+                        apply_new_column(lm, st, slot);
                     } else {
-                        const bool below = lm < lo;  // stored as (row of the older landmark, column of the newer)
-                        double4_t o0[4], o1[4];
-                        if (lm == spec_lm) {  // inputs were requested before the gate
-                            for (int a = 0; a < 2; a++)
-                                for (int e = 0; e < 2; e++) p[a][e] = spec_p[a][e];
-                            if (nslots > 0) fold_chunk(below, 0, nslots, spec_o0, spec_o1, p);
+                        LmState st;
+                        apply_new_self(lm, st, slot);
+                    }
+                }
+            } else if (decision == HDR_OLD || decision == HDR_COMPASS) {
+                const bool is_old = (decision == HDR_OLD);
+                const int n_lm = L.n_lm;
+                const int lo = L.lm;
+                const int nslots = is_old ? n_prev + slot : 0;
+                const int hi = own_hi < n_lm ? own_hi : n_lm;
+                // one landmark; `st` is either the register-resident r0 or a copy loaded from memory
+                auto gain_one = [&](int lm, LmState &st, bool use_spec) {
+                    double p[2][2] = {{0, 0}, {0, 0}};
+                    if (is_old) {
+                        if (lm == lo) {
+                            p[0][0] = st.dxx, p[0][1] = st.dxy, p[1][0] = st.dxy, p[1][1] = st.dyy;
                         } else {
-                            load_old_inputs(lm, lo, p);
-                            if (nslots > 0) {
-                                load_chunk(ip, below, 0, nslots, o0, o1);
-                                fold_chunk(below, 0, nslots, o0, o1, p);
+                            const bool below = lm < lo;  // stored as (row of the older landmark, column of the newer)
+                            double4_t o0[4], o1[4];
+                            if (use_spec) {  // requested before the gate
+                                for (int a = 0; a < 2; a++)
+                                    for (int e = 0; e < 2; e++) p[a][e] = spec_p[a][e];
+                                if (nslots > 0) fold_chunk(below, 0, nslots, spec_o0, spec_o1, p);
+                            } else {
+                                load_old_inputs(lm, lo, p);
+                                if (nslots > 0) {
+                                    load_chunk(2 * lm, below, 0, nslots, o0, o1);
+                                    fold_chunk(below, 0, nslots, o0, o1, p);
+                                }
+                            }
+                            for (int s0 = 4; s0 < nslots; s0 += 4) {
+                                load_chunk(2 * lm, below, s0, nslots, o0, o1);
+                                fold_chunk(below, s0, nslots, o0, o1, p);
                             }
                         }
-                        for (int s0 = 4; s0 < nslots; s0 += 4) {
-                            load_chunk(ip, below, s0, nslots, o0, o1);
-                            fold_chunk(below, s0, nslots, o0, o1, p);
-                        }
                     }
-                    for (int a = 0; a < 2; a++) {
-                        double u0 = 0, u1 = 0;
-                        for (int q = 0; q < 3; q++) {  // P[i,0:3] H_R^T, Update.cpp:186
-                            double pr = R0[(size_t)q * xs + i0 + a];
-                            u0 += pr * L.HRt[q * 2];
-                            u1 += pr * L.HRt[q * 2 + 1];
-                        }
-                        double w0 = p[a][0] * c + p[a][1] * s, w1 = p[a][0] * (-s) + p[a][1] * c;  // P[i,Lo:Lo+2] H_Li^T
-                        double s0 = u0 + w0, s1 = u1 + w1;
-                        K[a][0] = s0 * L.Sinv[0] + s1 * L.Sinv[2];
-                        K[a][1] = s0 * L.Sinv[1] + s1 * L.Sinv[3];
-                        Tt[a][0] = K[a][0] * L.S[0] + K[a][1] * L.S[2];
-                        Tt[a][1] = K[a][0] * L.S[1] + K[a][1] * L.S[3];
-                    }
-                } else {  // K = (1/S) P[:,2], kalmanfilter.cpp:118
-                    for (int a = 0; a < 2; a++) {
-                        K[a][0] = L.invS * R0[2 * (size_t)xs + i0 + a];
-                        K[a][1] = 0;
-                        Tt[a][0] = L.S[0] * K[a][0];
-                        Tt[a][1] = 0;
-                    }
+                    apply_gain(lm, st, is_old, p, slot);
+                };
+                if (lm0 < hi) gain_one(lm0, r0, spec_ok);
+                for (int lm = lm0 + nw; lm < hi; lm += nw) {
+                    LmState stm = lm_load(lm);
+                    gain_one(lm, stm, false);
                 }
-                // x += K res (Update.cpp:187 / kalmanfilter.cpp:121)
-                for (int a = 0; a < 2; a++) x[i0 + a] = x[i0 + a] + (K[a][0] * res0 + K[a][1] * res1);
-                // robot rows of P -= sym(K S K^T)
-                for (int r = 0; r < 3; r++)
-                    for (int a = 0; a < 2; a++)
-                        R0[(size_t)r * xs + i0 + a] -= sym_u(L.TR[r * 2], L.TR[r * 2 + 1], L.KR[r * 2], L.KR[r * 2 + 1], Tt[a][0], Tt[a][1], K[a][0], K[a][1]);
-                // own 2x2 block
-                Dx[lm] -= sym_u(Tt[0][0], Tt[0][1], K[0][0], K[0][1], Tt[0][0], Tt[0][1], K[0][0], K[0][1]);
-                Dx[dv.dn + lm] -= sym_u(Tt[0][0], Tt[0][1], K[0][0], K[0][1], Tt[1][0], Tt[1][1], K[1][0], K[1][1]);
-                Dx[2 * (size_t)dv.dn + lm] -= sym_u(Tt[1][0], Tt[1][1], K[1][0], K[1][1], Tt[1][0], Tt[1][1], K[1][0], K[1][1]);
-                // slot: P_LL += A B^T with A = -0.5 [T | K], B = [K | T]; one 64-byte line per landmark and side
-                double *fa = FAc + f_offset(dv.rows, ip, slot, 0), *fb = FBc + f_offset(dv.rows, ip, slot, 0);
-                *(double4_t *)fa = (double4_t){-0.5 * Tt[0][0], -0.5 * Tt[0][1], -0.5 * K[0][0], -0.5 * K[0][1]};
-                *(double4_t *)(fa + 4) = (double4_t){-0.5 * Tt[1][0], -0.5 * Tt[1][1], -0.5 * K[1][0], -0.5 * K[1][1]};
-                *(double4_t *)fb = (double4_t){K[0][0], K[0][1], Tt[0][0], Tt[0][1]};
-                *(double4_t *)(fb + 4) = (double4_t){K[1][0], K[1][1], Tt[1][0], Tt[1][1]};
             }
         }
         STAMP(6);  // landmark part
