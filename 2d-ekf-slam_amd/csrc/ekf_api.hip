@@ -86,7 +86,7 @@ extern "C" void ekf_default_params(ekf_params *p) {
     p->gamma_max = 50.0;
     p->gamma_min = 10.0;
     p->cond_limit = 80.0;
-    p->max_pending = 4;
+    p->max_pending = 16;
     p->log_capacity = 4096;
 }
 
@@ -520,6 +520,26 @@ extern "C" int ekf_num_landmarks(ekf_handle h) {
     int n;
     int rc = ekf_batch_num_landmarks(h, &n);
     return rc ? rc : n;
+}
+
+extern "C" int ekf_get_robot_cov(ekf_handle h, double P_RR_out[9]) {
+    if (!h || h->dv.B != 1 || !P_RR_out) return set_error(EKF_ERR_BAD_ARG, "single-filter call on a batch handle");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemcpy2DAsync(P_RR_out, 3 * sizeof(double), h->dv.R, (size_t)h->dv.xs * sizeof(double), 3 * sizeof(double), 3,
+                             hipMemcpyDeviceToHost, h->s_chain));
+    HIP_TRY(hipStreamSynchronize(h->s_chain));
+    return EKF_OK;
+}
+
+extern "C" int ekf_get_x(ekf_handle h, int index, double *x_out, int n_max) {
+    if (!h || index < 0 || index >= h->dv.B || !x_out || n_max < 0) return set_error(EKF_ERR_BAD_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    int rc = refresh_bounds(h);
+    if (rc) return rc;
+    int n = 3 + 2 * h->h_int[index];
+    int cnt = n < n_max ? n : n_max;
+    HIP_TRY(hipMemcpy(x_out, h->dv.x + (size_t)index * h->dv.xs, sizeof(double) * cnt, hipMemcpyDeviceToHost));
+    return n;
 }
 
 static int fetch_decisions(ekf_batch *h, int n_z, ekf_decision *out) {

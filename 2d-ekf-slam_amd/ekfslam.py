@@ -18,7 +18,7 @@ NEW, OLD, IGNORE = 1, 2, 3
 ABI_SYMBOLS = [
     "ekf_last_error", "ekf_default_params", "ekf_create", "ekf_batch_create", "ekf_destroy", "ekf_batch_size",
     "ekf_capacity", "ekf_propagate", "ekf_propagate_q", "ekf_update", "ekf_update_compass", "ekf_get_pose",
-    "ekf_num_landmarks", "ekf_batch_propagate", "ekf_batch_propagate_q", "ekf_batch_update",
+    "ekf_num_landmarks", "ekf_get_robot_cov", "ekf_get_x", "ekf_batch_propagate", "ekf_batch_propagate_q", "ekf_batch_update",
     "ekf_batch_update_compass", "ekf_batch_get_pose", "ekf_batch_num_landmarks", "ekf_get_state", "ekf_set_state",
     "ekf_broadcast_state", "ekf_script_load", "ekf_script_run", "ekf_sync", "ekf_flush", "ekf_timer_start",
     "ekf_timer_stop", "ekf_flush_profile", "ekf_flush_profile_read", "ekf_get_decisions", "ekf_get_stats",
@@ -77,6 +77,8 @@ def load():
     L.ekf_update_compass.argtypes = [_H, ctypes.c_double, ctypes.c_double]
     L.ekf_get_pose.argtypes = [_H, _dp]
     L.ekf_num_landmarks.argtypes = [_H]
+    L.ekf_get_robot_cov.argtypes = [_H, _dp]
+    L.ekf_get_x.argtypes = [_H, ctypes.c_int, _dp, ctypes.c_int]
     L.ekf_batch_propagate.argtypes = [_H, _dp, _dp, _dp]
     L.ekf_batch_propagate_q.argtypes = [_H, _dp, _dp, _dp, _dp]
     L.ekf_batch_update.argtypes = [_H, _dp, _dp, _up, ctypes.c_int, ctypes.POINTER(EkfDecision)]
@@ -192,6 +194,17 @@ class FilterBatch:
         out = np.empty((self.batch, 3))
         _chk(self.L.ekf_batch_get_pose(self.h, _p(out)))
         return out
+
+    def robot_cov(self):
+        out = np.empty((3, 3))
+        _chk(self.L.ekf_get_robot_cov(self.h, _p(out)))
+        return out
+
+    def get_x(self, index=0):
+        n = _chk(self.L.ekf_get_x(self.h, index, _p(np.empty(1)), 0))
+        x = np.empty(n)
+        _chk(self.L.ekf_get_x(self.h, index, _p(x), n))
+        return x
 
     def num_landmarks(self):
         out = np.empty(self.batch, dtype=np.int32)

@@ -1,0 +1,104 @@
+// compat/kalmanfilter.h -- header-compatible replacement for the reference's
+// odometry/kalmanfilter.h:21-43.  Same class name, same public members (X, Y, Phi, Num_Landmarks),
+// same three methods with the same signatures; the state lives in HBM behind the C ABI of
+// include/ekfslam_c.h (libekfslam_hip.so).  slam.cpp:127,136,146,170 compile against it unchanged.
+//
+// What stays on the host, exactly where the reference has it:
+//   - the ARIA velocity reads under robot->lock() and their unit conversions (kalmanfilter.cpp:17-26)
+//   - the two per-step file writes (kalmanfilter.cpp:51,56-59), same formats, same index quirk
+//   - the public mirrors refreshed after every call (kalmanfilter.cpp:46-48,85-89)
+// What the reference does not have: an error channel.  A failing C-ABI call throws std::runtime_error.
+#ifndef KALMANFILTER_H
+#define KALMANFILTER_H
+
+#include <fstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#if __has_include(<Eigen/Dense>)
+#include <Eigen/Dense>
+#else
+#include "standin/eigen_standin.h"
+#endif
+#if __has_include("Aria.h")
+#include "Aria.h"
+#else
+#include "standin/aria_standin.h"
+#endif
+
+#include "../include/ekfslam_c.h"
+
+#define INF 999999999999 /* kalmanfilter.h:17 */
+
+class KalmanFilter {
+public:
+    double X = 0.0;
+    double Y = 0.0;
+    double Phi = 0.0;
+    int Num_Landmarks = 0;
+
+    // capacity_landmarks / device_id are additions with defaults: `new KalmanFilter(&robot)` still works
+    explicit KalmanFilter(ArRobot *robot, int capacity_landmarks = 4096, int device_id = 0) : robot(robot) {
+        check(ekf_create(&h, capacity_landmarks, device_id, nullptr));  // x = 0_3, P = 0_3x3: kalmanfilter.cpp:10-11
+    }
+    ~KalmanFilter() { ekf_destroy(h); }
+    KalmanFilter(const KalmanFilter &) = delete;
+    KalmanFilter &operator=(const KalmanFilter &) = delete;
+
+    void doPropagation(double dt, std::ofstream &covFile, std::ofstream &knownfeaturesFile) {
+        robot->lock();  // kalmanfilter.cpp:17-20
+        double V = robot->getVel();
+        double RTV = robot->getRotVel() * 3.141592654 / 180.0;
+        robot->unlock();
+        double v = V / 1000.0;  // :26
+        double w = RTV;
+        check(ekf_propagate(h, v, w, dt));  // Q = (v*v) diag(0.01, 0.04)^2 and Propagate, :28-44
+        mirror();
+        double Prr[9];
+        check(ekf_get_robot_cov(h, Prr));
+        covFile << Prr[0] << " " << Prr[1] << " " << Prr[3] << " " << Prr[4] << std::endl;  // :51
+        if (Num_Landmarks > 0) {  // :53-60, including its stride-1 indexing
+            xbuf.resize(3 + 2 * (size_t)Num_Landmarks);
+            check(ekf_get_x(h, 0, xbuf.data(), (int)xbuf.size()));
+            for (int i = 1; i < Num_Landmarks; i++) knownfeaturesFile << xbuf[3 + i] << " " << xbuf[4 + i] << std::endl;
+        }
+    }
+
+    void doUpdate(Eigen::MatrixXd z_chunk, Eigen::MatrixXd R_chunk) {
+        int n_z = (int)(z_chunk.size() / 2);  // Update.cpp:27
+        decisions.resize(n_z);
+        // z_chunk.data() / R_chunk.data() are column-major, which is what the C ABI takes
+        check(ekf_update(h, z_chunk.data(), R_chunk.data(), n_z, decisions.data()));  // Gamma 50 / 10: kalmanfilter.cpp:67-68
+        mirror();
+    }
+
+    void doUpdateCompass(double z, double R) {
+        check(ekf_update_compass(h, z, R));
+        mirror();
+    }
+
+    // not in the reference: the gate decisions of the last doUpdate ("New " / "Old " / "Ignore ", Update.cpp:154,183,191)
+    const std::vector<ekf_decision> &lastDecisions() const { return decisions; }
+    ekf_handle handle() const { return h; }
+
+private:
+    ArRobot *robot;
+    ekf_handle h = nullptr;
+    std::vector<ekf_decision> decisions;
+    std::vector<double> xbuf;
+
+    void mirror() {  // kalmanfilter.cpp:46-48, 85-89
+        double pose[3];
+        check(ekf_get_pose(h, pose));
+        X = pose[0], Y = pose[1], Phi = pose[2];
+        int n = ekf_num_landmarks(h);
+        check(n);
+        Num_Landmarks = n;
+    }
+    static void check(int rc) {
+        if (rc < 0) throw std::runtime_error(std::string("libekfslam_hip: ") + ekf_last_error());
+    }
+};
+
+#endif  // KALMANFILTER_H

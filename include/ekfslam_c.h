@@ -52,8 +52,11 @@ typedef struct ekf_params {
     double gamma_max;   /* 50    kalmanfilter.cpp:67 (int there) */
     double gamma_min;   /* 10    kalmanfilter.cpp:68 (int there) */
     double cond_limit;  /* 80    Update.cpp:131 */
-    int max_pending;    /* rank-2 updates deferred before one dense pass over P_LL; 1 = a dense
-                           pass per measurement as the reference does (Update.cpp:188).  1..8 */
+    int max_pending;    /* measurements whose P_LL change is deferred into ONE dense pass over P_LL
+                           (each is a rank-4 slot of that pass); 1 = a dense pass per measurement as the
+                           reference does (Update.cpp:188).  1..32, default 16.  Results do not depend on
+                           it beyond rounding; x, the robot rows and the landmark 2x2 blocks are always
+                           current, and ekf_get_state / ekf_flush fold everything on demand. */
     int log_capacity;   /* decision-log entries kept per filter (ring) */
 } ekf_params;
 
@@ -75,7 +78,8 @@ const char *ekf_last_error(void);
 void ekf_default_params(ekf_params *p);
 
 /* KalmanFilter::KalmanFilter, kalmanfilter.cpp:4-12: x = 0_3, P = 0_3x3, no landmarks.
- * capacity_landmarks bounds N; all device memory is allocated here, none later. */
+ * capacity_landmarks bounds N; all device memory is allocated here, none later (except a transient
+ * staging buffer inside ekf_get_state / ekf_set_state). */
 int ekf_create(ekf_handle *out, int capacity_landmarks, int device_id, const ekf_params *params);
 int ekf_batch_create(ekf_handle *out, int batch, int capacity_landmarks, int device_id, const ekf_params *params);
 int ekf_destroy(ekf_handle h);
@@ -99,6 +103,11 @@ int ekf_update_compass(ekf_handle h, double z, double R);
 /* The public mirrors X, Y, Phi, Num_Landmarks of kalmanfilter.h:24-27 (synchronises). */
 int ekf_get_pose(ekf_handle h, double pose_out[3]);
 int ekf_num_landmarks(ekf_handle h);  /* >= 0, or a negative status */
+/* The robot block P[0:3,0:3], row-major (what kalmanfilter.cpp:51 logs a corner of); synchronises. */
+int ekf_get_robot_cov(ekf_handle h, double P_RR_out[9]);
+/* The state vector of filter `index` (what kalmanfilter.cpp:56-59 logs from); copies min(n, n_max)
+ * entries, returns n; synchronises.  The covariance stays on the device. */
+int ekf_get_x(ekf_handle h, int index, double *x_out, int n_max);
 
 /* ---- batched calls: arrays carry a leading [batch] dimension -------------------------------- */
 
@@ -130,13 +139,14 @@ int ekf_broadcast_state(ekf_handle h);
  * ekf_script_run only enqueues kernels (no host->device traffic, no synchronisation). */
 int ekf_script_load(ekf_handle h, int steps, int M, const double *ctrl, const double *z, const double *R,
                     const unsigned char *valid, const double *truth);
-/* use_graph != 0 replays the steps through captured HIP graphs. */
+/* use_graph != 0 replays the steps through captured HIP graphs (blocks of a few steps; the remainder
+ * goes out as plain launches). */
 int ekf_script_run(ekf_handle h, int first_step, int n_steps, int use_graph);
 
 /* ---- synchronisation, timing, diagnostics ---------------------------------------------------- */
 
 int ekf_sync(ekf_handle h);  /* waits for the stream, returns a sticky error (EKF_ERR_CAPACITY) if any filter raised one */
-/* Flush deferred rank-2 updates into P_LL now (asynchronous). */
+/* Fold the deferred slots into P_LL now (one dense pass, asynchronous). */
 int ekf_flush(ekf_handle h);
 /* hipEvent pair on the handle's stream. stop synchronises and returns elapsed milliseconds. */
 int ekf_timer_start(ekf_handle h);

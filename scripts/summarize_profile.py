@@ -1,0 +1,41 @@
+"""Condense a scripts/profile_r01.sh output directory into the small files committed under profiles/."""
+import collections, csv, glob, json, os, shutil, sys
+
+src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof_r01"
+tag = sys.argv[2] if len(sys.argv) > 2 else "r01_n4096_w16"
+dst = "profiles"
+os.makedirs(dst, exist_ok=True)
+ks = glob.glob(os.path.join(src, "trace/runc/*_kernel_stats.csv"))[0]
+shutil.copy(ks, os.path.join(dst, tag + "_kernel_stats.csv"))
+summary = {"command": "rocprofv3 --kernel-trace --stats | --pmc FETCH_SIZE | --pmc WRITE_SIZE | --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE  -- python3 bench.py --no-cpu-baseline --steps 64 --warmup 8 (scripts/profile_r01.sh)",
+           "kernels": {}, "bench_lines": {}}
+for row in csv.DictReader(open(ks)):
+    summary["kernels"][row["Name"].split("(")[0]] = {"calls": int(row["Calls"]), "avg_us": float(row["AverageNs"]) / 1e3, "pct": float(row["Percentage"])}
+for name in ("pmc_fetch", "pmc_write", "pmc_mfma"):
+    fs = glob.glob(os.path.join(src, name, "runc/*_counter_collection.csv"))
+    if not fs:
+        continue
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(fs[0])):
+        agg[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, v in agg.items():
+        if k in summary["kernels"]:
+            for c, vals in v.items():
+                summary["kernels"][k][c + "_mean_per_dispatch"] = sum(vals) / len(vals)
+for n in ("trace", "fetch", "write", "mfma"):
+    p = os.path.join(src, "bench_%s.json" % n)
+    if os.path.exists(p) and os.path.getsize(p):
+        d = json.load(open(p))
+        summary["bench_lines"][n] = {"value": d["value"], "flush_avg_launch_us_events": d["roofline"]["avg_launch_us"], "frac": d["roofline"]["frac"]}
+fl = summary["kernels"].get("k_flush", {})
+if "FETCH_SIZE_mean_per_dispatch" in fl and "WRITE_SIZE_mean_per_dispatch" in fl:
+    # rocprofv3 reports KB.  gfx950: FETCH_SIZE tallies the 128-byte requests of a 16 B/lane stream at 64 B
+    # (MI355X_MICROARCH.md, HBM): the tile stream (= WRITE_SIZE bytes, read once, written once) is doubled,
+    # what is left of FETCH_SIZE is the 8 B/lane operand traffic and is taken as reported.
+    f_kb, w_kb = fl["FETCH_SIZE_mean_per_dispatch"], fl["WRITE_SIZE_mean_per_dispatch"]
+    tile_read = w_kb * 1024.0
+    operand = max(f_kb * 1024.0 - tile_read / 2.0, 0.0)
+    summary["traffic"] = {"fetch_size_kb": f_kb, "write_size_kb": w_kb, "tile_read_bytes": tile_read, "operand_read_bytes": operand,
+                          "hbm_bytes_per_launch": tile_read + operand + w_kb * 1024.0}
+json.dump(summary, open(os.path.join(dst, tag + "_summary.json"), "w"), indent=1)
+print(json.dumps(summary, indent=1))
