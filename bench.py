@@ -47,6 +47,8 @@ def main():
     ap.add_argument("--max-pending", type=int, default=16, help="measurements folded per dense pass over P_LL (1 = a dense pass per measurement, as the reference does)")
     ap.add_argument("--graph", type=int, default=0, help="replay steps through HIP graphs (one k_chain launch already covers several steps; plain launches keep the per-launch dense-pass events)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the real thing) or gloo (rehearsal of the multi-rank path on a one-GPU box)")
+    ap.add_argument("--device", type=int, default=None, help="force a device id (rehearsal only; default LOCAL_RANK)")
     ap.add_argument("--no-flush-profile", action="store_true", help="do not bracket the dense pass with hipEvents")
     args = ap.parse_args()
 
@@ -70,15 +72,20 @@ def main():
     W = args.warmup if args.warmup is not None else d_warm
     M = args.M
 
-    torch.cuda.set_device(local_rank)
+    dev_id = local_rank if args.device is None else args.device
+    torch.cuda.set_device(dev_id)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_id))
+        else:
+            dist.init_process_group(args.dist_backend)
+    coll_device = torch.device("cuda", dev_id) if args.dist_backend == "nccl" else torch.device("cpu")
 
     # ---- inputs: built on the host, then moved to HBM (untimed) ------------------------------------
     lo, hi = mc.shard_range(B * world, rank, world)
-    f = pkg.FilterBatch(B, N, device=local_rank, max_pending=args.max_pending, log_capacity=max(4096, (K + W) * M))
+    f = pkg.FilterBatch(B, N, device=dev_id, max_pending=args.max_pending, log_capacity=max(4096, (K + W) * M))
     scripts = []
     for b, g in enumerate(range(lo, hi)):
         x0, P0 = pkg.scenarios.injected_state(N, seed=mc.filter_seed(seed, g), extent=extent)
@@ -108,14 +115,14 @@ def main():
     f.flush()                # P_LL fully folded inside the timed region, whatever K*M modulo the window is
     dev_ms = f.timer_stop()  # hipEvents on the handle's own stream
     summary = mc.summarise(f.stats())
-    gathered = mc.gather_stats(summary, device=torch.device("cuda", local_rank))  # the one RCCL collective
+    gathered = mc.gather_stats(summary, device=coll_device)  # the one collective (RCCL all-gather)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
     if dist is not None:
-        te = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        te = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
 
