@@ -52,6 +52,7 @@ struct ekf_batch {
     int cur_set;    // slot set being filled
     int pending;    // slots used in cur_set
     int buf_in;     // Bm buffer the NEXT dense pass reads
+    int stagger_ns;       // EKF_FLUSH_STAGGER_NS: first-generation de-phasing delay of the dense pass, -1 = automatic
     int flush_variant;    // EKF_FLUSH_VARIANT: 0 = one wave per 64x64 tile, 1 = one wave per 32x32 quadrant
     bool dbg_skip_flush;  // EKF_DEBUG_SKIP_FLUSH=1: timing experiments only, results are wrong
     // immediate-mode input ring (host-mapped pinned)
@@ -137,7 +138,8 @@ extern "C" int ekf_batch_create(ekf_handle *out, int batch, int capacity_landmar
     dv.logcap = h->params.log_capacity;
     dv.bm_stride = (size_t)dv.T * (dv.T + 1) / 2 * 4096;
     dv.rows = 64 * dv.T;
-    dv.f_stride = (size_t)(dv.maxp + 1) * dv.rows * 4;
+    dv.maxpairs = (dv.maxp + 1) / 2;
+    dv.f_stride = (size_t)(dv.maxpairs + 1) * dv.rows * 4;
     dv.gamma_max = h->params.gamma_max;
     dv.gamma_min = h->params.gamma_min;
     dv.cond_limit = h->params.cond_limit;
@@ -201,6 +203,7 @@ extern "C" int ekf_batch_create(ekf_handle *out, int batch, int capacity_landmar
     h->cur_set = 0;
     h->pending = 0;
     h->buf_in = 0;
+    h->stagger_ns = getenv("EKF_FLUSH_STAGGER_NS") ? atoi(getenv("EKF_FLUSH_STAGGER_NS")) : -1;
     h->flush_variant = getenv("EKF_FLUSH_VARIANT") ? atoi(getenv("EKF_FLUSH_VARIANT")) : 0;
     h->dbg_skip_flush = getenv("EKF_DEBUG_SKIP_FLUSH") && atoi(getenv("EKF_DEBUG_SKIP_FLUSH")) != 0;
     h->script_d = nullptr;
@@ -262,7 +265,8 @@ static int close_set(ekf_batch *h) {
     if (nT_hi > 0 && !h->dbg_skip_flush) {
         int total = nT_hi * (nT_hi + 1) / 2;
         dim3 grid(h->flush_variant == 1 ? total : cdiv(total, 4), h->dv.B);
-        auto kern = h->flush_variant == 1 ? k_flush_q : k_flush;
+        // half a tile period: about 4 us of HBM share plus 0.24 us of MFMA per slot (EKF_FLUSH_STAGGER_NS overrides)
+        int stagger_ticks = h->stagger_ns >= 0 ? h->stagger_ns / 10 : (400 + 12 * h->pending);
         if (h->prof_flush) {
             while (h->prof_pool.size() < h->prof_used + 2) {
                 hipEvent_t e;
@@ -271,9 +275,11 @@ static int close_set(ekf_batch *h) {
             }
             hipEvent_t e0 = h->prof_pool[h->prof_used++], e1 = h->prof_pool[h->prof_used++];
             // start/stop events ride on the dispatch packet itself: no extra barrier packets
-            hipExtLaunchKernelGGL(kern, grid, dim3(256), 0, h->s_chain, e0, e1, 0, h->dv, nT_hi, h->cur_set, h->pending, h->buf_in);
+            if (h->flush_variant == 1) hipExtLaunchKernelGGL(k_flush_q, grid, dim3(256), 0, h->s_chain, e0, e1, 0, h->dv, nT_hi, h->cur_set, h->pending, h->buf_in);
+            else hipExtLaunchKernelGGL(k_flush, grid, dim3(256), 0, h->s_chain, e0, e1, 0, h->dv, nT_hi, h->cur_set, h->pending, h->buf_in, stagger_ticks);
         } else {
-            hipLaunchKernelGGL(kern, grid, dim3(256), 0, h->s_chain, h->dv, nT_hi, h->cur_set, h->pending, h->buf_in);
+            if (h->flush_variant == 1) hipLaunchKernelGGL(k_flush_q, grid, dim3(256), 0, h->s_chain, h->dv, nT_hi, h->cur_set, h->pending, h->buf_in);
+            else hipLaunchKernelGGL(k_flush, grid, dim3(256), 0, h->s_chain, h->dv, nT_hi, h->cur_set, h->pending, h->buf_in, stagger_ticks);
         }
     }
     h->cur_set ^= 1;

@@ -26,6 +26,7 @@
 
 #define EKF_INF 999999999999.0 /* kalmanfilter.h:17 */
 #define EKF_MAX_PENDING 32
+#define EKF_MAX_PAIRS (EKF_MAX_PENDING / 2)
 #define EKF_CHAIN_MAX_THREADS 256 /* one control wave + up to 192 workers: one wave per SIMD, 512-VGPR budget */
 #define EKF_CHAIN_MAX_WGS 32 /* workgroups sharing one filter in k_chain */
 #define EKF_CHAIN_MAX_OPS 64 /* operations per k_chain launch */
@@ -40,13 +41,14 @@ struct EkfDev {
     int xs;    // stride of x and of each R row (doubles), multiple of 64, >= 3 + 2*Ncap
     int dn;    // stride of each D component, = 32*T
     int T;     // 64x64 tiles per side of P_LL
-    int maxp;  // slots per set
+    int maxp;  // slots (measurements) per set
+    int maxpairs;  // (maxp + 1) / 2 slot pairs per set; pair maxpairs is all zeros
     int logcap;
     int rows;  // 64*T: rows of one slot in FA / FB
     int lpw;   // landmarks owned by one k_chain workgroup
     int gmax;  // k_chain workgroups per filter
     size_t bm_stride;  // doubles per filter in one Bm buffer: T(T+1)/2 * 4096
-    size_t f_stride;   // doubles per (filter, set) in FA / FB: (maxp + 1) * rows * 4; slot maxp stays all zero
+    size_t f_stride;   // doubles per (filter, set) in FA / FB: (maxpairs + 1) * rows * 4
     double *x, *R, *D;
     double *Bm[2];
     double *FA, *FB;   // [B][2][f_stride]
@@ -78,7 +80,8 @@ __host__ __device__ inline size_t bm_offset(int T, int ip, int jp) {
     return t * 4096 + (size_t)chain * 256 + (size_t)(r >> 1) * 128 + (size_t)(g * 16 + c) * 2 + (r & 1);
 }
 
-// Offset (doubles) of entry (row i', slot m, component k) inside one (filter, set) of FA / FB.
-__host__ __device__ inline size_t f_offset(int rows, int ip, int m, int k) {
-    return ((size_t)m * rows + ip) * 4 + k;
+// Offset (doubles) of row i' of slot PAIR p inside one (filter, set) of FA / FB: 4 doubles, slot 2p in
+// [0..1], slot 2p+1 in [2..3].
+__host__ __device__ inline size_t pair_offset(int rows, int ip, int p) {
+    return ((size_t)p * rows + ip) * 4;
 }

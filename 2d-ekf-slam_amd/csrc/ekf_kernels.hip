@@ -61,9 +61,9 @@ struct ChainLds {
     double TR[6];    // rows 0..2 of K*S
     double invS;     // compass: 1/S                      (kalmanfilter.cpp:118)
     double newx[2], newrc[6], newdd[3];  // New landmark: state, P_R,new (3x2), 2x2 block
-    // slot rows of the matched landmark, [slot][side A/B][row e][k], and which slots are live
-    double lo_rows[2 * EKF_MAX_PENDING * 16];
-    int slot_on[2 * EKF_MAX_PENDING];  // [0, n_prev): the set a dense pass is consuming; then the set being filled
+    // rows of the matched landmark in every not-yet-folded slot pair, [pair][side A/B][row e][k], and which pairs are live
+    double lo_rows[2 * EKF_MAX_PAIRS * 16];
+    int pair_on[2 * EKF_MAX_PAIRS];  // slot PAIRS: first those of the set a dense pass is consuming, then the set being filled
 };
 
 // Diagnostic build (-DEKF_CHAIN_STAMPS): workgroup 0's thread 0 adds the 100 MHz wall-clock ticks each
@@ -215,6 +215,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
     // slot arrays addressed as base + set offset: a 4-way pointer select would become a scratch table
     const double *FAb = dv.FA + (size_t)b * 2 * dv.f_stride, *FBb = dv.FB + (size_t)b * 2 * dv.f_stride;
     const size_t off_c = (size_t)set * dv.f_stride, off_p = (size_t)(set ^ 1) * dv.f_stride;
+    const int np_prev = (n_prev + 1) >> 1;  // slot pairs of the set a dense pass is consuming
     const int T_ = dv.T, rows_ = dv.rows, dn_ = dv.dn;  // by-value captures: a reference to dv would push the kernel arguments to scratch
 
     auto lm_load = [=](int lm) {
@@ -238,16 +239,16 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
         for (int a = 0; a < 2; a++)
             for (int e = 0; e < 2; e++) p[a][e] = below ? Bmr[bm_offset(T_, ip + a, jo + e)] : Bmr[bm_offset(T_, jo + e, ip + a)];
     };
-    // this landmark's rows of slots [s0, s0 + 4): eight independent 32-byte loads.  Dead or absent
-    // slots re-read slot 0 of the current set (always valid memory); fold_chunk skips them.
+    // this landmark's rows of slot pairs [s0, s0 + 4): eight independent 32-byte loads.  Dead or absent
+    // pairs re-read pair 0 of the current set (always valid memory); fold_chunk skips them.
     auto load_chunk = [=](int ip, bool below, int s0, int nsl, double4_t *o0, double4_t *o1) {
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            int sidx = (s0 + q < nsl && L.slot_on[s0 + q]) ? s0 + q : -1;
-            bool isprev = sidx >= 0 && sidx < n_prev;
-            int m = sidx < 0 ? 0 : (isprev ? sidx : sidx - n_prev);
+            int sidx = (s0 + q < nsl && L.pair_on[s0 + q]) ? s0 + q : -1;
+            bool isprev = sidx >= 0 && sidx < np_prev;
+            int m = sidx < 0 ? 0 : (isprev ? sidx : sidx - np_prev);
             // own rows come from the A side when this landmark supplies the row index, else from the B side
-            const double *Fown = (below ? FAb : FBb) + (isprev ? off_p : off_c) + f_offset(rows_, ip, m, 0);
+            const double *Fown = (below ? FAb : FBb) + (isprev ? off_p : off_c) + pair_offset(rows_, ip, m);
             o0[q] = *(const double4_t *)Fown;
             o1[q] = *(const double4_t *)(Fown + 4);
         }
@@ -255,13 +256,35 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
     auto fold_chunk = [=](bool below, int s0, int nsl, const double4_t *o0, const double4_t *o1, double p[2][2]) {
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            if (!(s0 + q < nsl && L.slot_on[s0 + q])) continue;
+            if (!(s0 + q < nsl && L.pair_on[s0 + q])) continue;
             const double *lr = L.lo_rows + (s0 + q) * 16 + (below ? 8 : 0);
             for (int e = 0; e < 2; e++) {
                 p[0][e] += o0[q].x * lr[e * 4] + o0[q].y * lr[e * 4 + 1] + o0[q].z * lr[e * 4 + 2] + o0[q].w * lr[e * 4 + 3];
                 p[1][e] += o1[q].x * lr[e * 4] + o1[q].y * lr[e * 4 + 1] + o1[q].z * lr[e * 4 + 2] + o1[q].w * lr[e * 4 + 3];
             }
         }
+    };
+    // One landmark's two rows of a measurement's rank-2 slot: A rows (a00 a01 / a10 a11), B rows likewise.
+    // Slots are stored in pairs (one k=4 MFMA operand): an even slot writes whole 32-byte rows and
+    // zeroes its partner's half, an odd slot fills that half.
+    auto write_slot = [=](int lm, int slot, double a00, double a01, double a10, double a11, double b00, double b01, double b10, double b11) {
+        double *fa = FAc + pair_offset(rows_, 2 * lm, slot >> 1), *fb = FBc + pair_offset(rows_, 2 * lm, slot >> 1);
+        if ((slot & 1) == 0) {
+            *(double4_t *)fa = (double4_t){a00, a01, 0, 0};
+            *(double4_t *)(fa + 4) = (double4_t){a10, a11, 0, 0};
+            *(double4_t *)fb = (double4_t){b00, b01, 0, 0};
+            *(double4_t *)(fb + 4) = (double4_t){b10, b11, 0, 0};
+        } else {
+            *(double2_t *)(fa + 2) = (double2_t){a00, a01};
+            *(double2_t *)(fa + 6) = (double2_t){a10, a11};
+            *(double2_t *)(fb + 2) = (double2_t){b00, b01};
+            *(double2_t *)(fb + 6) = (double2_t){b10, b11};
+        }
+    };
+    // a slot that changes nothing (Ignore, masked, no room) still writes zeros: its pair partner may be live
+    auto zero_slot_rows = [=](int slot) {
+        const int hi = own_hi < L.n_lm ? own_hi : L.n_lm;
+        for (int lm = lm0; lm < hi; lm += nw) write_slot(lm, slot, 0, 0, 0, 0, 0, 0, 0, 0);
     };
     // Old / compass branch for one landmark: K rows, x += K res, robot rows and own block of P, the slot.
     // p = P[rows of lm, columns of the matched landmark] (Old only).  Updates st and writes it back.
@@ -304,12 +327,8 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
         st.dxy -= sym_u(Tt[0][0], Tt[0][1], K[0][0], K[0][1], Tt[1][0], Tt[1][1], K[1][0], K[1][1]);
         st.dyy -= sym_u(Tt[1][0], Tt[1][1], K[1][0], K[1][1], Tt[1][0], Tt[1][1], K[1][0], K[1][1]);
         lm_store(lm, st);
-        // slot: P_LL += A B^T with A = -0.5 [T | K], B = [K | T]; one 64-byte line per landmark and side
-        double *fa = FAc + f_offset(rows_, 2 * lm, slot, 0), *fb = FBc + f_offset(rows_, 2 * lm, slot, 0);
-        *(double4_t *)fa = (double4_t){-0.5 * Tt[0][0], -0.5 * Tt[0][1], -0.5 * K[0][0], -0.5 * K[0][1]};
-        *(double4_t *)(fa + 4) = (double4_t){-0.5 * Tt[1][0], -0.5 * Tt[1][1], -0.5 * K[1][0], -0.5 * K[1][1]};
-        *(double4_t *)fb = (double4_t){K[0][0], K[0][1], Tt[0][0], Tt[0][1]};
-        *(double4_t *)(fb + 4) = (double4_t){K[1][0], K[1][1], Tt[1][0], Tt[1][1]};
+        // slot: P_LL -= T K^T (rank 2; K S K^T is symmetric, only one triangle is stored).  A = -T, B = K.
+        write_slot(lm, slot, -Tt[0][0], -Tt[0][1], -Tt[1][0], -Tt[1][1], K[0][0], K[0][1], K[1][0], K[1][1]);
     };
     // New branch, an existing landmark lm < ln: its slot rows carry the new covariance column pair
     auto apply_new_column = [=](int lm, const LmState &st, int slot) {
@@ -325,11 +344,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
             v[a][0] = u0 * c + u1 * (-s);
             v[a][1] = u0 * s + u1 * c;
         }
-        double *fa = FAc + f_offset(rows_, 2 * lm, slot, 0), *fb = FBc + f_offset(rows_, 2 * lm, slot, 0);
-        *(double4_t *)fa = (double4_t){v[0][0], v[0][1], 0, 0};
-        *(double4_t *)(fa + 4) = (double4_t){v[1][0], v[1][1], 0, 0};
-        *(double4_t *)fb = (double4_t){0, 0, 0, 0};
-        *(double4_t *)(fb + 4) = (double4_t){0, 0, 0, 0};
+        write_slot(lm, slot, v[0][0], v[0][1], v[1][0], v[1][1], 0, 0, 0, 0);
     };
     // New branch, the appended landmark itself: state from the header, unit B rows
     auto apply_new_self = [=](int lm, LmState &st, int slot) {
@@ -337,16 +352,17 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
         for (int i = 0; i < 6; i++) st.rc[i] = L.newrc[i];
         st.dxx = L.newdd[0], st.dxy = L.newdd[1], st.dyy = L.newdd[2];
         lm_store(lm, st);
-        double *fa = FAc + f_offset(rows_, 2 * lm, slot, 0), *fb = FBc + f_offset(rows_, 2 * lm, slot, 0);
-        *(double4_t *)fa = (double4_t){0, 0, 0, 0};
-        *(double4_t *)(fa + 4) = (double4_t){0, 0, 0, 0};
-        *(double4_t *)fb = (double4_t){1, 0, 0, 0};
-        *(double4_t *)(fb + 4) = (double4_t){0, 1, 0, 0};
+        write_slot(lm, slot, 0, 0, 0, 0, 1, 0, 0, 1);
     };
 
     // stage this filter's operation records in LDS (one trip to HBM / host memory for the whole list)
     for (int q = tid; q < nops * 8; q += bd) recs[q] = op_record(in, cursor, k0 + (q >> 3), dv.B, b)[q & 7];
-    for (int q = tid; q < n_prev + slot0; q += bd) L.slot_on[q] = q < n_prev ? act_p[q] : act_c[q - n_prev];
+    for (int q = tid; q < np_prev + ((slot0 + 1) >> 1); q += bd) {  // which pairs hold anything
+        int p = q < np_prev ? q : q - np_prev;
+        const int *act = q < np_prev ? act_p : (const int *)act_c;
+        int cnt = q < np_prev ? n_prev : slot0;
+        L.pair_on[q] = act[2 * p] | (2 * p + 1 < cnt ? act[2 * p + 1] : 0);
+    }
     if (tid == 0) {
         for (int i = 0; i < 3; i++) {
             L.pose[i] = x[i];
@@ -447,10 +463,11 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
             __syncthreads();
             if (tid == 0) {
                 if (lead) act_c[slot] = 0;
-                L.slot_on[n_prev + slot] = 0;
+                if ((slot & 1) == 0) L.pair_on[np_prev + (slot >> 1)] = 0;
                 if (rec[6] == 2.0) L.n_sweep = L.n_lm;
             }
             __syncthreads();
+            if (worker) zero_slot_rows(slot);
             slot++;
             continue;
         }
@@ -533,14 +550,14 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
             // registers) so that it arrives while the control wave does the gate arithmetic.  Unused when the
             // gate says New / Ignore.
             const int w_lo = L.gi, w_jo = 2 * w_lo;
-            const int nsl = n_prev + slot;  // slots not yet folded into Bm[buf_read]
+            const int nsl = np_prev + ((slot + 1) >> 1);  // slot pairs not yet folded into Bm[buf_read] (an odd slot's pair has a zero half)
             if (worker && w_lo != 0x7fffffff) {
                 for (int q = wtid; q < nsl * 16; q += nw) {
                     int sidx = q >> 4, side = (q >> 3) & 1, e = (q >> 2) & 1, k = q & 3;
-                    bool isprev = sidx < n_prev;
-                    int m = isprev ? sidx : sidx - n_prev;
+                    bool isprev = sidx < np_prev;
+                    int m = isprev ? sidx : sidx - np_prev;
                     const double *F = (side == 0 ? FAb : FBb) + (isprev ? off_p : off_c);
-                    L.lo_rows[q] = L.slot_on[sidx] ? F[f_offset(rows_, w_jo + e, m, k)] : 0.0;
+                    L.lo_rows[q] = L.pair_on[sidx] ? F[pair_offset(rows_, w_jo + e, m) + k] : 0.0;
                 }
                 if (lm0 < own_hi && lm0 < n_lm_before && lm0 != w_lo) {
                     spec_ok = true;
@@ -654,7 +671,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                     if (lead) st->n_ignore++;
                     L.decision = HDR_IGNORE;
                 }
-                L.slot_on[n_prev + slot] = on;
+                if (on || (slot & 1) == 0) L.pair_on[np_prev + (slot >> 1)] = on | ((slot & 1) ? L.pair_on[np_prev + (slot >> 1)] : 0);
                 if (lead) {
                     act_c[slot] = on;
                     long long cnt = dv.log_count[b];
@@ -706,7 +723,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                 L.res[0] = res, L.res[1] = 0;
                 L.HRt[0] = -1, L.HRt[1] = 0;  // unused by the compass gain
                 L.decision = HDR_COMPASS;
-                L.slot_on[n_prev + slot] = 1;
+                L.pair_on[np_prev + (slot >> 1)] = 1;
                 if (lead) act_c[slot] = 1;
             }
             __syncthreads();
@@ -731,11 +748,13 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                         apply_new_self(lm, st, slot);
                     }
                 }
-            } else if (decision == HDR_OLD || decision == HDR_COMPASS) {
+            } else if (decision != HDR_OLD && decision != HDR_COMPASS) {
+                zero_slot_rows(slot);  // Ignore / no room
+            } else {
                 const bool is_old = (decision == HDR_OLD);
                 const int n_lm = L.n_lm;
                 const int lo = L.lm;
-                const int nslots = is_old ? n_prev + slot : 0;
+                const int nslots = is_old ? np_prev + ((slot + 1) >> 1) : 0;  // pairs to fold
                 const int hi = own_hi < n_lm ? own_hi : n_lm;
                 // one landmark; `st` is either the register-resident r0 or a copy loaded from memory
                 auto gain_one = [&](int lm, LmState &st, bool use_spec) {
@@ -803,12 +822,24 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
 // upper-triangle tiles.  One wave per 64x64 tile (32 KiB read + 32 KiB written, each as 32
 // wave-contiguous 1 KiB accesses); the rank-(4 * slots) contraction runs on
 // v_mfma_f64_16x16x4_f64 with the tile as the C/D operand.
-// Only the first nslots slots of the set were filled.
+// Only the first nslots slots of the set were filled; two rank-2 slots share one k=4 operand.
 // grid (ceil(nT_hi (nT_hi+1)/2 / 4), B), 256 threads.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void k_flush(EkfDev dv, int nT_hi, int set, int nslots, int buf) {
+__global__ __launch_bounds__(256, 2) void k_flush(EkfDev dv, int nT_hi, int set, int nslots, int buf, int stagger_ticks) {
     int b = blockIdx.y;
     int lane = threadIdx.x & 63;
+    // De-phasing: the two waves that share a SIMD would otherwise run load -> MFMA -> store in lock-step
+    // (equal work, simultaneous start), leaving HBM idle while both are in their MFMA phase and the MFMA
+    // pipe idle while both wait for HBM.  In the first generation of workgroups the wave in the odd wave
+    // slot of its SIMD starts half a period late; later generations inherit the offset of the wave they
+    // replace.  stagger_ticks is in 10 ns units of s_memrealtime.
+    if (stagger_ticks > 0 && blockIdx.x < 512 && blockIdx.y == 0) {
+        unsigned slot_in_simd = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1u;  // HW_REG_HW_ID.wave_id
+        if (slot_in_simd) {
+            unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            while ((long long)(__builtin_amdgcn_s_memrealtime() - t0) < stagger_ticks) __builtin_amdgcn_s_sleep(16);
+        }
+    }
     int u = blockIdx.x * 4 + (threadIdx.x >> 6);
     int total = nT_hi * (nT_hi + 1) / 2;
     if (u >= total) return;
@@ -841,9 +872,9 @@ __global__ __launch_bounds__(256, 2) void k_flush(EkfDev dv, int nT_hi, int set,
     // the next slot are requested before the 16 MFMAs of the current one issue, and the wait in front of
     // an MFMA block covers only its own, older loads.  Past the last live slot the walk reads slot
     // `maxp`, which is all zeros by construction (adds exact zeros).
-    unsigned live = 0;
-    for (int m = 0; m < nslots; m++) live |= (active[m] ? 1u : 0u) << m;
-    const int zero_slot = dv.maxp;
+    unsigned live = 0;  // slot PAIRS with at least one live slot (a dead half holds zeros)
+    for (int m = 0; m < nslots; m++) live |= (active[m] ? 1u : 0u) << (m >> 1);
+    const int zero_slot = dv.maxpairs;
     double a0[4], b0[4], a1[4], b1[4];
     int npairs = (__builtin_popcount(live) + 1) >> 1;
     int m0 = live ? __builtin_ctz(live) : zero_slot;
@@ -926,9 +957,9 @@ __global__ __launch_bounds__(256, 6) void k_flush_q(EkfDev dv, int nT_hi, int se
             double2_t lo = *(const double2_t *)p, hi = *(const double2_t *)(p + 128);
             acc[i * 2 + j] = (double4_t){lo.x, lo.y, hi.x, hi.y};
         }
-    unsigned live = 0;
-    for (int m = 0; m < nslots; m++) live |= (active[m] ? 1u : 0u) << m;
-    const int zero_slot = dv.maxp;
+    unsigned live = 0;  // slot PAIRS with at least one live slot (a dead half holds zeros)
+    for (int m = 0; m < nslots; m++) live |= (active[m] ? 1u : 0u) << (m >> 1);
+    const int zero_slot = dv.maxpairs;
     double a0[2], b0[2], a1[2], b1[2];
     int npairs = (__builtin_popcount(live) + 1) >> 1;
     int m0 = live ? __builtin_ctz(live) : zero_slot;

@@ -1,6 +1,6 @@
 // Host-only check of the HBM index maps in ekf_device.h: bm_offset must be a bijection from the
 // stored (i', j') pairs onto [0, tiles*4096) and agree with the MFMA C/D fragment order the dense
-// pass assumes; f_offset must be a bijection onto the slot array with one landmark per 64-byte line.
+// pass assumes; pair_offset must be a bijection onto the slot array with one landmark per 64-byte line.
 #include <cstdio>
 #include <vector>
 
@@ -33,17 +33,17 @@ int main() {
                             if (bm_offset(T, row, col) != want) return printf("fragment order mismatch\n"), 1;
                         }
         }
-    const int maxp = 3, rows = 64 * T;
-    std::vector<int> fh((size_t)maxp * rows * 4, 0);
+    const int pairs = 3, rows = 64 * T;
+    std::vector<int> fh((size_t)pairs * rows * 4, 0);
     for (int i = 0; i < n; i++)
-        for (int m = 0; m < maxp; m++)
-            for (int k = 0; k < 4; k++) fh[f_offset(rows, i, m, k)]++;
+        for (int p = 0; p < pairs; p++)
+            for (int k = 0; k < 4; k++) fh[pair_offset(rows, i, p) + k]++;
     for (size_t o = 0; o < fh.size(); o++)
-        if (fh[o] != 1) return printf("f_offset %zu hit %d times\n", o, fh[o]), 1;
-    // one landmark's two rows of a slot are one 64-byte line; a 16-row block is 512 contiguous bytes
-    for (int m = 0; m < maxp; m++)
+        if (fh[o] != 1) return printf("pair_offset %zu hit %d times\n", o, fh[o]), 1;
+    // one landmark's two rows of a slot pair are one 64-byte line; a 16-row block is 512 contiguous bytes
+    for (int p = 0; p < pairs; p++)
         for (int i = 0; i < n; i += 2)
-            if (f_offset(rows, i + 1, m, 3) - f_offset(rows, i, m, 0) != 7 || (f_offset(rows, i, m, 0) % 8) != 0) return printf("landmark line mismatch\n"), 1;
+            if (pair_offset(rows, i + 1, p) - pair_offset(rows, i, p) != 4 || (pair_offset(rows, i, p) % 8) != 0) return printf("landmark line mismatch\n"), 1;
     printf("layout ok\n");
     return 0;
 }
