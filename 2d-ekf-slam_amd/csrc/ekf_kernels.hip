@@ -69,13 +69,17 @@ struct ChainLds {
 // Diagnostic build (-DEKF_CHAIN_STAMPS): workgroup 0's thread 0 adds the 100 MHz wall-clock ticks each
 // segment of a measurement takes into dv.dbg[0..7]; nothing else reads that buffer.
 #ifdef EKF_CHAIN_STAMPS
-#define STAMP(slot_)                                                         \
-    do {                                                                     \
-        if (tid == 0 && g == 0 && b == 0) {                                  \
-            unsigned long long now_ = __builtin_amdgcn_s_memrealtime();      \
-            dv.dbg[slot_] += (long long)(now_ - stamp_t);                    \
-            stamp_t = now_;                                                  \
-        }                                                                    \
+// One asm statement per stamp with its own lgkmcnt(0): s_memrealtime is a scalar-memory op that returns
+// out of order with LDS reads, so a bare builtin can invalidate the compiler's counted lgkmcnt waits
+// (cdna_hip_programming.md, "In-kernel stamps").  Ticks accumulate in registers and are written once.
+#define STAMP(slot_)                                                                                  \
+    do {                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        unsigned long long now_;                                                                      \
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");             \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        stamp_acc[slot_] += (long long)(now_ - stamp_t);                                              \
+        stamp_t = now_;                                                                               \
     } while (0)
 #else
 #define STAMP(slot_) do { } while (0)
@@ -210,7 +214,9 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
     double *part = dv.part + (size_t)b * 2 * dv.gmax * 24;
     int epoch = 0;  // cross-workgroup barriers passed in this launch
 #ifdef EKF_CHAIN_STAMPS
-    unsigned long long stamp_t = __builtin_amdgcn_s_memrealtime();
+    unsigned long long stamp_t;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_t)::"memory");
+    long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     // slot arrays addressed as base + set offset: a 4-way pointer select would become a scratch table
     const double *FAb = dv.FA + (size_t)b * 2 * dv.f_stride, *FBb = dv.FB + (size_t)b * 2 * dv.f_stride;
@@ -796,6 +802,10 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
     }
 
     __syncthreads();
+#ifdef EKF_CHAIN_STAMPS
+    if (tid == 0 && g == 0 && b == 0)
+        for (int i = 0; i < 8; i++) dv.dbg[i] += stamp_acc[i];
+#endif
     if (tid == 0) {
         if (lead) {
             for (int i = 0; i < 3; i++) {
@@ -836,8 +846,14 @@ __global__ __launch_bounds__(256, 2) void k_flush(EkfDev dv, int nT_hi, int set,
     if (stagger_ticks > 0 && blockIdx.x < 512 && blockIdx.y == 0) {
         unsigned slot_in_simd = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1u;  // HW_REG_HW_ID.wave_id
         if (slot_in_simd) {
-            unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-            while ((long long)(__builtin_amdgcn_s_memrealtime() - t0) < stagger_ticks) __builtin_amdgcn_s_sleep(16);
+            // clock reads as one asm statement each, with their own lgkmcnt(0) (scalar-memory op: see STAMP)
+            unsigned long long t0, t1;
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+            for (int spin = 0; spin < 4096; spin++) {  // bounded: 4096 x 16 x 64 clocks is far beyond any stagger
+                asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+                if ((long long)(t1 - t0) >= stagger_ticks) break;
+                __builtin_amdgcn_s_sleep(16);
+            }
         }
     }
     int u = blockIdx.x * 4 + (threadIdx.x >> 6);

@@ -11,3 +11,4 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/b
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py $ARGS > $OUT/bench_write.json 2> $OUT/bench_write.err || exit 1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma -- python3 $R/bench.py $ARGS > $OUT/bench_mfma.json 2> $OUT/bench_mfma.err || echo "mfma pmc pass failed"
 find $OUT -name "*.csv" | head -20
+if grep -rqE "Memory access fault|GPU core dump" $OUT/*.err; then echo "GPU FAULT in a profiling pass"; exit 9; fi
