@@ -74,6 +74,7 @@ struct ekf_batch {
     size_t prof_used;
     long long prof_launches;
     double prof_ms;
+    EkfMirror *mirror_h;  // host view of dv.mirror
     // scratch
     std::vector<int> h_int;
 };
@@ -181,6 +182,9 @@ extern "C" int ekf_batch_create(ekf_handle *out, int batch, int capacity_landmar
     HIP_TRY(dev_alloc_zero(&dv.stats, B, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&h->cursor_d, 1, &h->device_bytes, s));
 
+    HIP_TRY(hipHostMalloc((void **)&h->mirror_h, B * sizeof(EkfMirror), hipHostMallocMapped));
+    memset(h->mirror_h, 0, B * sizeof(EkfMirror));
+    HIP_TRY(hipHostGetDevicePointer((void **)&dv.mirror, h->mirror_h, 0));
     size_t rec_bytes = B * 8 * sizeof(double);
     long ring_ops = (long)((16u << 20) / rec_bytes);
     if (ring_ops > 1024) ring_ops = 1024;
@@ -231,6 +235,7 @@ extern "C" int ekf_destroy(ekf_handle h) {
     hipFree(h->cursor_d);
     if (h->script_d) hipFree(h->script_d);
     hipHostFree(h->ring_h);
+    hipHostFree(h->mirror_h);
     for (int i = 0; i < 2; i++) hipEventDestroy(h->ring_ev[i]);
     hipEventDestroy(h->t0), hipEventDestroy(h->t1);
     for (auto e : h->prof_pool) hipEventDestroy(e);
@@ -349,11 +354,13 @@ static int ring_reserve(ekf_batch *h, int count, double **rec, int *k_out) {
     return EKF_OK;
 }
 
-static int refresh_bounds(ekf_batch *h) {  // synchronises the chain stream
-    HIP_TRY(hipMemcpyAsync(h->h_int.data(), h->dv.n_lm, sizeof(int) * h->dv.B, hipMemcpyDeviceToHost, h->s_chain));
+static int refresh_bounds(ekf_batch *h) {  // synchronises the stream, then reads the host-mapped mirror
     HIP_TRY(hipStreamSynchronize(h->s_chain));
     int mx = 0;
-    for (int b = 0; b < h->dv.B; b++) mx = h->h_int[b] > mx ? h->h_int[b] : mx;
+    for (int b = 0; b < h->dv.B; b++) {
+        h->h_int[b] = h->mirror_h[b].n_lm;
+        mx = h->h_int[b] > mx ? h->h_int[b] : mx;
+    }
     h->n_lm_hi = mx;
     return EKF_OK;
 }
@@ -486,10 +493,9 @@ extern "C" int ekf_record_truth(ekf_handle h, const double *truth) {
 extern "C" int ekf_sync(ekf_handle h) {
     if (!h) return set_error(EKF_ERR_BAD_ARG, "null handle");
     HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(hipMemcpyAsync(h->h_int.data(), h->dv.status, sizeof(int) * h->dv.B, hipMemcpyDeviceToHost, h->s_chain));
     HIP_TRY(hipStreamSynchronize(h->s_chain));
     for (int b = 0; b < h->dv.B; b++)
-        if (h->h_int[b] != 0) return set_error(h->h_int[b], "a New landmark did not fit capacity_landmarks");
+        if (h->mirror_h[b].status != 0) return set_error(h->mirror_h[b].status, "a New landmark did not fit capacity_landmarks");
     return EKF_OK;
 }
 
@@ -502,9 +508,11 @@ extern "C" int ekf_flush(ekf_handle h) {
 extern "C" int ekf_batch_get_pose(ekf_handle h, double *pose_out) {
     if (!h || !pose_out) return set_error(EKF_ERR_BAD_ARG, "null argument");
     HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(hipMemcpy2DAsync(pose_out, 3 * sizeof(double), h->dv.x, (size_t)h->dv.xs * sizeof(double), 3 * sizeof(double), h->dv.B,
-                             hipMemcpyDeviceToHost, h->s_chain));
-    return refresh_bounds(h);
+    int rc = refresh_bounds(h);
+    if (rc) return rc;
+    for (int b = 0; b < h->dv.B; b++)
+        for (int i = 0; i < 3; i++) pose_out[3 * b + i] = h->mirror_h[b].pose[i];
+    return EKF_OK;
 }
 
 extern "C" int ekf_get_pose(ekf_handle h, double pose_out[3]) {
@@ -552,22 +560,23 @@ static int fetch_decisions(ekf_batch *h, int n_z, ekf_decision *out) {
     // [batch][n_z]: the last entries of every filter's log.  Masked measurements leave no entry, so a
     // filter with fewer real entries gets zeroed records in front.
     int B = h->dv.B;
-    std::vector<long long> cnt(B);
-    HIP_TRY(hipMemcpyAsync(cnt.data(), h->dv.log_count, sizeof(long long) * B, hipMemcpyDeviceToHost, h->s_chain));
-    HIP_TRY(hipStreamSynchronize(h->s_chain));
+    int rc = refresh_bounds(h);  // synchronises
+    if (rc) return rc;
     for (int b = 0; b < B; b++) {
-        long long have = cnt[b] < n_z ? cnt[b] : n_z;
+        long long cnt = h->mirror_h[b].log_count;
+        long long have = cnt < n_z ? cnt : n_z;
         for (int j = 0; j < n_z - have; j++) {
             ekf_decision *dst = out + (size_t)b * n_z + j;
             dst->decision = 0, dst->matched = 0, dst->mahal = 0;
         }
         for (long long j = 0; j < have; j++) {
-            long long idx = cnt[b] - have + j;
+            long long idx = cnt - have + j;
             ekf_decision *dst = out + (size_t)b * n_z + (n_z - have + j);
-            HIP_TRY(hipMemcpy(dst, h->dv.log + (size_t)b * h->dv.logcap + (idx % h->dv.logcap), sizeof(ekf_decision), hipMemcpyDeviceToHost));
+            if (cnt - idx <= EKF_MIRROR_DECISIONS) *dst = h->mirror_h[b].last[idx % EKF_MIRROR_DECISIONS];  // still in the host mirror
+            else HIP_TRY(hipMemcpy(dst, h->dv.log + (size_t)b * h->dv.logcap + (idx % h->dv.logcap), sizeof(ekf_decision), hipMemcpyDeviceToHost));
         }
     }
-    return refresh_bounds(h);
+    return EKF_OK;
 }
 
 extern "C" int ekf_get_decisions(ekf_handle h, int index, ekf_decision *out, int count) {
@@ -677,7 +686,10 @@ extern "C" int ekf_broadcast_state(ekf_handle h) {
         HIP_TRY(hipMemcpyAsync(dv.n_lm_sweep + b, dv.n_lm_sweep, sizeof(int), hipMemcpyDeviceToDevice, s));
         HIP_TRY(hipMemcpyAsync(dv.n_lm_flush + 2 * (size_t)b, dv.n_lm_flush, 2 * sizeof(int), hipMemcpyDeviceToDevice, s));
         HIP_TRY(hipMemcpyAsync(dv.status + b, dv.status, sizeof(int), hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipMemcpyAsync(dv.log_count + b, dv.log_count, sizeof(long long), hipMemcpyDeviceToDevice, s));
     }
+    HIP_TRY(hipStreamSynchronize(s));
+    for (int b = 1; b < dv.B; b++) hipLaunchKernelGGL(k_set_meta, dim3(1), dim3(64), 0, s, dv, b, h->mirror_h[0].n_lm);  // also refreshes the host mirror
     return refresh_bounds(h);
 }
 

@@ -36,6 +36,18 @@ enum { OP_NOP = 0, OP_PROP = 1, OP_MEAS = 2, OP_COMPASS = 3, OP_TRUTH = 4, OP_SK
 // header decisions (internal)
 enum { HDR_NONE = 0, HDR_NEW = 1, HDR_OLD = 2, HDR_IGNORE = 3, HDR_COMPASS = 4, HDR_NEW_NOFIT = 5 };
 
+// What the host wants to see after every call (kalmanfilter.h:24-27 mirrors, sticky status, the newest
+// gate decisions), written by k_chain into host-mapped pinned memory so that an API call needs no
+// device-to-host copy: synchronise the stream, then read.
+#define EKF_MIRROR_DECISIONS 64
+struct EkfMirror {
+    double pose[3];
+    int n_lm;
+    int status;
+    long long log_count;
+    ekf_decision last[EKF_MIRROR_DECISIONS];  // entry i of the log lives at last[i % 64]
+};
+
 struct EkfDev {
     int B, Ncap;
     int xs;    // stride of x and of each R row (doubles), multiple of 64, >= 3 + 2*Ncap
@@ -61,6 +73,7 @@ struct EkfDev {
     ekf_decision *log;
     long long *log_count;
     ekf_stats *stats;
+    EkfMirror *mirror;  // [B], host-mapped
     double gamma_max, gamma_min, cond_limit;
 };
 

@@ -138,40 +138,63 @@ struct SweepBest {
     double w[16];  // res(2) S00,S01,S11 hcol(2) P_R,Li(6) D(3)
 };
 
-// one landmark of the association sweep, Update.cpp:103-148
-__device__ __forceinline__ void sweep_one(int lm, const LmState &st, double z0, double z1, const double *Rm, double c, double s,
-                                          double px, double py, const double *Prr, double cond_limit, SweepBest &best) {
-    double dp0 = st.x0 - px, dp1 = st.x1 - py;
+// What the association sweep needs of the robot block, the same for every landmark of a measurement:
+// with H_R = [-C^T | h] (Update.cpp:112-114) the term H_R P_RR H_R^T is M0 - u h^T - h u^T + pff h h^T,
+// M0 = C^T P_xy C, u = C^T p_phi.
+struct SweepConst {
+    double c, s, px, py;
+    double M0[3];  // 00, 01 (symmetrised), 11
+    double u0, u1, pff;
+    double R00, R01, R10, R11;
+};
+
+__device__ __forceinline__ SweepConst sweep_const(double c, double s, double px, double py, const double *Prr, const double *Rm) {
+    SweepConst k;
+    k.c = c, k.s = s, k.px = px, k.py = py;
+    // C^T X C for X = P_xy, C^T = [[c, s], [-s, c]]
+    double a00 = c * Prr[0] + s * Prr[3], a01 = c * Prr[1] + s * Prr[4];
+    double a10 = -s * Prr[0] + c * Prr[3], a11 = -s * Prr[1] + c * Prr[4];
+    double m00 = a00 * c + a01 * s, m01 = -a00 * s + a01 * c;
+    double m10 = a10 * c + a11 * s, m11 = -a10 * s + a11 * c;
+    k.M0[0] = m00, k.M0[1] = 0.5 * (m01 + m10), k.M0[2] = m11;
+    k.u0 = c * Prr[2] + s * Prr[5];
+    k.u1 = -s * Prr[2] + c * Prr[5];
+    k.pff = Prr[8];
+    k.R00 = Rm[0], k.R01 = Rm[1], k.R10 = Rm[2], k.R11 = Rm[3];
+    return k;
+}
+
+// one landmark of the association sweep, Update.cpp:103-148.  S (:122) is assembled from the per-
+// measurement constants above plus C^T P_xy,Li C, a_phi C and C^T P_LiLi C; same value as the
+// reference's four products up to rounding (about 50 multiply-adds instead of 140).
+__device__ __forceinline__ void sweep_one(int lm, const LmState &st, double z0, double z1, const SweepConst &k, double cond_limit,
+                                          SweepBest &best) {
+    const double c = k.c, s = k.s;
+    double dp0 = st.x0 - k.px, dp1 = st.x1 - k.py;
     // z_hat = C^T dp (:109), res = z - z_hat (:111)
     double res0 = z0 - (c * dp0 + s * dp1);
     double res1 = z1 - (-s * dp0 + c * dp1);
-    // H_R = [-C^T | -C^T J dp] (:112-114)
+    // third column of H_R = -C^T J dp (:112-114)
     double h0 = -s * dp0 + c * dp1;
     double h1 = -c * dp0 - s * dp1;
-    double HR[6] = {-c, -s, h0, s, -c, h1};
-    double HL[4] = {c, s, -s, c};  // H_Li = C^T
-    const double *A = st.rc;       // P_RLi 3x2
-    double Pll[4] = {st.dxx, st.dxy, st.dxy, st.dyy};
-    // S = H_R P_RR H_R^T + H_Li P_LiR H_R^T + H_R P_RLi H_Li^T + H_Li P_LiLi H_Li^T + R (:122)
-    double S[4];
-    for (int i = 0; i < 2; i++)
-        for (int j = 0; j < 2; j++) {
-            double t1 = 0, t2 = 0, t3 = 0, t4 = 0;
-            for (int q = 0; q < 3; q++) {
-                double hp = HR[i * 3] * Prr[q] + HR[i * 3 + 1] * Prr[3 + q] + HR[i * 3 + 2] * Prr[6 + q];
-                t1 += hp * HR[j * 3 + q];
-                double lp = HL[i * 2] * A[q * 2] + HL[i * 2 + 1] * A[q * 2 + 1];  // (H_Li P_LiR)[i][q], P_LiR = A^T
-                t2 += lp * HR[j * 3 + q];
-            }
-            for (int q = 0; q < 2; q++) {
-                double ha = HR[i * 3] * A[q] + HR[i * 3 + 1] * A[2 + q] + HR[i * 3 + 2] * A[4 + q];
-                t3 += ha * HL[j * 2 + q];
-                double lp = HL[i * 2] * Pll[q] + HL[i * 2 + 1] * Pll[2 + q];
-                t4 += lp * HL[j * 2 + q];
-            }
-            S[i * 2 + j] = (((t1 + t2) + t3) + t4) + Rm[i * 2 + j];
-        }
-    double S00 = S[0], S01 = 0.5 * (S[1] + S[2]), S11 = S[3];  // :123-124
+    const double *A = st.rc;  // P_RLi 3x2: rows x, y, phi
+    // V = C^T A_xy C, w = a_phi C
+    double b00 = c * A[0] + s * A[2], b01 = c * A[1] + s * A[3];
+    double b10 = -s * A[0] + c * A[2], b11 = -s * A[1] + c * A[3];
+    double v00 = b00 * c + b01 * s, v01 = -b00 * s + b01 * c;
+    double v10 = b10 * c + b11 * s, v11 = -b10 * s + b11 * c;
+    double w0 = A[4] * c + A[5] * s, w1 = -A[4] * s + A[5] * c;
+    // X = H_R P_RLi H_Li^T = -V + h w   (and its transpose is H_Li P_LiR H_R^T)
+    double x00 = h0 * w0 - v00, x01 = h0 * w1 - v01, x10 = h1 * w0 - v10, x11 = h1 * w1 - v11;
+    // L = C^T P_LiLi C
+    double l00 = c * st.dxx + s * st.dxy, l01 = c * st.dxy + s * st.dyy;
+    double l10 = -s * st.dxx + c * st.dxy, l11 = -s * st.dxy + c * st.dyy;
+    double q00 = l00 * c + l01 * s, q01 = -l00 * s + l01 * c;
+    double q10 = l10 * c + l11 * s, q11 = -l10 * s + l11 * c;
+    // S = H_R P_RR H_R^T + X^T + X + L + R (:122), then 0.5 (S + S^T) (:123-124)
+    double S00 = (k.M0[0] - 2.0 * k.u0 * h0 + k.pff * h0 * h0) + 2.0 * x00 + q00 + k.R00;
+    double S11 = (k.M0[2] - 2.0 * k.u1 * h1 + k.pff * h1 * h1) + 2.0 * x11 + q11 + k.R11;
+    double S01 = (k.M0[1] - k.u0 * h1 - k.u1 * h0 + k.pff * h0 * h1) + (x01 + x10) + 0.5 * (q01 + q10) + 0.5 * (k.R01 + k.R10);
     // condition number = sigma_max / sigma_min of the symmetric 2x2 (:127-128)
     double e = 0.5 * (S00 + S11), f = 0.5 * (S00 - S11);
     double q = fabs(e), r = sqrt(f * f + S01 * S01);
@@ -494,10 +517,11 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
             best.d = EKF_INF, best.lm = 0x7fffffff;
             for (int i = 0; i < 16; i++) best.w[i] = 0;
             if (worker) {
-                if (lm0 < sweep_hi) sweep_one(lm0, r0, z0, z1, Rm, c, s, px, py, Prr, dv.cond_limit, best);
+                const SweepConst kc = sweep_const(c, s, px, py, Prr, Rm);
+                if (lm0 < sweep_hi) sweep_one(lm0, r0, z0, z1, kc, dv.cond_limit, best);
                 for (int lm = lm0 + nw; lm < sweep_hi; lm += nw) {
                     LmState st = lm_load(lm);
-                    sweep_one(lm, st, z0, z1, Rm, c, s, px, py, Prr, dv.cond_limit, best);
+                    sweep_one(lm, st, z0, z1, kc, dv.cond_limit, best);
                 }
             }
             // workgroup arg-min with first-index tie-break
@@ -686,6 +710,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                     lg->matched = have ? 3 + 2 * L.gi : 0;
                     lg->mahal = mahal;
                     dv.log_count[b] = cnt + 1;
+                    dv.mirror[b].last[cnt % EKF_MIRROR_DECISIONS] = *lg;  // posted write to host memory
                 }
                 if (rec[6] == 2.0) L.n_sweep = L.n_lm;  // last measurement of the chunk
             }
@@ -815,6 +840,11 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
             dv.n_lm[b] = L.n_lm;
             dv.n_lm_sweep[b] = L.n_sweep;
             dv.n_lm_flush[(size_t)b * 2 + set] = L.n_lm;
+            EkfMirror *mr = dv.mirror + b;
+            for (int i = 0; i < 3; i++) mr->pose[i] = L.pose[i];
+            mr->n_lm = L.n_lm;
+            mr->status = dv.status[b];
+            mr->log_count = dv.log_count[b];
         }
         if (G > 1) {
             // the last workgroup of this filter to leave re-arms the barrier for the next launch
@@ -843,17 +873,14 @@ __global__ __launch_bounds__(256, 2) void k_flush(EkfDev dv, int nT_hi, int set,
     // pipe idle while both wait for HBM.  In the first generation of workgroups the wave in the odd wave
     // slot of its SIMD starts half a period late; later generations inherit the offset of the wave they
     // replace.  stagger_ticks is in 10 ns units of s_memrealtime.
-    if (stagger_ticks > 0 && blockIdx.x < 512 && blockIdx.y == 0) {
-        unsigned slot_in_simd = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1u;  // HW_REG_HW_ID.wave_id
-        if (slot_in_simd) {
-            // clock reads as one asm statement each, with their own lgkmcnt(0) (scalar-memory op: see STAMP)
-            unsigned long long t0, t1;
-            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
-            for (int spin = 0; spin < 4096; spin++) {  // bounded: 4096 x 16 x 64 clocks is far beyond any stagger
-                asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
-                if ((long long)(t1 - t0) >= stagger_ticks) break;
-                __builtin_amdgcn_s_sleep(16);
-            }
+    if (stagger_ticks > 0 && blockIdx.y == 0 && blockIdx.x >= 256 && blockIdx.x < 512) {
+        // the second workgroup dealt to each CU in the first generation
+        unsigned long long t0, t1;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+        for (int spin = 0; spin < 4096; spin++) {  // bounded: 4096 x 16 x 64 clocks is far beyond any stagger
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+            if ((long long)(t1 - t0) >= stagger_ticks) break;
+            __builtin_amdgcn_s_sleep(16);
         }
     }
     int u = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1076,6 +1103,11 @@ __global__ void k_set_meta(EkfDev dv, int b, int n_lm) {
     dv.n_lm_flush[(size_t)b * 2] = n_lm;
     dv.n_lm_flush[(size_t)b * 2 + 1] = n_lm;
     dv.status[b] = 0;
+    EkfMirror *mr = dv.mirror + b;
+    for (int i = 0; i < 3; i++) mr->pose[i] = dv.x[(size_t)b * dv.xs + i];
+    mr->n_lm = n_lm;
+    mr->status = 0;
+    mr->log_count = dv.log_count[b];
     for (int m = 0; m < 2 * dv.maxp; m++) dv.slot_active[(size_t)b * 2 * dv.maxp + m] = 0;
 }
 

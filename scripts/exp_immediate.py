@@ -7,8 +7,8 @@ import __graft_entry__ as ge
 pkg = ge.load_package()
 for N in (50, 1024, 4096):
     kf = pkg.KalmanFilter(capacity_landmarks=N)
-    x0, P0 = pkg.scenarios.injected_state(N, seed=1)
-    sc = pkg.scenarios.steady_script(x0, steps=60, M=4, seed=2, min_separation=0.5 if N < 1000 else 1.5)
+    x0, P0 = pkg.scenarios.injected_state(N, seed=1, extent=50.0 * (N / 4096.0) ** 0.5)  # constant landmark density
+    sc = pkg.scenarios.steady_script(x0, steps=60, M=4, seed=2, min_separation=1.0)
     t0 = time.perf_counter(); kf.set_state(x0, P0); t_set = time.perf_counter() - t0
     for s in range(10):
         kf.doPropagation(0.05, 300.0, 0.05 * 180 / 3.141592654)
