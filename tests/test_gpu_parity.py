@@ -290,3 +290,107 @@ def test_bad_arguments(pkg):
     with pytest.raises(pkg.EkfError):
         f.set_state(x0, P0)  # larger than capacity
     f.close()
+
+
+def lifecycle_as_script(pkg, steps, M, seed=20260001):
+    """Config-1 style lifecycle packed into the scripted form: M measurement slots per step, a validity
+    mask for the steps that saw fewer features."""
+    script = pkg.scenarios.lifecycle_script(seed=seed, steps=steps, max_feats=M)
+    ctrl = np.zeros((steps, 1, 3))
+    z = np.zeros((steps, M, 1, 2))
+    R = np.zeros((steps, M, 1, 4))
+    R[..., 0] = R[..., 3] = 1.0
+    valid = np.zeros((steps, M, 1), dtype=np.uint8)
+    for s, st in enumerate(script):
+        ctrl[s, 0] = (st["v"], st["w"], st["dt"])
+        for m, (fx, fy) in enumerate(st["feats_mm"]):
+            zz, RR = pkg.scenarios.measurement_from_feature_mm(fx, fy)
+            z[s, m, 0] = zz
+            R[s, m, 0] = RR.ravel(order="F")
+            valid[s, m, 0] = 1
+    return script, ctrl, z, R, valid
+
+
+@pytest.mark.parametrize("max_pending,graph", [(1, False), (2, True), (7, False), (16, True), (32, False)])
+def test_scripted_lifecycle_with_new_landmarks(pkg, oc, max_pending, graph):
+    """New / Old / Ignore and masked slots inside scripted (and graph-replayed) steps, every window size:
+    the slot machinery (pairs, zero halves, New-landmark slots) against the oracle."""
+    steps, M = 160, 3
+    script, ctrl, z, R, valid = lifecycle_as_script(pkg, steps, M)
+    f = pkg.FilterBatch(1, 64, max_pending=max_pending, log_capacity=1024)
+    f.script_load(ctrl, z, R, valid=valid)
+    f.script_run(0, steps, use_graph=graph)
+    f.sync()
+    x, P = np.zeros(3), np.zeros((3, 3))
+    decs = []
+    for st in script:
+        x, P = oc.propagate(x, P, st["v"], st["w"], oc.make_Q(st["v"]), st["dt"])
+        for fx, fy in st["feats_mm"]:
+            zz, RR = oc.make_measurement(fx, fy)
+            x, P, dec, mat, _ = oc.update(x, P, zz.reshape(2, 1), RR)
+            decs.append((dec[0], mat[0]))
+    g = f.decisions(0, len(decs))
+    assert [(d[0], d[1]) for d in g] == decs
+    assert {d[0] for d in decs} >= {pkg.ekfslam.NEW, pkg.ekfslam.OLD}
+    xg, Pg = f.get_state()
+    assert_state_close(xg, Pg, x, P, "window %d" % max_pending)
+    assert_bitwise_symmetric(Pg)
+    f.close()
+
+
+def test_long_chunk_spans_several_launches(pkg, oc):
+    """One doUpdate chunk of 70 measurements (more than one k_chain launch holds): Update.cpp:26's stale
+    n_lm must survive the split -- later measurements of the chunk cannot match landmarks it added."""
+    N = 30
+    x0, P0 = pkg.scenarios.injected_state(N, seed=77, extent=8.0)
+    sc = pkg.scenarios.steady_script(x0, steps=18, M=4, seed=78, min_separation=0.5)
+    zs = sc["z"].reshape(-1, 2)[:70].copy()
+    Rs = sc["R"].reshape(-1, 4)[:70].copy()
+    zs[10] = (14.0, 3.0)   # two far observations: New landmarks in the middle of the chunk ...
+    zs[40] = (14.02, 3.01)  # ... and a re-observation of the first that must be New again
+    f = pkg.FilterBatch(1, 40, max_pending=16)
+    f.set_state(x0, P0)
+    Rm = np.stack([r.reshape(2, 2, order="F") for r in Rs])
+    dec = f.update(zs.reshape(1, 70, 2), Rm.reshape(1, 70, 2, 2))[0]
+    xo, Po, deco, mato, _ = oc.update(x0, P0, zs.T, np.concatenate(list(Rm), axis=1))
+    assert [(d[0], d[1]) for d in dec] == list(zip(deco, mato))
+    assert deco[10] == oc.NEW and deco[40] == oc.NEW
+    xg, Pg = f.get_state()
+    assert_state_close(xg, Pg, xo, Po, "70-measurement chunk")
+    f.close()
+
+
+def test_decision_log_wraps(pkg):
+    kf = pkg.KalmanFilter(capacity_landmarks=8, log_capacity=16)
+    kf.doPropagation(0.1, 300.0, 0.0)
+    z, R = pkg.scenarios.measurement_from_feature_mm(2500.0, 300.0)
+    for _ in range(40):
+        kf.doUpdate(z.reshape(2, 1), R)
+    d = kf._f.decisions(0, 100)
+    assert len(d) == 16 and d[0][0] in (pkg.ekfslam.OLD, pkg.ekfslam.NEW) and all(e[0] == pkg.ekfslam.OLD for e in d[1:])
+    assert kf._f.stats()[0]["n_old"] == 39 and kf._f.stats()[0]["n_new"] == 1
+
+
+def test_small_batch_of_multi_workgroup_filters(pkg, oc):
+    """B = 2 filters of N = 600: each filter's chain is spread over several workgroups (cross-workgroup
+    arg-min barrier) while two filters share the launch."""
+    B, N = 2, 600
+    f = pkg.FilterBatch(B, N, max_pending=8)
+    xs, Ps, scs = [], [], []
+    for b in range(B):
+        x0, P0 = pkg.scenarios.injected_state(N, seed=900 + b, extent=20.0)
+        f.set_state(x0, P0, index=b)
+        xs.append(x0), Ps.append(P0)
+        scs.append(pkg.scenarios.steady_script(x0, steps=5, M=4, seed=950 + b, min_separation=1.0))
+    ctrl = np.stack([s["ctrl"] for s in scs], axis=1)
+    z = np.stack([s["z"] for s in scs], axis=2)
+    R = np.stack([s["R"] for s in scs], axis=2)
+    f.script_load(ctrl, z, R)
+    f.script_run(0, 5)
+    f.sync()
+    for b in range(B):
+        xo, Po, decs = run_oracle_script(oc, xs[b], Ps[b], scs[b], 5, 4)
+        assert [(d[0], d[1]) for d in f.decisions(b, 20)] == decs
+        xg, Pg = f.get_state(b)
+        assert_state_close(xg, Pg, xo, Po, "filter %d" % b)
+    f.close()
