@@ -7,8 +7,15 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 typedef double double2_t __attribute__((ext_vector_type(2)));
 
 template <bool IO, bool OPLOADS, bool MFMA>
-__global__ __launch_bounds__(256, 2) void k(double *Bm, const double *FA, const double *FB, int nT, int nslots, int rows, double *sink) {
+__global__ __launch_bounds__(256, 2) void k(double *Bm, const double *FA, const double *FB, int nT, int nslots, int rows, double *sink, unsigned long long *clk) {
     int lane = threadIdx.x & 63;
+    // in-kernel clock: shader-clock ticks (s_memtime) over 100 MHz wall ticks (s_memrealtime) for one mid-grid wave
+    const bool probe = (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0);
+    unsigned long long c0 = 0, r0 = 0;
+    if (probe) {
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(c0)::"memory");
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r0)::"memory");
+    }
     int u = blockIdx.x * 4 + (threadIdx.x >> 6);
     int total = nT * (nT + 1) / 2;
     if (u >= total) return;
@@ -71,23 +78,35 @@ __global__ __launch_bounds__(256, 2) void k(double *Bm, const double *FA, const 
         for (int ch = 0; ch < 16; ch++) s += acc[ch].x + acc[ch].y + acc[ch].z + acc[ch].w;
         if (s == 12345.678) sink[0] = s;  // keep the accumulators alive without traffic
     }
+    if (probe) {
+        unsigned long long c1, r1;
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(c1)::"memory");
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r1)::"memory");
+        clk[0] = c1 - c0;
+        clk[1] = r1 - r0;
+    }
 }
 
 template <bool IO, bool OPLOADS, bool MFMA>
 void run(const char *label, double *Bm, double *FA, double *FB, int nT, int nslots, int rows, double *sink) {
+    static unsigned long long *clk = nullptr;
+    if (!clk) hipMalloc(&clk, 16);
     int total = nT * (nT + 1) / 2;
     dim3 grid((total + 3) / 4);
     hipEvent_t e0, e1;
     hipEventCreate(&e0), hipEventCreate(&e1);
-    for (int w = 0; w < 3; w++) k<IO, OPLOADS, MFMA><<<grid, 256>>>(Bm, FA, FB, nT, nslots, rows, sink);
+    for (int w = 0; w < 3; w++) k<IO, OPLOADS, MFMA><<<grid, 256>>>(Bm, FA, FB, nT, nslots, rows, sink, clk);
     hipEventRecord(e0);
     const int reps = 20;
-    for (int r = 0; r < reps; r++) k<IO, OPLOADS, MFMA><<<grid, 256>>>(Bm, FA, FB, nT, nslots, rows, sink);
+    for (int r = 0; r < reps; r++) k<IO, OPLOADS, MFMA><<<grid, 256>>>(Bm, FA, FB, nT, nslots, rows, sink, clk);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms;
     hipEventElapsedTime(&ms, e0, e1);
-    printf("  %-34s slots=%2d : %7.1f us per launch\n", label, nslots, ms * 1e3 / reps);
+    unsigned long long hc[2];
+    hipMemcpy(hc, clk, 16, hipMemcpyDeviceToHost);
+    printf("  %-34s pairs=%2d : %7.1f us per launch   probe wave: %6.2f us alive, shader clock %.2f GHz\n", label, nslots, ms * 1e3 / reps, hc[1] * 0.01,
+           hc[1] ? (double)hc[0] / (double)hc[1] * 0.1 : 0.0);
 }
 
 int main() {

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256, 2) void k_ref(double *Bm, const double *FA, co
 // same tile row (I, J0 + w); wave 3 is the loader: it streams the group's operands (A rows of I, B rows
 // of the four J) into LDS in chunks of CH pairs, double-buffered.  Compute waves only ever wait on
 // lgkmcnt inside the MFMA loop, so their next tile's global loads stay in flight under it.
-#define CH 4  // pairs per chunk: A 2 KiB + B 6 KiB per pair -> 32 KiB per chunk, two chunks in LDS
+#define CH 8  // pairs per chunk: A 2 KiB + B 6 KiB per pair -> 64 KiB per chunk, two chunks in LDS
 #define NW 3  // compute waves = tiles per group
 struct Chunk {
     double A[CH][64 * 4];      // [pair][row][k]
@@ -71,49 +71,63 @@ __device__ __forceinline__ bool group_of(const int2 *tab, int g, int ngroups, in
     return true;
 }
 
-// loader wave: one chunk = 2048 16-byte elements (A: 512, then B: 1536); all 32 loads of a lane are in
-// flight before the first LDS write
+// loader wave: one chunk = CH pairs = CH * (1 + NW) * 128 16-byte elements (A part, then B part); all the
+// loads of a lane are in flight before the first LDS write
+#define ELEMS_A (CH * 128)
+#define ELEMS (CH * (1 + NW) * 128)
 __device__ __forceinline__ void stage_chunk(Chunk *dst, const double *FA, const double *FB, size_t ss, int I, int J0, int nT, int p0, int npairs, int lane) {
-    double2_t t[32];
+    double *flat = (double *)dst;  // A then B, exactly the element order below
+    // in passes of 32 elements per lane (128 VGPRs): the compute waves' two accumulator sets share this register budget
+    for (int pass = 0; pass < ELEMS / 64 / 32; pass++) {
+        double2_t t[32];
 #pragma unroll
-    for (int i = 0; i < 32; i++) {
-        int q = lane + 64 * i;
-        const double *src;
-        if (q < 512) {
-            int p = q / 128, off = (q % 128) * 2;
-            int pp = p0 + p < npairs ? p0 + p : npairs - 1;
-            src = FA + (size_t)pp * ss + (size_t)64 * I * 4 + off;
-        } else {
-            int q2 = q - 512;
-            int p = q2 / (128 * NW), w = (q2 / 128) % NW, off = (q2 % 128) * 2;
-            int pp = p0 + p < npairs ? p0 + p : npairs - 1;
-            int J = J0 + w < nT ? J0 + w : nT - 1;
-            src = FB + (size_t)pp * ss + (size_t)64 * J * 4 + off;
+        for (int i = 0; i < 32; i++) {
+            int q = lane + 64 * (pass * 32 + i);
+            const double *src;
+            if (q < ELEMS_A) {
+                int p = q / 128, off = (q % 128) * 2;
+                int pp = p0 + p < npairs ? p0 + p : npairs - 1;
+                src = FA + (size_t)pp * ss + (size_t)64 * I * 4 + off;
+            } else {
+                int q2 = q - ELEMS_A;
+                int p = q2 / (128 * NW), w = (q2 / 128) % NW, off = (q2 % 128) * 2;
+                int pp = p0 + p < npairs ? p0 + p : npairs - 1;
+                int J = J0 + w < nT ? J0 + w : nT - 1;
+                src = FB + (size_t)pp * ss + (size_t)64 * J * 4 + off;
+            }
+            t[i] = *(const double2_t *)src;
         }
-        t[i] = *(const double2_t *)src;
-    }
-    double *flat = (double *)dst;  // A then B, exactly the element order above
 #pragma unroll
-    for (int i = 0; i < 32; i++) *(double2_t *)(flat + (size_t)(lane + 64 * i) * 2) = t[i];
+        for (int i = 0; i < 32; i++) *(double2_t *)(flat + (size_t)(lane + 64 * (pass * 32 + i)) * 2) = t[i];
+    }
+}
+
+__device__ __forceinline__ void lds_barrier() {
+    // raw barrier: __syncthreads() would add s_waitcnt vmcnt(0) and drain the tile loads in flight
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) only
+    __builtin_amdgcn_s_barrier();
 }
 
 __global__ __launch_bounds__(256, 1) void k_loader(double *Bm, const double *FA, const double *FB, int nT, int npairs, int rows, int ngroups,
                                                     int *counter, const int2 *tab) {
     extern __shared__ double lds_raw[];
     Chunk *ck = (Chunk *)lds_raw;  // two chunks
-    __shared__ int s_g[2];
+    __shared__ int s_g[4];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const size_t ss = (size_t)rows * 4;
     const int nchunks = (npairs + CH - 1) / CH;
     double4_t acc[16], nxt[16];
-    int par = 0;  // which s_g entry holds the current group
-    if (threadIdx.x == 0) s_g[0] = atomicAdd(counter, 1);
+    // groups: current g, next gn (both dequeued up front); one more is dequeued per iteration
+    if (threadIdx.x == 0) {
+        s_g[0] = atomicAdd(counter, 1);
+        s_g[1] = atomicAdd(counter, 1);
+    }
     __syncthreads();
-    int g = s_g[0];
-    int I = 0, J0 = 0;
+    int g = s_g[0], gn = s_g[1];
+    int I = 0, J0 = 0, In = 0, J0n = 0;
     bool have = group_of(tab, g, ngroups, I, J0);
-    // prologue: compute waves load their first tile
-    if (wave < NW && have && J0 + wave < nT) {
+    bool have_n = group_of(tab, gn, ngroups, In, J0n);
+    if (wave < NW && have && J0 + wave < nT) {  // first tile
         int u = I * nT - (I * (I - 1)) / 2 + (J0 + wave - I);
         const double *tp = Bm + (size_t)u * 4096 + (size_t)lane * 2;
 #pragma unroll
@@ -122,18 +136,13 @@ __global__ __launch_bounds__(256, 1) void k_loader(double *Bm, const double *FA,
             acc[ch] = (double4_t){lo.x, lo.y, hi.x, hi.y};
         }
     }
-    int buf = 0;
+    int buf = 0, slot = 2;
+    if (wave == NW && have) stage_chunk(&ck[0], FA, FB, ss, I, J0, nT, 0, npairs, lane);
+    lds_barrier();
     while (have) {
-        // next group (one dequeue per group, overlapped with everything below)
-        if (threadIdx.x == 0) s_g[par ^ 1] = atomicAdd(counter, 1);
-        // loader: chunk 0 of this group
-        if (wave == NW) stage_chunk(&ck[buf], FA, FB, ss, I, J0, nT, 0, npairs, lane);
-        __syncthreads();  // chunk 0 staged; s_g[par^1] written
-        int gn = s_g[par ^ 1];
-        int In = 0, J0n = 0;
-        bool have_n = group_of(tab, gn, ngroups, In, J0n);
+        if (threadIdx.x == 0) s_g[slot & 3] = atomicAdd(counter, 1);  // the group after next
         const bool mine = wave < NW && J0 + wave < nT;
-        // compute waves: request the next tile now; nothing below waits on vmcnt until the stores
+        // compute waves: request the next group's tile now; nothing below waits on vmcnt until the stores
         if (wave < NW && have_n && J0n + wave < nT) {
             int u = In * nT - (In * (In - 1)) / 2 + (J0n + wave - In);
             const double *tp = Bm + (size_t)u * 4096 + (size_t)lane * 2;
@@ -144,8 +153,11 @@ __global__ __launch_bounds__(256, 1) void k_loader(double *Bm, const double *FA,
             }
         }
         for (int c = 0; c < nchunks; c++) {
-            // loader: stage chunk c + 1 into the other buffer while the compute waves work on chunk c
-            if (wave == NW && c + 1 < nchunks) stage_chunk(&ck[buf ^ 1], FA, FB, ss, I, J0, nT, (c + 1) * CH, npairs, lane);
+            // loader: the chunk after this one -- of this group, or the first of the next group
+            if (wave == NW) {
+                if (c + 1 < nchunks) stage_chunk(&ck[buf ^ 1], FA, FB, ss, I, J0, nT, (c + 1) * CH, npairs, lane);
+                else if (have_n) stage_chunk(&ck[buf ^ 1], FA, FB, ss, In, J0n, nT, 0, npairs, lane);
+            }
             if (mine) {
                 int np = npairs - c * CH < CH ? npairs - c * CH : CH;
                 for (int p = 0; p < np; p++) {
@@ -161,7 +173,7 @@ __global__ __launch_bounds__(256, 1) void k_loader(double *Bm, const double *FA,
                         for (int cc = 0; cc < 4; cc++) acc[rc * 4 + cc] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[rc], b[cc], acc[rc * 4 + cc], 0, 0, 0);
                 }
             }
-            __syncthreads();  // chunk c consumed, chunk c + 1 staged
+            lds_barrier();  // chunk c consumed, the next chunk staged
             buf ^= 1;
         }
         if (mine) {
@@ -175,7 +187,10 @@ __global__ __launch_bounds__(256, 1) void k_loader(double *Bm, const double *FA,
         }
 #pragma unroll
         for (int ch = 0; ch < 16; ch++) acc[ch] = nxt[ch];
-        I = In, J0 = J0n, have = have_n, par ^= 1;
+        I = In, J0 = J0n, have = have_n;
+        int gnn = s_g[slot & 3];  // written before this iteration's first barrier
+        slot++;
+        have_n = group_of(tab, gnn, ngroups, In, J0n);
     }
 }
 
