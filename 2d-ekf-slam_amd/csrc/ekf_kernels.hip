@@ -44,6 +44,11 @@ struct ChainLds {
     double Prr[9];
     double a, b;  // Phi_R = [[1,0,a],[0,1,b],[0,0,1]]   (Propagate.cpp:42-44)
     int n_lm, n_sweep;
+    // statistics and log position of the launch, kept here so that the gate does no global read-modify-write
+    ekf_stats st;
+    long long log_count;
+    ekf_decision dec_buf[EKF_CHAIN_MAX_OPS];  // this launch's decisions, copied to the host-mapped mirror once at the end
+    int n_dec;
     // arg-min reduction
     double wd[EKF_CHAIN_MAX_THREADS / 64];
     int wi[EKF_CHAIN_MAX_THREADS / 64];
@@ -400,6 +405,11 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
         sincos(L.pose[2], &L.s, &L.c);
         L.n_lm = dv.n_lm[b];
         L.n_sweep = dv.n_lm_sweep[b];
+        if (lead) {
+            L.st = dv.stats[b];
+            L.log_count = dv.log_count[b];
+            L.n_dec = 0;
+        }
     }
     LmState r0 = {0, 0, {0, 0, 0, 0, 0, 0}, 0, 0, 0};
     if (worker && lm0 < own_hi && lm0 < dv.n_lm[b]) r0 = lm_load(lm0);
@@ -480,9 +490,8 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                 double det = a * A + bb * Bc + c * Cc;
                 double Dd = a * f - c * c, Ee = bb * c - a * e, Ff = a * d - bb * bb;
                 double q = e0 * (A * e0 + Bc * e1 + Cc * e2) + e1 * (Bc * e0 + Dd * e1 + Ee * e2) + e2 * (Cc * e0 + Ee * e1 + Ff * e2);
-                ekf_stats *st = dv.stats + b;
-                st->nees_sum += q / det;
-                st->nees_count++;
+                L.st.nees_sum += q / det;
+                L.st.nees_count++;
             }
             continue;
         }
@@ -600,7 +609,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                 const bool have = (L.gi != 0x7fffffff);
                 const double mahal = have ? L.gd : EKF_INF;
                 int decision;
-                ekf_stats *st = dv.stats + b;
+                ekf_stats *st = &L.st;  // workgroup 0 writes it back at the end of the launch
                 const int n_lm = L.n_lm;
                 int on = 0;
                 if (!have || mahal > dv.gamma_max) {  // :152
@@ -662,7 +671,8 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                     }
                     double S00 = L.w[2], S01 = L.w[3], S11 = L.w[4];
                     double det = S00 * S11 - S01 * S01;
-                    double Si[4] = {S11 / det, -S01 / det, -S01 / det, S00 / det};
+                    double idet = 1.0 / det;
+                    double Si[4] = {S11 * idet, -S01 * idet, -S01 * idet, S00 * idet};
                     double HRt[6] = {-c, s, -s, -c, L.w[5], L.w[6]};  // rows of H_R^T
                     double res0 = L.w[0], res1 = L.w[1];
                     double KR[6], TR[6];
@@ -704,13 +714,14 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                 if (on || (slot & 1) == 0) L.pair_on[np_prev + (slot >> 1)] = on | ((slot & 1) ? L.pair_on[np_prev + (slot >> 1)] : 0);
                 if (lead) {
                     act_c[slot] = on;
-                    long long cnt = dv.log_count[b];
-                    ekf_decision *lg = dv.log + (size_t)b * dv.logcap + (cnt % dv.logcap);
-                    lg->decision = decision;
-                    lg->matched = have ? 3 + 2 * L.gi : 0;
-                    lg->mahal = mahal;
-                    dv.log_count[b] = cnt + 1;
-                    dv.mirror[b].last[cnt % EKF_MIRROR_DECISIONS] = *lg;  // posted write to host memory
+                    long long cnt = L.log_count;
+                    ekf_decision e;
+                    e.decision = decision;
+                    e.matched = have ? 3 + 2 * L.gi : 0;
+                    e.mahal = mahal;
+                    dv.log[(size_t)b * dv.logcap + (cnt % dv.logcap)] = e;
+                    L.dec_buf[L.n_dec++] = e;  // the host-mapped mirror gets it at the end of the launch (a PCIe write here would sit in front of the next barrier)
+                    L.log_count = cnt + 1;
                 }
                 if (rec[6] == 2.0) L.n_sweep = L.n_lm;  // last measurement of the chunk
             }
@@ -843,8 +854,11 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
             EkfMirror *mr = dv.mirror + b;
             for (int i = 0; i < 3; i++) mr->pose[i] = L.pose[i];
             mr->n_lm = L.n_lm;
+            dv.stats[b] = L.st;
+            dv.log_count[b] = L.log_count;
+            for (int i = 0; i < L.n_dec; i++) mr->last[(L.log_count - L.n_dec + i) % EKF_MIRROR_DECISIONS] = L.dec_buf[i];
             mr->status = dv.status[b];
-            mr->log_count = dv.log_count[b];
+            mr->log_count = L.log_count;
         }
         if (G > 1) {
             // the last workgroup of this filter to leave re-arms the barrier for the next launch

@@ -394,3 +394,27 @@ def test_small_batch_of_multi_workgroup_filters(pkg, oc):
         xg, Pg = f.get_state(b)
         assert_state_close(xg, Pg, xo, Po, "filter %d" % b)
     f.close()
+
+
+def test_lifecycle_with_multi_workgroup_capacity(pkg, oc):
+    """The map grows from empty inside a filter whose capacity spreads it over several workgroups: the
+    cross-workgroup arg-min must cope with workgroups that own no landmark yet."""
+    script = pkg.scenarios.lifecycle_script(steps=150, compass_every=13)
+    kf = pkg.KalmanFilter(capacity_landmarks=1000, max_pending=5)
+    x, P = np.zeros(3), np.zeros((3, 3))
+    for st in script:
+        rot_deg = st["w"] * 180.0 / 3.141592654
+        kf.doPropagation(st["dt"], st["v"] * 1000.0, rot_deg)
+        v, w = (st["v"] * 1000.0) / 1000.0, rot_deg * 3.141592654 / 180.0
+        x, P = oc.propagate(x, P, v, w, oc.make_Q(v), st["dt"])
+        if st["compass"] is not None:
+            kf.doUpdateCompass(st["compass"], 0.0005)
+            x, P = oc.compass(x, P, st["compass"], 0.0005)
+        for fx, fy in st["feats_mm"]:
+            z, R = oc.make_measurement(fx, fy)
+            kf.doUpdate(z.reshape(2, 1), R)
+            x, P, dec, mat, _ = oc.update(x, P, z.reshape(2, 1), R)
+            assert kf.last_decisions[0][:2] == (dec[0], mat[0])
+    xg, Pg = kf.state()
+    assert_state_close(xg, Pg, x, P, "capacity 1000")
+    assert_bitwise_symmetric(Pg)
