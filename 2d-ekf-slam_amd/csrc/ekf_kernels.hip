@@ -32,6 +32,11 @@ __device__ __forceinline__ double sym_u(double ti0, double ti1, double ki0, doub
     return 0.5 * (d1 + d2);
 }
 
+// A value that is the same in every lane of the wave, moved to a scalar register: branches on it become
+// scalar branches instead of EXEC-masked regions (faster, and per-lane state of inactive lanes is never at
+// the mercy of register-allocator copies made inside a masked region).
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
 __device__ __forceinline__ bool cand_better(double da, int ia, double db, int ib) {
     // strict '>' with ascending scan order (Update.cpp:140): smaller d wins, ties -> lower index
     return (da < db) || (da == db && ia < ib);
@@ -88,6 +93,26 @@ struct ChainLds {
     } while (0)
 #else
 #define STAMP(slot_) do { } while (0)
+#endif
+
+// Diagnostic build (-DEKF_CHAIN_CHECK): every data-dependent global index of k_chain is range-checked;
+// the first violation is recorded in dv.dbg[8..11] (line, index, limit, thread) and the access is redirected
+// to element 0, so a bad index shows up as a report instead of a GPU fault.
+#ifdef EKF_CHAIN_CHECK
+__device__ __forceinline__ size_t chk_idx(long long *dbg, int line, long long idx, long long limit) {
+    if (idx < 0 || idx >= limit) {
+        if (atomicCAS((unsigned long long *)&dbg[8], 0ULL, (unsigned long long)line) == 0ULL) {
+            dbg[9] = idx;
+            dbg[10] = limit;
+            dbg[11] = (long long)blockIdx.x * 100000 + threadIdx.x;
+        }
+        return 0;
+    }
+    return (size_t)idx;
+}
+#define CK(idx, limit) chk_idx(dv_dbg, __LINE__, (long long)(idx), (long long)(limit))
+#else
+#define CK(idx, limit) ((size_t)(idx))
 #endif
 
 // Barrier over the G workgroups of one filter (MI355X_MICROARCH.md "Valid forms": every storing wave
@@ -225,7 +250,8 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
     const int tid = threadIdx.x;
     const int bd = blockDim.x;
     const bool lead = (g == 0);
-    const bool worker = tid >= 64;  // wave 0 is the control wave
+    const bool worker = uni(tid >= 64) != 0;  // wave 0 is the control wave; wave-uniform
+    const bool ctrl = !worker && (tid == 0);  // the one lane that runs the serial robot-block arithmetic
     const int wtid = tid - 64, nw = bd - 64;
     const int xs = dv.xs;
     const int own_lo = g * dv.lpw, own_hi = own_lo + dv.lpw;  // landmarks this workgroup owns
@@ -250,39 +276,43 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
     const double *FAb = dv.FA + (size_t)b * 2 * dv.f_stride, *FBb = dv.FB + (size_t)b * 2 * dv.f_stride;
     const size_t off_c = (size_t)set * dv.f_stride, off_p = (size_t)(set ^ 1) * dv.f_stride;
     const int np_prev = (n_prev + 1) >> 1;  // slot pairs of the set a dense pass is consuming
+    long long *const dv_dbg = dv.dbg;
+    (void)dv_dbg;
+    const long long lim_x = xs, lim_R = 3LL * xs, lim_D = 3LL * dv.dn, lim_B = (long long)dv.bm_stride, lim_F = 2LL * (long long)dv.f_stride;
+    (void)lim_x, (void)lim_R, (void)lim_D, (void)lim_B, (void)lim_F;
     const int T_ = dv.T, rows_ = dv.rows, dn_ = dv.dn;  // by-value captures: a reference to dv would push the kernel arguments to scratch
 
     auto lm_load = [=](int lm) {
         LmState st;
         int Li = 3 + 2 * lm;
-        st.x0 = x[Li], st.x1 = x[Li + 1];
-        for (int i = 0; i < 3; i++) st.rc[i * 2] = R0[(size_t)i * xs + Li], st.rc[i * 2 + 1] = R0[(size_t)i * xs + Li + 1];
-        st.dxx = Dx[lm], st.dxy = Dx[dn_ + lm], st.dyy = Dx[2 * (size_t)dn_ + lm];
+        st.x0 = x[CK(Li, lim_x)], st.x1 = x[CK(Li + 1, lim_x)];
+        for (int i = 0; i < 3; i++) st.rc[i * 2] = R0[CK((size_t)i * xs + Li, lim_R)], st.rc[i * 2 + 1] = R0[CK((size_t)i * xs + Li + 1, lim_R)];
+        st.dxx = Dx[CK(lm, lim_D)], st.dxy = Dx[CK(dn_ + lm, lim_D)], st.dyy = Dx[CK(2 * (size_t)dn_ + lm, lim_D)];
         return st;
     };
     auto lm_store = [=](int lm, const LmState &st) {
         int Li = 3 + 2 * lm;
-        x[Li] = st.x0, x[Li + 1] = st.x1;
-        for (int i = 0; i < 3; i++) R0[(size_t)i * xs + Li] = st.rc[i * 2], R0[(size_t)i * xs + Li + 1] = st.rc[i * 2 + 1];
-        Dx[lm] = st.dxx, Dx[dn_ + lm] = st.dxy, Dx[2 * (size_t)dn_ + lm] = st.dyy;
+        x[CK(Li, lim_x)] = st.x0, x[CK(Li + 1, lim_x)] = st.x1;
+        for (int i = 0; i < 3; i++) R0[CK((size_t)i * xs + Li, lim_R)] = st.rc[i * 2], R0[CK((size_t)i * xs + Li + 1, lim_R)] = st.rc[i * 2 + 1];
+        Dx[CK(lm, lim_D)] = st.dxx, Dx[CK(dn_ + lm, lim_D)] = st.dxy, Dx[CK(2 * (size_t)dn_ + lm, lim_D)] = st.dyy;
     };
     // P[rows of lm, columns of lo] as stored in Bm[buf_read] (row index = the older landmark)
     auto load_old_inputs = [=](int lm, int lo, double p[2][2]) {
         const bool below = lm < lo;
         const int ip = 2 * lm, jo = 2 * lo;
         for (int a = 0; a < 2; a++)
-            for (int e = 0; e < 2; e++) p[a][e] = below ? Bmr[bm_offset(T_, ip + a, jo + e)] : Bmr[bm_offset(T_, jo + e, ip + a)];
+            for (int e = 0; e < 2; e++) p[a][e] = below ? Bmr[CK(bm_offset(T_, ip + a, jo + e), lim_B)] : Bmr[CK(bm_offset(T_, jo + e, ip + a), lim_B)];
     };
     // this landmark's rows of slot pairs [s0, s0 + 4): eight independent 32-byte loads.  Dead or absent
     // pairs re-read pair 0 of the current set (always valid memory); fold_chunk skips them.
     auto load_chunk = [=](int ip, bool below, int s0, int nsl, double4_t *o0, double4_t *o1) {
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            int sidx = (s0 + q < nsl && L.pair_on[s0 + q]) ? s0 + q : -1;
+            int sidx = (s0 + q < nsl && uni(L.pair_on[s0 + q])) ? s0 + q : -1;
             bool isprev = sidx >= 0 && sidx < np_prev;
             int m = sidx < 0 ? 0 : (isprev ? sidx : sidx - np_prev);
             // own rows come from the A side when this landmark supplies the row index, else from the B side
-            const double *Fown = (below ? FAb : FBb) + (isprev ? off_p : off_c) + pair_offset(rows_, ip, m);
+            const double *Fown = (below ? FAb : FBb) + CK((isprev ? off_p : off_c) + pair_offset(rows_, ip, m), lim_F - 7);
             o0[q] = *(const double4_t *)Fown;
             o1[q] = *(const double4_t *)(Fown + 4);
         }
@@ -290,7 +320,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
     auto fold_chunk = [=](bool below, int s0, int nsl, const double4_t *o0, const double4_t *o1, double p[2][2]) {
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            if (!(s0 + q < nsl && L.pair_on[s0 + q])) continue;
+            if (!(s0 + q < nsl && uni(L.pair_on[s0 + q]))) continue;
             const double *lr = L.lo_rows + (s0 + q) * 16 + (below ? 8 : 0);
             for (int e = 0; e < 2; e++) {
                 p[0][e] += o0[q].x * lr[e * 4] + o0[q].y * lr[e * 4 + 1] + o0[q].z * lr[e * 4 + 2] + o0[q].w * lr[e * 4 + 3];
@@ -302,7 +332,8 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
     // Slots are stored in pairs (one k=4 MFMA operand): an even slot writes whole 32-byte rows and
     // zeroes its partner's half, an odd slot fills that half.
     auto write_slot = [=](int lm, int slot, double a00, double a01, double a10, double a11, double b00, double b01, double b10, double b11) {
-        double *fa = FAc + pair_offset(rows_, 2 * lm, slot >> 1), *fb = FBc + pair_offset(rows_, 2 * lm, slot >> 1);
+        const size_t wo = CK(off_c + pair_offset(rows_, 2 * lm, slot >> 1), lim_F - 7) - off_c;
+        double *fa = FAc + wo, *fb = FBc + wo;
         if ((slot & 1) == 0) {
             *(double4_t *)fa = (double4_t){a00, a01, 0, 0};
             *(double4_t *)(fa + 4) = (double4_t){a10, a11, 0, 0};
@@ -317,7 +348,8 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
     };
     // a slot that changes nothing (Ignore, masked, no room) still writes zeros: its pair partner may be live
     auto zero_slot_rows = [=](int slot) {
-        const int hi = own_hi < L.n_lm ? own_hi : L.n_lm;
+        const int n_now = uni(L.n_lm);
+        const int hi = own_hi < n_now ? own_hi : n_now;
         for (int lm = lm0; lm < hi; lm += nw) write_slot(lm, slot, 0, 0, 0, 0, 0, 0, 0, 0);
     };
     // Old / compass branch for one landmark: K rows, x += K res, robot rows and own block of P, the slot.
@@ -416,9 +448,18 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
     __syncthreads();
 
     int slot = slot0;
+    // The gate decides whether the current slot's pair becomes live while the workers are still reading
+    // pair_on for this measurement (staging, prefetch, fold): the control lane therefore parks the new flag
+    // and commits it after the first workgroup barrier of the NEXT operation.  For the measurement being
+    // processed the old flag is the right one: its own slot is not folded into itself.
+    int pend_idx = -1, pend_val = 0;
+    auto commit_pair = [&]() {
+        if (pend_idx >= 0) L.pair_on[pend_idx] = pend_val;
+        pend_idx = -1;
+    };
     for (int op = 0; op < nops; op++) {
         const double *rec = recs + op * 8;
-        const int type = (int)rec[7];  // uniform over the filter's workgroups
+        const int type = uni((int)rec[7]);  // uniform over the filter's workgroups
         // inputs of the Old branch requested ahead of the gate (measurements only)
         double spec_p[2][2] = {{0, 0}, {0, 0}};
         double4_t spec_o0[4], spec_o1[4];
@@ -427,7 +468,8 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
         if (type == OP_PROP) {
             // ---- Propagate.cpp:15-75; rec = (v, w, dt, q00, q10, q01, q11) -------------------------
             __syncthreads();
-            if (tid == 0) {
+            if (!worker && tid == 0) {
+                commit_pair();
                 double v = rec[0], w = rec[1], dt = rec[2];
                 double Q[4] = {rec[3], rec[5], rec[4], rec[6]};  // row-major from column-major
                 double so = L.s, co = L.c;
@@ -459,7 +501,8 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
             // P_RL <- Phi_R P_RL (:56); P_LR is the same storage
             if (worker) {
                 const double a = L.a, bb = L.b;
-                const int hi = own_hi < L.n_lm ? own_hi : L.n_lm;
+                const int n_now = uni(L.n_lm);
+                const int hi = own_hi < n_now ? own_hi : n_now;
                 if (lm0 < hi) {
                     for (int e = 0; e < 2; e++) {
                         r0.rc[e] = r0.rc[e] + a * r0.rc[4 + e];
@@ -482,7 +525,8 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
         if (type == OP_TRUTH) {
             // NEES sample e^T P_RR^-1 e against rec = (x, y, phi)
             __syncthreads();
-            if (tid == 0 && lead) {
+            if (!worker && tid == 0) commit_pair();
+            if (!worker && tid == 0 && lead) {
                 double e0 = L.pose[0] - rec[0], e1 = L.pose[1] - rec[1], e2 = L.pose[2] - rec[2];
                 e2 -= 6.283185307179586 * floor((e2 + 3.141592653589793) / 6.283185307179586);
                 double a = L.Prr[0], bb = L.Prr[1], c = L.Prr[2], d = L.Prr[4], e = L.Prr[5], f = L.Prr[8];
@@ -490,8 +534,11 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                 double det = a * A + bb * Bc + c * Cc;
                 double Dd = a * f - c * c, Ee = bb * c - a * e, Ff = a * d - bb * bb;
                 double q = e0 * (A * e0 + Bc * e1 + Cc * e2) + e1 * (Bc * e0 + Dd * e1 + Ee * e2) + e2 * (Cc * e0 + Ee * e1 + Ff * e2);
-                L.st.nees_sum += q / det;
-                L.st.nees_count++;
+                double nees = q / det;
+                if (det > 0.0 && nees >= 0.0 && nees < EKF_INF) {  // a fresh filter has P_RR = 0: no sample then
+                    L.st.nees_sum += nees;
+                    L.st.nees_count++;
+                }
             }
             continue;
         }
@@ -499,7 +546,8 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
         if (type == OP_SKIP_SLOT) {
             // a masked measurement: consumes its slot, changes nothing
             __syncthreads();
-            if (tid == 0) {
+            if (!worker && tid == 0) {
+                commit_pair();
                 if (lead) act_c[slot] = 0;
                 if ((slot & 1) == 0) L.pair_on[np_prev + (slot >> 1)] = 0;
                 if (rec[6] == 2.0) L.n_sweep = L.n_lm;
@@ -518,9 +566,9 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
             const double c = L.c, s = L.s, px = L.pose[0], py = L.pose[1];
             double Prr[9];
             for (int i = 0; i < 9; i++) Prr[i] = L.Prr[i];
-            const int n_sweep = L.n_sweep;  // Update.cpp:26: fixed for the whole chunk
+            const int n_sweep = uni(L.n_sweep);  // Update.cpp:26: fixed for the whole chunk
             const int sweep_hi = own_hi < n_sweep ? own_hi : n_sweep;
-            const int n_lm_before = L.n_lm;
+            const int n_lm_before = uni(L.n_lm);
 
             SweepBest best;
             best.d = EKF_INF, best.lm = 0x7fffffff;
@@ -552,7 +600,10 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                 if (cand_better(L.wd[wv], L.wi[wv], gd, gi)) gd = L.wd[wv], gi = L.wi[wv];
             if (gi != 0x7fffffff && gi == best.lm)  // this thread owns the workgroup's winner
                 for (int i = 0; i < 16; i++) L.w[i] = best.w[i];
-            if (tid == 0) L.gd = gd, L.gi = gi;
+            if (!worker && tid == 0) {
+                L.gd = gd, L.gi = gi;
+                commit_pair();  // every worker has left the previous operation's landmark part
+            }
             __syncthreads();  // (2)
             STAMP(1);  // sweep + workgroup arg-min
             if (G > 1) {
@@ -588,7 +639,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
             // need (the matched landmark's slot rows into LDS, their own P_LL entries and slot rows into
             // registers) so that it arrives while the control wave does the gate arithmetic.  Unused when the
             // gate says New / Ignore.
-            const int w_lo = L.gi, w_jo = 2 * w_lo;
+            const int w_lo = uni(L.gi), w_jo = 2 * w_lo;
             const int nsl = np_prev + ((slot + 1) >> 1);  // slot pairs not yet folded into Bm[buf_read] (an odd slot's pair has a zero half)
             if (worker && w_lo != 0x7fffffff) {
                 for (int q = wtid; q < nsl * 16; q += nw) {
@@ -596,7 +647,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                     bool isprev = sidx < np_prev;
                     int m = isprev ? sidx : sidx - np_prev;
                     const double *F = (side == 0 ? FAb : FBb) + (isprev ? off_p : off_c);
-                    L.lo_rows[q] = L.pair_on[sidx] ? F[pair_offset(rows_, w_jo + e, m) + k] : 0.0;
+                    L.lo_rows[q] = L.pair_on[sidx] ? ((side == 0 ? FAb : FBb)[CK((isprev ? off_p : off_c) + pair_offset(rows_, w_jo + e, m) + k, lim_F)]) : 0.0;
                 }
                 if (lm0 < own_hi && lm0 < n_lm_before && lm0 != w_lo) {
                     spec_ok = true;
@@ -605,7 +656,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                 }
             }
             // ---- gate + robot block, Update.cpp:152-191 ----------------------------------------------
-            if (tid == 0) {
+            if (!worker && tid == 0) {
                 const bool have = (L.gi != 0x7fffffff);
                 const double mahal = have ? L.gd : EKF_INF;
                 int decision;
@@ -711,7 +762,10 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                     if (lead) st->n_ignore++;
                     L.decision = HDR_IGNORE;
                 }
-                if (on || (slot & 1) == 0) L.pair_on[np_prev + (slot >> 1)] = on | ((slot & 1) ? L.pair_on[np_prev + (slot >> 1)] : 0);
+                if (on || (slot & 1) == 0) {
+                    pend_idx = np_prev + (slot >> 1);
+                    pend_val = on | ((slot & 1) ? L.pair_on[pend_idx] : 0);
+                }
                 if (lead) {
                     act_c[slot] = on;
                     long long cnt = L.log_count;
@@ -730,7 +784,8 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
         } else if (type == OP_COMPASS) {
             // ---- kalmanfilter.cpp:96-130; rec = (z, R) -----------------------------------------------
             __syncthreads();
-            if (tid == 0) {
+            if (!worker && tid == 0) {
+                commit_pair();
                 double z = rec[0], Rc = rec[1];
                 double z_hat = L.pose[2];
                 z_hat -= 6.283185307 * floor(z_hat / 6.283185307);  // :98-99
@@ -774,10 +829,10 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
         }
 
         // ---- landmark part of the branch taken ----------------------------------------------------------
-        const int decision = L.decision;
+        const int decision = uni(L.decision);
         if (worker) {
             if (decision == HDR_NEW) {
-                const int ln = L.lm;
+                const int ln = uni(L.lm);
                 const int hi = own_hi < ln ? own_hi : ln;
                 if (lm0 < hi) apply_new_column(lm0, r0, slot);
                 else if (lm0 == ln && lm0 < own_hi) apply_new_self(lm0, r0, slot);
@@ -794,8 +849,8 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                 zero_slot_rows(slot);  // Ignore / no room
             } else {
                 const bool is_old = (decision == HDR_OLD);
-                const int n_lm = L.n_lm;
-                const int lo = L.lm;
+                const int n_lm = uni(L.n_lm);
+                const int lo = uni(L.lm);
                 const int nslots = is_old ? np_prev + ((slot + 1) >> 1) : 0;  // pairs to fold
                 const int hi = own_hi < n_lm ? own_hi : n_lm;
                 // one landmark; `st` is either the register-resident r0 or a copy loaded from memory

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Static check of the generated gfx950 assembly for one miscompile pattern.
+
+The register allocator's live-range splitting may place its copies (v_mov / v_accvgpr_write of a
+long-lived per-lane value) at the END of a block that runs under a narrowed exec mask, right in front of
+the `s_or_b64 exec, exec, s[..]` that widens the mask again.  Lanes that were masked off then lose the
+value although they need it later (k_chain: lanes whose landmark does not exist yet wake up when a New
+landmark is appended).  Seen with hipcc 7.2 / clang 22 at -O2/-O3 with the greedy VGPR allocator; the
+build therefore uses -mllvm -vgpr-regalloc=basic (no live-range splitting), and this script fails when a
+run of >= MIN_COPIES register-to-register copies directly precedes an exec-widening instruction.
+
+usage: check_exec_split.py file.s [MIN_COPIES]
+"""
+import re
+import sys
+
+COPY = re.compile(r"^\s*(v_mov_b32_e32|v_mov_b64_e32|v_accvgpr_write_b32|v_accvgpr_mov_b32)\s+[va]\[?\d+(:\d+)?\]?, [va]\[?\d+(:\d+)?\]?\s*$")
+WIDEN = re.compile(r"^\s*s_or_b64 exec, exec, s\[\d+:\d+\]")
+
+
+def main():
+    path = sys.argv[1]
+    min_copies = int(sys.argv[2]) if len(sys.argv) > 2 else 8  # a few copies are ordinary phi moves of the region itself
+    lines = [l for l in open(path) if not re.match(r"^\s*(\.loc|;|\.Ltmp|\.cfi)", l)]
+    func, bad, run = None, [], 0
+    for i, l in enumerate(lines):
+        m = re.match(r"^(_Z\w+):", l)
+        if m:
+            func, run = m.group(1), 0
+            continue
+        if COPY.match(l):
+            run += 1
+            continue
+        if WIDEN.match(l) and run >= min_copies:
+            bad.append((func, i + 1, run))
+        run = 0
+    for f, ln, n in bad:
+        print("%s: %d register copies directly before an exec-widening s_or_b64 (line %d of the filtered listing)" % (f, n, ln))
+    print("%s: %d suspicious site(s)" % (path, len(bad)))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
