@@ -45,6 +45,7 @@ struct ekf_batch {
     int device;
     hipStream_t s_chain;  // the one stream: chain kernels and dense passes alternate on it
     int chain_wgs;        // k_chain workgroups per filter
+    size_t chain_lds;     // dynamic LDS of a k_chain launch: the own-row cache
     size_t device_bytes;
     int chain_threads;
     // host-side tracking
@@ -135,20 +136,24 @@ extern "C" int ekf_batch_create(ekf_handle *out, int batch, int capacity_landmar
     dv.T = (2 * capacity_landmarks + 63) / 64;
     dv.xs = ((3 + 64 * dv.T) + 63) / 64 * 64;
     dv.dn = 32 * dv.T;
-    dv.maxp = h->params.max_pending;
     dv.logcap = h->params.log_capacity;
     dv.bm_stride = (size_t)dv.T * (dv.T + 1) / 2 * 4096;
     dv.rows = 64 * dv.T;
-    dv.maxpairs = (dv.maxp + 1) / 2;
-    dv.f_stride = (size_t)(dv.maxpairs + 1) * dv.rows * 4;
     dv.gamma_max = h->params.gamma_max;
     dv.gamma_min = h->params.gamma_min;
     dv.cond_limit = h->params.cond_limit;
-    // k_chain geometry: about one landmark per thread, at most 32 workgroups per filter, and few
+    // k_chain geometry.  About one landmark per worker thread, at most 32 workgroups per filter, and few
     // enough workgroups in total (<= 256) that all of them are resident at once: the cross-workgroup
-    // barrier needs every workgroup of a filter running
+    // barrier needs every workgroup of a filter running.  Every workgroup keeps its landmarks' rows of every
+    // slot of the open window in LDS (64 bytes per landmark and slot), so landmarks-per-workgroup x window
+    // must fit the CU's LDS next to the kernel's static 12 KB: more workgroups first, then a shorter window.
     const int max_workers = EKF_CHAIN_MAX_THREADS - 64;
+    const long lds_budget = (long)prop.sharedMemPerBlock - 12288;
+    if (lds_budget < 64 * 64) return set_error(EKF_ERR_NO_DEVICE, "device reports too little LDS per workgroup");
+    int maxp = h->params.max_pending;
     int G = (capacity_landmarks + max_workers - 1) / max_workers;
+    int G_lds = (int)(((long)capacity_landmarks * maxp * 64 + lds_budget - 1) / lds_budget);
+    if (G_lds > G) G = G_lds;
     if (G > EKF_CHAIN_MAX_WGS) G = EKF_CHAIN_MAX_WGS;
     if (G * batch > 256) G = 256 / batch;
     if (G < 1) G = 1;
@@ -157,6 +162,14 @@ extern "C" int ekf_batch_create(ekf_handle *out, int batch, int capacity_landmar
     h->chain_wgs = G;
     dv.gmax = G;
     dv.lpw = (capacity_landmarks + G - 1) / G;
+    if ((long)dv.lpw * maxp * 64 > lds_budget) maxp = (int)(lds_budget / ((long)dv.lpw * 64));
+    if (maxp < 1) return set_error(EKF_ERR_BAD_ARG, "capacity too large for this batch size (one window slot does not fit LDS)");
+    h->params.max_pending = maxp;  // the effective window, see ekf_window()
+    dv.maxp = maxp;
+    dv.maxpairs = (dv.maxp + 1) / 2;
+    dv.f_stride = (size_t)(dv.maxpairs + 1) * dv.rows * 4;
+    h->chain_lds = (size_t)dv.lpw * maxp * 64;
+    HIP_TRY(hipFuncSetAttribute((const void *)k_chain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_budget));  // one setting for every handle
     int workers = (dv.lpw + 63) / 64 * 64;
     if (workers > max_workers) workers = max_workers;
     h->chain_threads = 64 + workers;  // wave 0 is the control wave
@@ -175,7 +188,7 @@ extern "C" int ekf_batch_create(ekf_handle *out, int batch, int capacity_landmar
     HIP_TRY(dev_alloc_zero(&dv.status, B, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.slot_active, B * 2 * dv.maxp, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.bar, B * 2, &h->device_bytes, s));
-    HIP_TRY(dev_alloc_zero(&dv.dbg, 16, &h->device_bytes, s));
+    HIP_TRY(dev_alloc_zero(&dv.dbg, 32, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.part, B * 2 * dv.gmax * 24, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.log, B * dv.logcap, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.log_count, B, &h->device_bytes, s));
@@ -245,6 +258,8 @@ extern "C" int ekf_destroy(ekf_handle h) {
 }
 
 extern "C" int ekf_batch_size(ekf_handle h) { return h ? h->dv.B : EKF_ERR_BAD_ARG; }
+extern "C" int ekf_window(ekf_handle h) { return h ? h->dv.maxp : EKF_ERR_BAD_ARG; }
+
 extern "C" int ekf_capacity(ekf_handle h) { return h ? h->dv.Ncap : EKF_ERR_BAD_ARG; }
 extern "C" void *ekf_stream(ekf_handle h) { return h ? (void *)h->s_chain : nullptr; }
 extern "C" size_t ekf_device_bytes(ekf_handle h) { return h ? h->device_bytes : 0; }
@@ -318,8 +333,8 @@ static int launch_ops(ekf_batch *h, const double *in, const int *cursor, int k0,
             if (rc) return rc;
             continue;
         }
-        hipLaunchKernelGGL(k_chain, dim3(h->chain_wgs, h->dv.B), dim3(h->chain_threads), 0, h->s_chain, h->dv, in, cursor, k0 + start,
-                           i - start, h->pending, h->cur_set, h->buf_in, 0);
+        hipLaunchKernelGGL(k_chain, dim3(h->chain_wgs, h->dv.B), dim3(h->chain_threads), h->chain_lds, h->s_chain, h->dv, in, cursor,
+                           k0 + start, i - start, h->pending, h->cur_set, h->buf_in);
         h->pending = used;
         if (used == h->dv.maxp) {
             int rc = close_set(h);
@@ -828,8 +843,8 @@ extern "C" int ekf_debug_stamps(ekf_handle h, long long *out16, int reset) {
     if (!h || !out16) return EKF_ERR_BAD_ARG;
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->s_chain));
-    HIP_TRY(hipMemcpy(out16, h->dv.dbg, 16 * sizeof(long long), hipMemcpyDeviceToHost));
-    if (reset) HIP_TRY(hipMemset(h->dv.dbg, 0, 16 * sizeof(long long)));
+    HIP_TRY(hipMemcpy(out16, h->dv.dbg, 32 * sizeof(long long), hipMemcpyDeviceToHost));
+    if (reset) HIP_TRY(hipMemset(h->dv.dbg, 0, 32 * sizeof(long long)));
     return EKF_OK;
 }
 

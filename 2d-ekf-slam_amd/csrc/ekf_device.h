@@ -68,7 +68,7 @@ struct EkfDev {
     int *n_lm_flush;   // [B][2]: landmark count when set s was last written (sizes its dense pass)
     int *slot_active;  // [B][2][maxp]
     int *bar;          // [B][2]: cross-workgroup barrier arrivals, exit count
-    long long *dbg;    // [16] diagnostic tick counters (EKF_CHAIN_STAMPS builds)
+    long long *dbg;    // [32] diagnostics: tick counters of the control lane [0..7] and of the first worker [16..23] (EKF_CHAIN_STAMPS), first bad index [8..11] (EKF_CHAIN_CHECK)
     double *part;      // [B][2][gmax][24]: per-workgroup arg-min records, double-buffered by barrier parity
     ekf_decision *log;
     long long *log_count;

@@ -42,13 +42,17 @@ __device__ __forceinline__ bool cand_better(double da, int ia, double db, int ib
     return (da < db) || (da == db && ia < ib);
 }
 
-struct ChainLds {
-    // robot state, authoritative while the kernel runs (every workgroup of a filter holds an identical copy)
+// The robot block and the landmark counts.  Two copies live in LDS: operations read rs[cur], the control lane
+// writes the complete next state into rs[cur ^ 1] (k_chain, "the operation loop").
+struct RobotState {
     double pose[3];
     double c, s;  // cos/sin of pose[2]
     double Prr[9];
-    double a, b;  // Phi_R = [[1,0,a],[0,1,b],[0,0,1]]   (Propagate.cpp:42-44)
     int n_lm, n_sweep;
+};
+
+struct ChainLds {
+    RobotState rs[2];  // every workgroup of a filter holds an identical copy
     // statistics and log position of the launch, kept here so that the gate does no global read-modify-write
     ekf_stats st;
     long long log_count;
@@ -61,20 +65,54 @@ struct ChainLds {
     int gi;     // its landmark, 0x7fffffff when none
     // data of the winning landmark: res(2) S00,S01,S11 hcol(2) P_R,Lo(6) D(3)
     double w[16];
-    // header of the branch taken
-    int decision, lm;
-    double HRt[6];   // H_R^T, 3x2 row-major              (Update.cpp:112-114 / 163-166)
-    double Sinv[4];  // row-major
-    double S[4];     // row-major, symmetric              (Update.cpp:122-124)
-    double res[2];   //                                   (Update.cpp:111)
-    double KR[6];    // rows 0..2 of K, 3x2 row-major     (Update.cpp:186)
-    double TR[6];    // rows 0..2 of K*S
-    double invS;     // compass: 1/S                      (kalmanfilter.cpp:118)
+    // headers of the rare branches, written by the control lane before a workgroup barrier
+    double HRt[6];   // New: H_R^T at the new landmark, 3x2 row-major   (Update.cpp:163-166)
     double newx[2], newrc[6], newdd[3];  // New landmark: state, P_R,new (3x2), 2x2 block
-    // rows of the matched landmark in every not-yet-folded slot pair, [pair][side A/B][row e][k], and which pairs are live
-    double lo_rows[2 * EKF_MAX_PAIRS * 16];
-    int pair_on[2 * EKF_MAX_PAIRS];  // slot PAIRS: first those of the set a dense pass is consuming, then the set being filled
+    double KR[6], TR[6];                 // compass: rows 0..2 of K and of K*S in column 0 (kalmanfilter.cpp:118)
+    double S0, invS, res0;               // compass: S, 1/S, residual
+    // rows of the matched landmark in every slot of the set being filled, [slot][side A/B][row e][k], and which slots are live
+    double lo_rows[EKF_MAX_PENDING * 8];
+    int slot_on[EKF_MAX_PENDING];
 };
+
+// Header of the Old branch (Update.cpp:181-189): a pure function of the heading the sweep ran with and of the
+// winner record.  The control lane (robot block) and every worker (its landmarks) build it independently;
+// contraction is off so that both copies round identically.
+struct OldHdr {
+    double c, s, h0, h1;       // H_R^T rows are (-c, s), (-s, -c), (h0, h1)
+    double Si00, Si01, Si11;   // S^-1
+    double S00, S01, S11;
+    double res0, res1;
+};
+
+__device__ __forceinline__ OldHdr old_header(double c, double s, const double *w) {
+#pragma clang fp contract(off)
+    OldHdr h;
+    h.c = c, h.s = s, h.h0 = w[5], h.h1 = w[6];
+    h.S00 = w[2], h.S01 = w[3], h.S11 = w[4];
+    double det = h.S00 * h.S11 - h.S01 * h.S01;
+    double idet = 1.0 / det;
+    h.Si00 = h.S11 * idet, h.Si01 = -h.S01 * idet, h.Si11 = h.S00 * idet;
+    h.res0 = w[0], h.res1 = w[1];
+    return h;
+}
+
+// Row r (0..2) of K and of T = K S: K_r = (P_RR[r,:] H_R^T + P[r, Lo:Lo+2] H_Li^T) S^-1, Update.cpp:186
+__device__ __forceinline__ void old_robot_row(const OldHdr &h, const double *Prow, double p0, double p1, double &k0, double &k1,
+                                              double &t0, double &t1) {
+#pragma clang fp contract(off)
+    double u0 = 0, u1 = 0;
+    u0 += Prow[0] * (-h.c), u1 += Prow[0] * h.s;
+    u0 += Prow[1] * (-h.s), u1 += Prow[1] * (-h.c);
+    u0 += Prow[2] * h.h0, u1 += Prow[2] * h.h1;
+    double w0 = p0 * h.c + p1 * h.s, w1 = p0 * (-h.s) + p1 * h.c;  // H_Li^T = C
+    double s0 = u0 + w0, s1 = u1 + w1;
+    k0 = s0 * h.Si00 + s1 * h.Si01;
+    k1 = s0 * h.Si01 + s1 * h.Si11;
+    t0 = k0 * h.S00 + k1 * h.S01;
+    t1 = k0 * h.S01 + k1 * h.S11;
+}
+
 
 // Diagnostic build (-DEKF_CHAIN_STAMPS): workgroup 0's thread 0 adds the 100 MHz wall-clock ticks each
 // segment of a measurement takes into dv.dbg[0..7]; nothing else reads that buffer.
@@ -153,8 +191,10 @@ __device__ __forceinline__ void filter_barrier(int *bar, int target, int *status
 //   in/cursor/k0/nops : the operation list
 //   slot0             : first free slot of set `set`
 //   buf_read          : Bm buffer to read P_LL columns from
-//   n_prev            : > 0 when the other set has been handed to a dense pass that reads
-//                       Bm[buf_read]: its first n_prev slots are not in that buffer yet
+// Dynamic LDS: every landmark's own rows of every slot of the set being filled (64 bytes per landmark and
+// slot, component-major so that a wave reads one component of consecutive landmarks conflict-free); the fold
+// of the not-yet-flushed slots into P[own rows, matched columns] then needs no trip to memory.  The host sizes
+// lpw * maxp * 64 bytes to fit the CU's 160 KB (ekf_batch_create).
 // ---------------------------------------------------------------------------------------------
 struct LmState {  // everything the chain keeps per landmark
     double x0, x1;   // position estimate
@@ -242,9 +282,10 @@ __device__ __forceinline__ void sweep_one(int lm, const LmState &st, double z0, 
 }
 
 __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, const double *in, const int *cursor, int k0,
-                                                                int nops, int slot0, int set, int buf_read, int n_prev) {
+                                                                int nops, int slot0, int set, int buf_read) {
     __shared__ ChainLds L;
     __shared__ double recs[EKF_CHAIN_MAX_OPS * 8];
+    extern __shared__ double own_rows[];  // [slot][component 0..7 = A00 A01 A10 A11 B00 B01 B10 B11][local landmark]
     const int g = blockIdx.x, G = gridDim.x;
     const int b = blockIdx.y;
     const int tid = threadIdx.x;
@@ -263,7 +304,6 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
     double *FAc = dv.FA + ((size_t)b * 2 + set) * dv.f_stride;
     double *FBc = dv.FB + ((size_t)b * 2 + set) * dv.f_stride;
     int *act_c = dv.slot_active + ((size_t)b * 2 + set) * dv.maxp;
-    const int *act_p = dv.slot_active + ((size_t)b * 2 + (set ^ 1)) * dv.maxp;
     int *bar = dv.bar + (size_t)b * 2;
     double *part = dv.part + (size_t)b * 2 * dv.gmax * 24;
     int epoch = 0;  // cross-workgroup barriers passed in this launch
@@ -274,8 +314,8 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
 #endif
     // slot arrays addressed as base + set offset: a 4-way pointer select would become a scratch table
     const double *FAb = dv.FA + (size_t)b * 2 * dv.f_stride, *FBb = dv.FB + (size_t)b * 2 * dv.f_stride;
-    const size_t off_c = (size_t)set * dv.f_stride, off_p = (size_t)(set ^ 1) * dv.f_stride;
-    const int np_prev = (n_prev + 1) >> 1;  // slot pairs of the set a dense pass is consuming
+    const size_t off_c = (size_t)set * dv.f_stride;
+    const int lpw_ = dv.lpw;
     long long *const dv_dbg = dv.dbg;
     (void)dv_dbg;
     const long long lim_x = xs, lim_R = 3LL * xs, lim_D = 3LL * dv.dn, lim_B = (long long)dv.bm_stride, lim_F = 2LL * (long long)dv.f_stride;
@@ -303,37 +343,15 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
         for (int a = 0; a < 2; a++)
             for (int e = 0; e < 2; e++) p[a][e] = below ? Bmr[CK(bm_offset(T_, ip + a, jo + e), lim_B)] : Bmr[CK(bm_offset(T_, jo + e, ip + a), lim_B)];
     };
-    // this landmark's rows of slot pairs [s0, s0 + 4): eight independent 32-byte loads.  Dead or absent
-    // pairs re-read pair 0 of the current set (always valid memory); fold_chunk skips them.
-    auto load_chunk = [=](int ip, bool below, int s0, int nsl, double4_t *o0, double4_t *o1) {
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            int sidx = (s0 + q < nsl && uni(L.pair_on[s0 + q])) ? s0 + q : -1;
-            bool isprev = sidx >= 0 && sidx < np_prev;
-            int m = sidx < 0 ? 0 : (isprev ? sidx : sidx - np_prev);
-            // own rows come from the A side when this landmark supplies the row index, else from the B side
-            const double *Fown = (below ? FAb : FBb) + CK((isprev ? off_p : off_c) + pair_offset(rows_, ip, m), lim_F - 7);
-            o0[q] = *(const double4_t *)Fown;
-            o1[q] = *(const double4_t *)(Fown + 4);
-        }
-    };
-    auto fold_chunk = [=](bool below, int s0, int nsl, const double4_t *o0, const double4_t *o1, double p[2][2]) {
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            if (!(s0 + q < nsl && uni(L.pair_on[s0 + q]))) continue;
-            const double *lr = L.lo_rows + (s0 + q) * 16 + (below ? 8 : 0);
-            for (int e = 0; e < 2; e++) {
-                p[0][e] += o0[q].x * lr[e * 4] + o0[q].y * lr[e * 4 + 1] + o0[q].z * lr[e * 4 + 2] + o0[q].w * lr[e * 4 + 3];
-                p[1][e] += o1[q].x * lr[e * 4] + o1[q].y * lr[e * 4 + 1] + o1[q].z * lr[e * 4 + 2] + o1[q].w * lr[e * 4 + 3];
-            }
-        }
-    };
     // One landmark's two rows of a measurement's rank-2 slot: A rows (a00 a01 / a10 a11), B rows likewise.
     // Slots are stored in pairs (one k=4 MFMA operand): an even slot writes whole 32-byte rows and
     // zeroes its partner's half, an odd slot fills that half.
     auto write_slot = [=](int lm, int slot, double a00, double a01, double a10, double a11, double b00, double b01, double b10, double b11) {
         const size_t wo = CK(off_c + pair_offset(rows_, 2 * lm, slot >> 1), lim_F - 7) - off_c;
         double *fa = FAc + wo, *fb = FBc + wo;
+        double *cr = own_rows + (size_t)slot * 8 * lpw_ + (lm - own_lo);
+        cr[0] = a00, cr[lpw_] = a01, cr[2 * lpw_] = a10, cr[3 * lpw_] = a11;
+        cr[4 * lpw_] = b00, cr[5 * lpw_] = b01, cr[6 * lpw_] = b10, cr[7 * lpw_] = b11;
         if ((slot & 1) == 0) {
             *(double4_t *)fa = (double4_t){a00, a01, 0, 0};
             *(double4_t *)(fa + 4) = (double4_t){a10, a11, 0, 0};
@@ -347,47 +365,41 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
         }
     };
     // a slot that changes nothing (Ignore, masked, no room) still writes zeros: its pair partner may be live
-    auto zero_slot_rows = [=](int slot) {
-        const int n_now = uni(L.n_lm);
+    auto zero_slot_rows = [=](int slot, int n_now) {
         const int hi = own_hi < n_now ? own_hi : n_now;
-        for (int lm = lm0; lm < hi; lm += nw) write_slot(lm, slot, 0, 0, 0, 0, 0, 0, 0, 0);
+        for (int lm = lm0; lm < hi; lm += nw) write_slot(lm, slot, 0, 0, 0, 0, 0, 0, 0, 0);  // (the LDS copy is never read: slot_on = 0)
     };
-    // Old / compass branch for one landmark: K rows, x += K res, robot rows and own block of P, the slot.
-    // p = P[rows of lm, columns of the matched landmark] (Old only).  Updates st and writes it back.
-    auto apply_gain = [=](int lm, LmState &st, bool is_old, const double p[2][2], int slot) {
-        const double c = -L.HRt[0], s = L.HRt[1];  // C of the pose the header was built with: H_R^T = [-C | ...]^T
-        const double res0 = L.res[0], res1 = L.res[1];
+    // Old branch for one landmark (Update.cpp:186-188,193-194): K rows, x += K res, robot rows and own block of
+    // P, the slot.  p = P[rows of lm, columns of the matched landmark]; Prr and wv are the robot block the sweep
+    // ran on and the winner record (both in LDS, read as broadcasts).  Updates st and writes it back.
+    auto apply_old = [=](int lm, LmState &st, const double p[2][2], int slot, const OldHdr &h, const double *Prr, const double *wv) {
+        const double c = h.c, s = h.s;
+        const double HRt[6] = {-c, s, -s, -c, h.h0, h.h1};  // rows of H_R^T
         double K[2][2], Tt[2][2];
-        if (is_old) {
-            for (int a = 0; a < 2; a++) {
-                double u0 = 0, u1 = 0;
-                for (int q = 0; q < 3; q++) {  // P[i,0:3] H_R^T, Update.cpp:186
-                    double pr = st.rc[q * 2 + a];
-                    u0 += pr * L.HRt[q * 2];
-                    u1 += pr * L.HRt[q * 2 + 1];
-                }
-                double w0 = p[a][0] * c + p[a][1] * s, w1 = p[a][0] * (-s) + p[a][1] * c;  // P[i,Lo:Lo+2] H_Li^T
-                double s0 = u0 + w0, s1 = u1 + w1;
-                K[a][0] = s0 * L.Sinv[0] + s1 * L.Sinv[2];
-                K[a][1] = s0 * L.Sinv[1] + s1 * L.Sinv[3];
-                Tt[a][0] = K[a][0] * L.S[0] + K[a][1] * L.S[2];
-                Tt[a][1] = K[a][0] * L.S[1] + K[a][1] * L.S[3];
+        for (int a = 0; a < 2; a++) {
+            double u0 = 0, u1 = 0;
+            for (int q = 0; q < 3; q++) {  // P[i,0:3] H_R^T, Update.cpp:186
+                double pr = st.rc[q * 2 + a];
+                u0 += pr * HRt[q * 2];
+                u1 += pr * HRt[q * 2 + 1];
             }
-        } else {  // K = (1/S) P[:,2], kalmanfilter.cpp:118
-            for (int a = 0; a < 2; a++) {
-                K[a][0] = L.invS * st.rc[4 + a];
-                K[a][1] = 0;
-                Tt[a][0] = L.S[0] * K[a][0];
-                Tt[a][1] = 0;
-            }
+            double w0 = p[a][0] * c + p[a][1] * s, w1 = p[a][0] * (-s) + p[a][1] * c;  // P[i,Lo:Lo+2] H_Li^T
+            double s0 = u0 + w0, s1 = u1 + w1;
+            K[a][0] = s0 * h.Si00 + s1 * h.Si01;
+            K[a][1] = s0 * h.Si01 + s1 * h.Si11;
+            Tt[a][0] = K[a][0] * h.S00 + K[a][1] * h.S01;
+            Tt[a][1] = K[a][0] * h.S01 + K[a][1] * h.S11;
         }
-        // x += K res (Update.cpp:187 / kalmanfilter.cpp:121)
-        st.x0 = st.x0 + (K[0][0] * res0 + K[0][1] * res1);
-        st.x1 = st.x1 + (K[1][0] * res0 + K[1][1] * res1);
-        // robot rows of P -= sym(K S K^T)
-        for (int r = 0; r < 3; r++)
-            for (int a = 0; a < 2; a++)
-                st.rc[r * 2 + a] -= sym_u(L.TR[r * 2], L.TR[r * 2 + 1], L.KR[r * 2], L.KR[r * 2 + 1], Tt[a][0], Tt[a][1], K[a][0], K[a][1]);
+        // x += K res (Update.cpp:187)
+        st.x0 = st.x0 + (K[0][0] * h.res0 + K[0][1] * h.res1);
+        st.x1 = st.x1 + (K[1][0] * h.res0 + K[1][1] * h.res1);
+        // robot rows of P -= sym(K S K^T); the robot rows of K and K S are recomputed here exactly as the control
+        // lane computes them for P_RR (old_robot_row), so nobody waits for anybody
+        for (int r = 0; r < 3; r++) {
+            double kr0, kr1, tr0, tr1;
+            old_robot_row(h, Prr + 3 * r, wv[7 + 2 * r], wv[8 + 2 * r], kr0, kr1, tr0, tr1);
+            for (int a = 0; a < 2; a++) st.rc[r * 2 + a] -= sym_u(tr0, tr1, kr0, kr1, Tt[a][0], Tt[a][1], K[a][0], K[a][1]);
+        }
         // own 2x2 block
         st.dxx -= sym_u(Tt[0][0], Tt[0][1], K[0][0], K[0][1], Tt[0][0], Tt[0][1], K[0][0], K[0][1]);
         st.dxy -= sym_u(Tt[0][0], Tt[0][1], K[0][0], K[0][1], Tt[1][0], Tt[1][1], K[1][0], K[1][1]);
@@ -396,9 +408,26 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
         // slot: P_LL -= T K^T (rank 2; K S K^T is symmetric, only one triangle is stored).  A = -T, B = K.
         write_slot(lm, slot, -Tt[0][0], -Tt[0][1], -Tt[1][0], -Tt[1][1], K[0][0], K[0][1], K[1][0], K[1][1]);
     };
+    // compass branch for one landmark (kalmanfilter.cpp:118-124): K = (1/S) P[:,2], header from LDS
+    auto apply_compass = [=](int lm, LmState &st, int slot) {
+        const double res0 = L.res0, invS = L.invS, S0 = L.S0;
+        double K[2], Tt[2];
+        for (int a = 0; a < 2; a++) {
+            K[a] = invS * st.rc[4 + a];
+            Tt[a] = S0 * K[a];
+        }
+        st.x0 = st.x0 + (K[0] * res0 + 0.0 * 0.0);  // :121 (second column of K is zero)
+        st.x1 = st.x1 + (K[1] * res0 + 0.0 * 0.0);
+        for (int r = 0; r < 3; r++)
+            for (int a = 0; a < 2; a++) st.rc[r * 2 + a] -= sym_u(L.TR[r * 2], 0, L.KR[r * 2], 0, Tt[a], 0, K[a], 0);
+        st.dxx -= sym_u(Tt[0], 0, K[0], 0, Tt[0], 0, K[0], 0);
+        st.dxy -= sym_u(Tt[0], 0, K[0], 0, Tt[1], 0, K[1], 0);
+        st.dyy -= sym_u(Tt[1], 0, K[1], 0, Tt[1], 0, K[1], 0);
+        lm_store(lm, st);
+        write_slot(lm, slot, -Tt[0], -0.0, -Tt[1], -0.0, K[0], 0, K[1], 0);
+    };
     // New branch, an existing landmark lm < ln: its slot rows carry the new covariance column pair
-    auto apply_new_column = [=](int lm, const LmState &st, int slot) {
-        const double c = L.c, s = L.s;  // pose is unchanged by New
+    auto apply_new_column = [=](int lm, const LmState &st, int slot, double c, double s) {
         double v[2][2];
         for (int a = 0; a < 2; a++) {
             double u0 = 0, u1 = 0;
@@ -418,25 +447,38 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
         for (int i = 0; i < 6; i++) st.rc[i] = L.newrc[i];
         st.dxx = L.newdd[0], st.dxy = L.newdd[1], st.dyy = L.newdd[2];
         lm_store(lm, st);
+        for (int sl = 0; sl < slot; sl++)  // the landmark did not exist in the earlier slots of this window
+            for (int cmp = 0; cmp < 8; cmp++) own_rows[((size_t)sl * 8 + cmp) * lpw_ + (lm - own_lo)] = 0.0;
         write_slot(lm, slot, 0, 0, 0, 0, 1, 0, 0, 1);
     };
 
     // stage this filter's operation records in LDS (one trip to HBM / host memory for the whole list)
     for (int q = tid; q < nops * 8; q += bd) recs[q] = op_record(in, cursor, k0 + (q >> 3), dv.B, b)[q & 7];
-    for (int q = tid; q < np_prev + ((slot0 + 1) >> 1); q += bd) {  // which pairs hold anything
-        int p = q < np_prev ? q : q - np_prev;
-        const int *act = q < np_prev ? act_p : (const int *)act_c;
-        int cnt = q < np_prev ? n_prev : slot0;
-        L.pair_on[q] = act[2 * p] | (2 * p + 1 < cnt ? act[2 * p + 1] : 0);
+    for (int q = tid; q < slot0; q += bd) L.slot_on[q] = act_c[q];  // which slots of this set hold anything
+    if (worker) {  // slots filled by earlier launches: own rows back into LDS
+        const int n_now = dv.n_lm[b];
+        const int hi = own_hi < n_now ? own_hi : n_now;
+        for (int lm = lm0; lm < hi; lm += nw)
+            for (int sl = 0; sl < slot0; sl++) {
+                if (!act_c[sl]) continue;
+                const size_t o = CK(off_c + pair_offset(rows_, 2 * lm, sl >> 1), lim_F - 7) + (sl & 1) * 2;
+                double *cr = own_rows + (size_t)sl * 8 * lpw_ + (lm - own_lo);
+                for (int a = 0; a < 2; a++)
+                    for (int k = 0; k < 2; k++) {
+                        cr[(a * 2 + k) * lpw_] = FAb[o + a * 4 + k];
+                        cr[(4 + a * 2 + k) * lpw_] = FBb[o + a * 4 + k];
+                    }
+            }
     }
     if (tid == 0) {
+        RobotState &R = L.rs[0];
         for (int i = 0; i < 3; i++) {
-            L.pose[i] = x[i];
-            for (int j = 0; j < 3; j++) L.Prr[i * 3 + j] = R0[(size_t)i * xs + j];
+            R.pose[i] = x[i];
+            for (int j = 0; j < 3; j++) R.Prr[i * 3 + j] = R0[(size_t)i * xs + j];
         }
-        sincos(L.pose[2], &L.s, &L.c);
-        L.n_lm = dv.n_lm[b];
-        L.n_sweep = dv.n_lm_sweep[b];
+        sincos(R.pose[2], &R.s, &R.c);
+        R.n_lm = dv.n_lm[b];
+        R.n_sweep = dv.n_lm_sweep[b];
         if (lead) {
             L.st = dv.stats[b];
             L.log_count = dv.log_count[b];
@@ -447,42 +489,43 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
     if (worker && lm0 < own_hi && lm0 < dv.n_lm[b]) r0 = lm_load(lm0);
     __syncthreads();
 
+    // ---- the operation loop -------------------------------------------------------------------------------
+    // Rules that make the loop race-free:
+    //  * the robot block lives in L.rs[cur]; nobody writes it during an operation.  The control lane writes the
+    //    complete next state into L.rs[cur ^ 1]; every state-changing operation ends with ONE workgroup barrier
+    //    and then flips cur.
+    //  * slot_on[slot] of the slot being filled is written by the control lane while the workers read the flags
+    //    of the EARLIER slots only (a slot is not folded into itself).
+    //  * everything a measurement's branch needs is a pure function of (L.rs[cur], the winner record L.w, L.gd,
+    //    L.gi), so every thread evaluates the gate itself; in the Old branch the workers also rebuild the gain
+    //    header themselves and update their landmarks WHILE the control lane updates the robot block.
     int slot = slot0;
-    // The gate decides whether the current slot's pair becomes live while the workers are still reading
-    // pair_on for this measurement (staging, prefetch, fold): the control lane therefore parks the new flag
-    // and commits it after the first workgroup barrier of the NEXT operation.  For the measurement being
-    // processed the old flag is the right one: its own slot is not folded into itself.
-    int pend_idx = -1, pend_val = 0;
-    auto commit_pair = [&]() {
-        if (pend_idx >= 0) L.pair_on[pend_idx] = pend_val;
-        pend_idx = -1;
-    };
+    int cur = 0;
     for (int op = 0; op < nops; op++) {
         const double *rec = recs + op * 8;
         const int type = uni((int)rec[7]);  // uniform over the filter's workgroups
-        // inputs of the Old branch requested ahead of the gate (measurements only)
-        double spec_p[2][2] = {{0, 0}, {0, 0}};
-        double4_t spec_o0[4], spec_o1[4];
-        bool spec_ok = false;
+        const RobotState &RS = L.rs[cur];
+        RobotState &RN = L.rs[cur ^ 1];
 
         if (type == OP_PROP) {
             // ---- Propagate.cpp:15-75; rec = (v, w, dt, q00, q10, q01, q11) -------------------------
-            __syncthreads();
-            if (!worker && tid == 0) {
-                commit_pair();
-                double v = rec[0], w = rec[1], dt = rec[2];
+            const double v = rec[0], dt = rec[2];
+            const double so = RS.s, co = RS.c;
+            const double pa = -dt * v * so, pb = dt * v * co;  // Phi_R = [[1,0,pa],[0,1,pb],[0,0,1]], :42-44
+            if (ctrl) {
+                double w = rec[1];
                 double Q[4] = {rec[3], rec[5], rec[4], rec[6]};  // row-major from column-major
-                double so = L.s, co = L.c;
-                L.pose[0] = L.pose[0] + dt * (v * co);  // :33-38
-                L.pose[1] = L.pose[1] + dt * (v * so);
-                L.pose[2] = L.pose[2] + dt * w;
-                double Phi[9] = {1, 0, -dt * v * so, 0, 1, dt * v * co, 0, 0, 1};  // :42-44
-                double Gm[6] = {-dt * co, 0, -dt * so, 0, 0, -dt};                // :46-48
+                double Prr[9];
+                for (int i = 0; i < 9; i++) Prr[i] = RS.Prr[i];
+                RN.pose[0] = RS.pose[0] + dt * (v * co);  // :33-38
+                RN.pose[1] = RS.pose[1] + dt * (v * so);
+                RN.pose[2] = RS.pose[2] + dt * w;
+                double Phi[9] = {1, 0, pa, 0, 1, pb, 0, 0, 1};
+                double Gm[6] = {-dt * co, 0, -dt * so, 0, 0, -dt};  // :46-48
                 double t1[9], t2[9], GQ[6], Pn[9];
                 // (Phi * P_RR) * Phi^T + (G * Q) * G^T, :53
                 for (int i = 0; i < 3; i++)
-                    for (int j = 0; j < 3; j++)
-                        t1[i * 3 + j] = Phi[i * 3] * L.Prr[j] + Phi[i * 3 + 1] * L.Prr[3 + j] + Phi[i * 3 + 2] * L.Prr[6 + j];
+                    for (int j = 0; j < 3; j++) t1[i * 3 + j] = Phi[i * 3] * Prr[j] + Phi[i * 3 + 1] * Prr[3 + j] + Phi[i * 3 + 2] * Prr[6 + j];
                 for (int i = 0; i < 3; i++)
                     for (int j = 0; j < 3; j++)
                         t2[i * 3 + j] = t1[i * 3] * Phi[j * 3] + t1[i * 3 + 1] * Phi[j * 3 + 1] + t1[i * 3 + 2] * Phi[j * 3 + 2];
@@ -492,21 +535,18 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                     for (int j = 0; j < 3; j++) Pn[i * 3 + j] = t2[i * 3 + j] + (GQ[i * 2] * Gm[j * 2] + GQ[i * 2 + 1] * Gm[j * 2 + 1]);
                 // 0.5 (P + P^T), :66-67 (a no-op outside this block: P enters bitwise symmetric)
                 for (int i = 0; i < 3; i++)
-                    for (int j = 0; j < 3; j++) L.Prr[i * 3 + j] = 0.5 * (Pn[i * 3 + j] + Pn[j * 3 + i]);
-                L.a = Phi[2];
-                L.b = Phi[5];
-                sincos(L.pose[2], &L.s, &L.c);
+                    for (int j = 0; j < 3; j++) RN.Prr[i * 3 + j] = 0.5 * (Pn[i * 3 + j] + Pn[j * 3 + i]);
+                sincos(RN.pose[2], &RN.s, &RN.c);
+                RN.n_lm = RS.n_lm, RN.n_sweep = RS.n_sweep;
             }
-            __syncthreads();
-            // P_RL <- Phi_R P_RL (:56); P_LR is the same storage
+            // P_RL <- Phi_R P_RL (:56); P_LR is the same storage.  Needs only the OLD heading: no waiting.
             if (worker) {
-                const double a = L.a, bb = L.b;
-                const int n_now = uni(L.n_lm);
+                const int n_now = uni(RS.n_lm);
                 const int hi = own_hi < n_now ? own_hi : n_now;
                 if (lm0 < hi) {
                     for (int e = 0; e < 2; e++) {
-                        r0.rc[e] = r0.rc[e] + a * r0.rc[4 + e];
-                        r0.rc[2 + e] = r0.rc[2 + e] + bb * r0.rc[4 + e];
+                        r0.rc[e] = r0.rc[e] + pa * r0.rc[4 + e];
+                        r0.rc[2 + e] = r0.rc[2 + e] + pb * r0.rc[4 + e];
                         R0[3 + 2 * lm0 + e] = r0.rc[e];
                         R0[(size_t)xs + 3 + 2 * lm0 + e] = r0.rc[2 + e];
                     }
@@ -515,21 +555,21 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                     for (int e = 0; e < 2; e++) {
                         double *Rj = R0 + 3 + 2 * lm + e;
                         double p2 = Rj[2 * (size_t)xs];
-                        Rj[0] = Rj[0] + a * p2;
-                        Rj[xs] = Rj[xs] + bb * p2;
+                        Rj[0] = Rj[0] + pa * p2;
+                        Rj[xs] = Rj[xs] + pb * p2;
                     }
             }
+            __syncthreads();
+            cur ^= 1;
             continue;
         }
 
         if (type == OP_TRUTH) {
-            // NEES sample e^T P_RR^-1 e against rec = (x, y, phi)
-            __syncthreads();
-            if (!worker && tid == 0) commit_pair();
-            if (!worker && tid == 0 && lead) {
-                double e0 = L.pose[0] - rec[0], e1 = L.pose[1] - rec[1], e2 = L.pose[2] - rec[2];
+            // NEES sample e^T P_RR^-1 e against rec = (x, y, phi); control lane of workgroup 0 only, no barrier
+            if (ctrl && lead) {
+                double e0 = RS.pose[0] - rec[0], e1 = RS.pose[1] - rec[1], e2 = RS.pose[2] - rec[2];
                 e2 -= 6.283185307179586 * floor((e2 + 3.141592653589793) / 6.283185307179586);
-                double a = L.Prr[0], bb = L.Prr[1], c = L.Prr[2], d = L.Prr[4], e = L.Prr[5], f = L.Prr[8];
+                double a = RS.Prr[0], bb = RS.Prr[1], c = RS.Prr[2], d = RS.Prr[4], e = RS.Prr[5], f = RS.Prr[8];
                 double A = d * f - e * e, Bc = c * e - bb * f, Cc = bb * e - c * d;
                 double det = a * A + bb * Bc + c * Cc;
                 double Dd = a * f - c * c, Ee = bb * c - a * e, Ff = a * d - bb * bb;
@@ -545,15 +585,15 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
 
         if (type == OP_SKIP_SLOT) {
             // a masked measurement: consumes its slot, changes nothing
-            __syncthreads();
-            if (!worker && tid == 0) {
-                commit_pair();
+            if (ctrl) {
                 if (lead) act_c[slot] = 0;
-                if ((slot & 1) == 0) L.pair_on[np_prev + (slot >> 1)] = 0;
-                if (rec[6] == 2.0) L.n_sweep = L.n_lm;
+                L.slot_on[slot] = 0;
+                RN = RS;
+                if (rec[6] == 2.0) RN.n_sweep = RS.n_lm;
             }
+            if (worker) zero_slot_rows(slot, uni(RS.n_lm));
             __syncthreads();
-            if (worker) zero_slot_rows(slot);
+            cur ^= 1;
             slot++;
             continue;
         }
@@ -563,18 +603,17 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
             STAMP(0);  // everything since the previous measurement ended
             const double z0 = rec[0], z1 = rec[1];
             const double Rm[4] = {rec[2], rec[4], rec[3], rec[5]};  // row-major R
-            const double c = L.c, s = L.s, px = L.pose[0], py = L.pose[1];
-            double Prr[9];
-            for (int i = 0; i < 9; i++) Prr[i] = L.Prr[i];
-            const int n_sweep = uni(L.n_sweep);  // Update.cpp:26: fixed for the whole chunk
+            const int n_sweep = uni(RS.n_sweep);  // Update.cpp:26: fixed for the whole chunk
             const int sweep_hi = own_hi < n_sweep ? own_hi : n_sweep;
-            const int n_lm_before = uni(L.n_lm);
+            const int n_lm_before = uni(RS.n_lm);
 
             SweepBest best;
             best.d = EKF_INF, best.lm = 0x7fffffff;
             for (int i = 0; i < 16; i++) best.w[i] = 0;
             if (worker) {
-                const SweepConst kc = sweep_const(c, s, px, py, Prr, Rm);
+                double Prr[9];
+                for (int i = 0; i < 9; i++) Prr[i] = RS.Prr[i];
+                const SweepConst kc = sweep_const(RS.c, RS.s, RS.pose[0], RS.pose[1], Prr, Rm);
                 if (lm0 < sweep_hi) sweep_one(lm0, r0, z0, z1, kc, dv.cond_limit, best);
                 for (int lm = lm0 + nw; lm < sweep_hi; lm += nw) {
                     LmState st = lm_load(lm);
@@ -600,10 +639,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                 if (cand_better(L.wd[wv], L.wi[wv], gd, gi)) gd = L.wd[wv], gi = L.wi[wv];
             if (gi != 0x7fffffff && gi == best.lm)  // this thread owns the workgroup's winner
                 for (int i = 0; i < 16; i++) L.w[i] = best.w[i];
-            if (!worker && tid == 0) {
-                L.gd = gd, L.gi = gi;
-                commit_pair();  // every worker has left the previous operation's landmark part
-            }
+            if (ctrl) L.gd = gd, L.gi = gi;
             __syncthreads();  // (2)
             STAMP(1);  // sweep + workgroup arg-min
             if (G > 1) {
@@ -635,41 +671,119 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                 __syncthreads();
                 STAMP(3);  // pick over workgroups
             }
-            // ---- the winner is known, the gate is not yet.  Workers request everything the Old branch will
-            // need (the matched landmark's slot rows into LDS, their own P_LL entries and slot rows into
-            // registers) so that it arrives while the control wave does the gate arithmetic.  Unused when the
-            // gate says New / Ignore.
-            const int w_lo = uni(L.gi), w_jo = 2 * w_lo;
-            const int nsl = np_prev + ((slot + 1) >> 1);  // slot pairs not yet folded into Bm[buf_read] (an odd slot's pair has a zero half)
-            if (worker && w_lo != 0x7fffffff) {
-                for (int q = wtid; q < nsl * 16; q += nw) {
-                    int sidx = q >> 4, side = (q >> 3) & 1, e = (q >> 2) & 1, k = q & 3;
-                    bool isprev = sidx < np_prev;
-                    int m = isprev ? sidx : sidx - np_prev;
-                    const double *F = (side == 0 ? FAb : FBb) + (isprev ? off_p : off_c);
-                    L.lo_rows[q] = L.pair_on[sidx] ? ((side == 0 ? FAb : FBb)[CK((isprev ? off_p : off_c) + pair_offset(rows_, w_jo + e, m) + k, lim_F)]) : 0.0;
-                }
-                if (lm0 < own_hi && lm0 < n_lm_before && lm0 != w_lo) {
-                    spec_ok = true;
-                    load_old_inputs(lm0, w_lo, spec_p);
-                    if (nsl > 0) load_chunk(2 * lm0, lm0 < w_lo, 0, nsl, spec_o0, spec_o1);
+            // ---- gate, Update.cpp:152,181,191: a pure function of the winner, evaluated by every thread ----------
+            const int w_lo = uni(L.gi);
+            const bool have = (w_lo != 0x7fffffff);
+            const double mahal = have ? L.gd : EKF_INF;
+            int hdr;
+            if (!have || mahal > dv.gamma_max) hdr = (n_lm_before >= dv.Ncap) ? HDR_NEW_NOFIT : HDR_NEW;  // :152
+            else if (mahal < dv.gamma_min) hdr = HDR_OLD;                                                // :181
+            else hdr = HDR_IGNORE;                                                                         // :191
+            hdr = uni(hdr);
+            const int on = (hdr == HDR_NEW || hdr == HDR_OLD) ? 1 : 0;
+            const int n_lm_after = n_lm_before + (hdr == HDR_NEW ? 1 : 0);
+            if (ctrl) {
+                // bookkeeping common to all branches
+                L.slot_on[slot] = on;
+                if (lead) {
+                    ekf_stats *st = &L.st;  // written back at the end of the launch
+                    if (hdr == HDR_OLD) {
+                        st->n_old++;
+                        st->nis_sum += mahal;
+                        st->nis_count++;
+                    } else if (hdr == HDR_IGNORE) {
+                        st->n_ignore++;
+                    } else {
+                        st->n_new++;
+                        if (hdr == HDR_NEW_NOFIT) dv.status[b] = EKF_ERR_CAPACITY;
+                    }
+                    act_c[slot] = on;
+                    long long cnt = L.log_count;
+                    ekf_decision e;
+                    e.decision = hdr == HDR_OLD ? EKF_DECISION_OLD : (hdr == HDR_IGNORE ? EKF_DECISION_IGNORE : EKF_DECISION_NEW);
+                    e.matched = have ? 3 + 2 * w_lo : 0;
+                    e.mahal = mahal;
+                    dv.log[(size_t)b * dv.logcap + (cnt % dv.logcap)] = e;
+                    L.dec_buf[L.n_dec++] = e;  // the host-mapped mirror gets it at the end of the launch
+                    L.log_count = cnt + 1;
                 }
             }
-            // ---- gate + robot block, Update.cpp:152-191 ----------------------------------------------
-            if (!worker && tid == 0) {
-                const bool have = (L.gi != 0x7fffffff);
-                const double mahal = have ? L.gd : EKF_INF;
-                int decision;
-                ekf_stats *st = &L.st;  // workgroup 0 writes it back at the end of the launch
-                const int n_lm = L.n_lm;
-                int on = 0;
-                if (!have || mahal > dv.gamma_max) {  // :152
-                    decision = EKF_DECISION_NEW;
-                    if (lead) st->n_new++;
-                    if (n_lm >= dv.Ncap) {
-                        if (lead) dv.status[b] = EKF_ERR_CAPACITY;
-                        L.decision = HDR_NEW_NOFIT;
-                    } else {
+
+            if (hdr == HDR_OLD) {
+                // ---- Old, Update.cpp:181-189.  Workers: request the matched landmark's slot rows (into LDS) and their
+                // own P_LL entries and slot rows (into registers), barrier, fold, gain, store.  Control lane: robot block.
+                const int w_jo = 2 * w_lo;
+                const int hi = own_hi < n_lm_before ? own_hi : n_lm_before;
+                double pf_p[2][2] = {{0, 0}, {0, 0}};
+                if (worker) {
+                    if (lm0 < hi && lm0 != w_lo) load_old_inputs(lm0, w_lo, pf_p);  // in flight across the barrier
+                    for (int q = wtid; q < slot * 8; q += nw) {
+                        int sl = q >> 3, side = (q >> 2) & 1, e = (q >> 1) & 1, k = q & 1;
+                        L.lo_rows[q] = L.slot_on[sl] ? ((side == 0 ? FAb : FBb)[CK(off_c + pair_offset(rows_, w_jo + e, sl >> 1) + (sl & 1) * 2 + k, lim_F)]) : 0.0;
+                    }
+                }
+                __syncthreads();  // (3) staged rows visible
+                STAMP(4);
+                if (worker) {
+                    const OldHdr h = old_header(RS.c, RS.s, L.w);
+                    auto gain_one = [&](int lm, LmState &st, bool prefetched) {
+                        double p[2][2] = {{0, 0}, {0, 0}};
+                        if (lm == w_lo) {
+                            p[0][0] = st.dxx, p[0][1] = st.dxy, p[1][0] = st.dxy, p[1][1] = st.dyy;
+                        } else {
+                            const bool below = lm < w_lo;  // stored as (row of the older landmark, column of the newer)
+                            if (prefetched) {
+                                for (int a = 0; a < 2; a++)
+                                    for (int e = 0; e < 2; e++) p[a][e] = pf_p[a][e];
+                            } else {
+                                load_old_inputs(lm, w_lo, p);
+                            }
+                            // the slots of this set are not in Bm yet: P[lm rows, lo cols] += sum_k A_lm[.,k] B_lo[.,k] (or B_lm A_lo)
+                            const double *own = own_rows + (below ? 0 : 4 * lpw_) + (lm - own_lo);
+                            const double *lr = L.lo_rows + (below ? 4 : 0);
+                            for (int sl = 0; sl < slot; sl++) {
+                                if (!uni(L.slot_on[sl])) continue;
+                                const double *o = own + (size_t)sl * 8 * lpw_, *q = lr + sl * 8;
+                                const double o00 = o[0], o01 = o[lpw_], o10 = o[2 * lpw_], o11 = o[3 * lpw_];
+                                p[0][0] += o00 * q[0] + o01 * q[1];
+                                p[0][1] += o00 * q[2] + o01 * q[3];
+                                p[1][0] += o10 * q[0] + o11 * q[1];
+                                p[1][1] += o10 * q[2] + o11 * q[3];
+                            }
+                        }
+                        apply_old(lm, st, p, slot, h, RS.Prr, L.w);
+                    };
+                    if (lm0 < hi) gain_one(lm0, r0, true);
+                    for (int lm = lm0 + nw; lm < hi; lm += nw) {
+                        LmState stm = lm_load(lm);
+                        gain_one(lm, stm, false);
+                    }
+                } else if (tid == 0) {
+                    // robot block: x_R += K_R res (:187), P_RR -= sym(K_R S K_R^T) (:188,193-194)
+                    const OldHdr h = old_header(RS.c, RS.s, L.w);
+                    double KR[6], TR[6];
+                    for (int r = 0; r < 3; r++) old_robot_row(h, RS.Prr + 3 * r, L.w[7 + 2 * r], L.w[8 + 2 * r], KR[r * 2], KR[r * 2 + 1], TR[r * 2], TR[r * 2 + 1]);
+                    for (int r = 0; r < 3; r++) RN.pose[r] = RS.pose[r] + (KR[r * 2] * h.res0 + KR[r * 2 + 1] * h.res1);
+                    for (int r = 0; r < 3; r++)
+                        for (int q = r; q < 3; q++) {
+                            double u = sym_u(TR[r * 2], TR[r * 2 + 1], KR[r * 2], KR[r * 2 + 1], TR[q * 2], TR[q * 2 + 1], KR[q * 2], KR[q * 2 + 1]);
+                            double nv = RS.Prr[r * 3 + q] - u;
+                            RN.Prr[r * 3 + q] = nv;
+                            RN.Prr[q * 3 + r] = nv;
+                        }
+                    sincos(RN.pose[2], &RN.s, &RN.c);
+                    RN.n_lm = n_lm_before;
+                    RN.n_sweep = (rec[6] == 2.0) ? n_lm_before : n_sweep;  // last measurement of the chunk
+                }
+                STAMP(5);  // landmark part (workers) / robot block (control lane)
+            } else {
+                // ---- New (Update.cpp:152-178), Ignore (:191), no room: rare, the control lane goes first ------------
+                if (ctrl) {
+                    RN = RS;
+                    if (hdr == HDR_NEW) {
+                        const double c = RS.c, s = RS.s, px = RS.pose[0], py = RS.pose[1];
+                        double Prr[9];
+                        for (int i = 0; i < 9; i++) Prr[i] = RS.Prr[i];
                         double nl0 = px + (c * z0 - s * z1), nl1 = py + (s * z0 + c * z1);  // :155
                         double dp0 = nl0 - px, dp1 = nl1 - py;
                         double h0 = -s * dp0 + c * dp1, h1 = -c * dp0 - s * dp1;  // :166
@@ -708,86 +822,44 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                             L.HRt[q * 2 + 1] = HR[3 + q];
                         }
                         L.newx[0] = nl0, L.newx[1] = nl1;
-                        L.decision = HDR_NEW;
-                        L.lm = n_lm;
-                        L.n_lm = n_lm + 1;
-                        on = 1;
+                        RN.n_lm = n_lm_after;
                     }
-                } else if (mahal < dv.gamma_min) {  // :181
-                    decision = EKF_DECISION_OLD;
-                    if (lead) {
-                        st->n_old++;
-                        st->nis_sum += mahal;
-                        st->nis_count++;
-                    }
-                    double S00 = L.w[2], S01 = L.w[3], S11 = L.w[4];
-                    double det = S00 * S11 - S01 * S01;
-                    double idet = 1.0 / det;
-                    double Si[4] = {S11 * idet, -S01 * idet, -S01 * idet, S00 * idet};
-                    double HRt[6] = {-c, s, -s, -c, L.w[5], L.w[6]};  // rows of H_R^T
-                    double res0 = L.w[0], res1 = L.w[1];
-                    double KR[6], TR[6];
-                    for (int r = 0; r < 3; r++) {  // :186 for the robot rows
-                        double u0 = 0, u1 = 0;
-                        for (int q = 0; q < 3; q++) {
-                            u0 += Prr[r * 3 + q] * HRt[q * 2];
-                            u1 += Prr[r * 3 + q] * HRt[q * 2 + 1];
+                    if (rec[6] == 2.0) RN.n_sweep = n_lm_after;  // last measurement of the chunk
+                }
+                __syncthreads();  // (3')
+                if (worker) {
+                    if (hdr == HDR_NEW) {
+                        const int ln = n_lm_before;
+                        const double c = RS.c, s = RS.s;  // the pose is unchanged by New
+                        const int hi = own_hi < ln ? own_hi : ln;
+                        if (lm0 < hi) apply_new_column(lm0, r0, slot, c, s);
+                        else if (lm0 == ln && lm0 < own_hi) apply_new_self(lm0, r0, slot);
+                        for (int lm = lm0 + nw; lm < own_hi && lm <= ln; lm += nw) {
+                            if (lm < ln) {
+                                LmState st = lm_load(lm);
+                                apply_new_column(lm, st, slot, c, s);
+                            } else {
+                                LmState st;
+                                apply_new_self(lm, st, slot);
+                            }
                         }
-                        double p0 = L.w[7 + r * 2], p1 = L.w[8 + r * 2];
-                        double w0 = p0 * c + p1 * s, w1 = p0 * (-s) + p1 * c;  // P[:,Lo:Lo+2] H_Li^T, H_Li^T = C
-                        double s0 = u0 + w0, s1 = u1 + w1;
-                        KR[r * 2] = s0 * Si[0] + s1 * Si[2];
-                        KR[r * 2 + 1] = s0 * Si[1] + s1 * Si[3];
-                        TR[r * 2] = KR[r * 2] * S00 + KR[r * 2 + 1] * S01;
-                        TR[r * 2 + 1] = KR[r * 2] * S01 + KR[r * 2 + 1] * S11;
+                    } else {
+                        zero_slot_rows(slot, n_lm_before);  // Ignore / no room
                     }
-                    for (int r = 0; r < 3; r++) L.pose[r] = L.pose[r] + (KR[r * 2] * res0 + KR[r * 2 + 1] * res1);  // :187
-                    for (int r = 0; r < 3; r++)
-                        for (int q = r; q < 3; q++) {  // :188 + :193-194 on the 3x3 block
-                            double u = sym_u(TR[r * 2], TR[r * 2 + 1], KR[r * 2], KR[r * 2 + 1], TR[q * 2], TR[q * 2 + 1], KR[q * 2], KR[q * 2 + 1]);
-                            double nv = Prr[r * 3 + q] - u;
-                            L.Prr[r * 3 + q] = nv;
-                            L.Prr[q * 3 + r] = nv;
-                        }
-                    sincos(L.pose[2], &L.s, &L.c);
-                    for (int q = 0; q < 6; q++) L.HRt[q] = HRt[q], L.KR[q] = KR[q], L.TR[q] = TR[q];
-                    for (int q = 0; q < 4; q++) L.Sinv[q] = Si[q];
-                    L.S[0] = S00, L.S[1] = S01, L.S[2] = S01, L.S[3] = S11;
-                    L.res[0] = res0, L.res[1] = res1;
-                    L.decision = HDR_OLD;
-                    L.lm = L.gi;
-                    on = 1;
-                } else {
-                    decision = EKF_DECISION_IGNORE;  // :191
-                    if (lead) st->n_ignore++;
-                    L.decision = HDR_IGNORE;
                 }
-                if (on || (slot & 1) == 0) {
-                    pend_idx = np_prev + (slot >> 1);
-                    pend_val = on | ((slot & 1) ? L.pair_on[pend_idx] : 0);
-                }
-                if (lead) {
-                    act_c[slot] = on;
-                    long long cnt = L.log_count;
-                    ekf_decision e;
-                    e.decision = decision;
-                    e.matched = have ? 3 + 2 * L.gi : 0;
-                    e.mahal = mahal;
-                    dv.log[(size_t)b * dv.logcap + (cnt % dv.logcap)] = e;
-                    L.dec_buf[L.n_dec++] = e;  // the host-mapped mirror gets it at the end of the launch (a PCIe write here would sit in front of the next barrier)
-                    L.log_count = cnt + 1;
-                }
-                if (rec[6] == 2.0) L.n_sweep = L.n_lm;  // last measurement of the chunk
             }
-            __syncthreads();  // (3)
-            STAMP(4);  // gate + robot block (workers: requests in flight)
-        } else if (type == OP_COMPASS) {
+            __syncthreads();  // end of the measurement
+            STAMP(6);
+            cur ^= 1;
+            slot++;
+            continue;
+        }
+
+        if (type == OP_COMPASS) {
             // ---- kalmanfilter.cpp:96-130; rec = (z, R) -----------------------------------------------
-            __syncthreads();
-            if (!worker && tid == 0) {
-                commit_pair();
+            if (ctrl) {
                 double z = rec[0], Rc = rec[1];
-                double z_hat = L.pose[2];
+                double z_hat = RS.pose[2];
                 z_hat -= 6.283185307 * floor(z_hat / 6.283185307);  // :98-99
                 double res1 = z - z_hat, res2 = z - 6.283185307 - z_hat, res3 = z + 6.283185307 - z_hat;
                 double res;
@@ -795,7 +867,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                 else if (fabs(res2) <= fabs(res3)) res = res2;
                 else res = res3;
                 double Prr[9];
-                for (int i = 0; i < 9; i++) Prr[i] = L.Prr[i];
+                for (int i = 0; i < 9; i++) Prr[i] = RS.Prr[i];
                 double S = Prr[8] + Rc;  // :114
                 double invS = 1 / S;
                 double KR[3], TR[3];
@@ -803,112 +875,60 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                     KR[r] = invS * Prr[r * 3 + 2];  // :118
                     TR[r] = S * KR[r];
                 }
-                for (int r = 0; r < 3; r++) L.pose[r] = L.pose[r] + res * KR[r];  // :121
+                for (int r = 0; r < 3; r++) RN.pose[r] = RS.pose[r] + res * KR[r];  // :121
                 for (int r = 0; r < 3; r++)
                     for (int q = r; q < 3; q++) {  // :122-124
                         double nv = Prr[r * 3 + q] - sym_u(TR[r], 0, KR[r], 0, TR[q], 0, KR[q], 0);
-                        L.Prr[r * 3 + q] = nv;
-                        L.Prr[q * 3 + r] = nv;
+                        RN.Prr[r * 3 + q] = nv;
+                        RN.Prr[q * 3 + r] = nv;
                     }
-                sincos(L.pose[2], &L.s, &L.c);
+                sincos(RN.pose[2], &RN.s, &RN.c);
+                RN.n_lm = RS.n_lm, RN.n_sweep = RS.n_sweep;
                 for (int r = 0; r < 3; r++) {
                     L.KR[r * 2] = KR[r], L.KR[r * 2 + 1] = 0;
                     L.TR[r * 2] = TR[r], L.TR[r * 2 + 1] = 0;
                 }
-                L.S[0] = S;
+                L.S0 = S;
                 L.invS = invS;
-                L.res[0] = res, L.res[1] = 0;
-                L.HRt[0] = -1, L.HRt[1] = 0;  // unused by the compass gain
-                L.decision = HDR_COMPASS;
-                L.pair_on[np_prev + (slot >> 1)] = 1;
+                L.res0 = res;
+                L.slot_on[slot] = 1;
                 if (lead) act_c[slot] = 1;
             }
             __syncthreads();
-        } else {
-            continue;  // OP_NOP
-        }
-
-        // ---- landmark part of the branch taken ----------------------------------------------------------
-        const int decision = uni(L.decision);
-        if (worker) {
-            if (decision == HDR_NEW) {
-                const int ln = uni(L.lm);
-                const int hi = own_hi < ln ? own_hi : ln;
-                if (lm0 < hi) apply_new_column(lm0, r0, slot);
-                else if (lm0 == ln && lm0 < own_hi) apply_new_self(lm0, r0, slot);
-                for (int lm = lm0 + nw; lm < own_hi && lm <= ln; lm += nw) {
-                    if (lm < ln) {
-                        LmState st = lm_load(lm);
-                        apply_new_column(lm, st, slot);
-                    } else {
-                        LmState st;
-                        apply_new_self(lm, st, slot);
-                    }
-                }
-            } else if (decision != HDR_OLD && decision != HDR_COMPASS) {
-                zero_slot_rows(slot);  // Ignore / no room
-            } else {
-                const bool is_old = (decision == HDR_OLD);
-                const int n_lm = uni(L.n_lm);
-                const int lo = uni(L.lm);
-                const int nslots = is_old ? np_prev + ((slot + 1) >> 1) : 0;  // pairs to fold
+            if (worker) {
+                const int n_lm = uni(RS.n_lm);
                 const int hi = own_hi < n_lm ? own_hi : n_lm;
-                // one landmark; `st` is either the register-resident r0 or a copy loaded from memory
-                auto gain_one = [&](int lm, LmState &st, bool use_spec) {
-                    double p[2][2] = {{0, 0}, {0, 0}};
-                    if (is_old) {
-                        if (lm == lo) {
-                            p[0][0] = st.dxx, p[0][1] = st.dxy, p[1][0] = st.dxy, p[1][1] = st.dyy;
-                        } else {
-                            const bool below = lm < lo;  // stored as (row of the older landmark, column of the newer)
-                            double4_t o0[4], o1[4];
-                            if (use_spec) {  // requested before the gate
-                                for (int a = 0; a < 2; a++)
-                                    for (int e = 0; e < 2; e++) p[a][e] = spec_p[a][e];
-                                if (nslots > 0) fold_chunk(below, 0, nslots, spec_o0, spec_o1, p);
-                            } else {
-                                load_old_inputs(lm, lo, p);
-                                if (nslots > 0) {
-                                    load_chunk(2 * lm, below, 0, nslots, o0, o1);
-                                    fold_chunk(below, 0, nslots, o0, o1, p);
-                                }
-                            }
-                            for (int s0 = 4; s0 < nslots; s0 += 4) {
-                                load_chunk(2 * lm, below, s0, nslots, o0, o1);
-                                fold_chunk(below, s0, nslots, o0, o1, p);
-                            }
-                        }
-                    }
-                    apply_gain(lm, st, is_old, p, slot);
-                };
-                if (lm0 < hi) gain_one(lm0, r0, spec_ok);
+                if (lm0 < hi) apply_compass(lm0, r0, slot);
                 for (int lm = lm0 + nw; lm < hi; lm += nw) {
                     LmState stm = lm_load(lm);
-                    gain_one(lm, stm, false);
+                    apply_compass(lm, stm, slot);
                 }
             }
+            __syncthreads();
+            cur ^= 1;
+            slot++;
+            continue;
         }
-        STAMP(6);  // landmark part
-        slot++;
+        // OP_NOP
     }
 
-    __syncthreads();
 #ifdef EKF_CHAIN_STAMPS
-    if (tid == 0 && g == 0 && b == 0)
-        for (int i = 0; i < 8; i++) dv.dbg[i] += stamp_acc[i];
+    if ((tid == 0 || tid == 64) && g == 0 && b == 0)
+        for (int i = 0; i < 8; i++) dv.dbg[(tid == 0 ? 0 : 16) + i] += stamp_acc[i];
 #endif
     if (tid == 0) {
         if (lead) {
+            const RobotState &R = L.rs[cur];
             for (int i = 0; i < 3; i++) {
-                x[i] = L.pose[i];
-                for (int j = 0; j < 3; j++) R0[(size_t)i * xs + j] = L.Prr[i * 3 + j];
+                x[i] = R.pose[i];
+                for (int j = 0; j < 3; j++) R0[(size_t)i * xs + j] = R.Prr[i * 3 + j];
             }
-            dv.n_lm[b] = L.n_lm;
-            dv.n_lm_sweep[b] = L.n_sweep;
-            dv.n_lm_flush[(size_t)b * 2 + set] = L.n_lm;
+            dv.n_lm[b] = R.n_lm;
+            dv.n_lm_sweep[b] = R.n_sweep;
+            dv.n_lm_flush[(size_t)b * 2 + set] = R.n_lm;
             EkfMirror *mr = dv.mirror + b;
-            for (int i = 0; i < 3; i++) mr->pose[i] = L.pose[i];
-            mr->n_lm = L.n_lm;
+            for (int i = 0; i < 3; i++) mr->pose[i] = R.pose[i];
+            mr->n_lm = R.n_lm;
             dv.stats[b] = L.st;
             dv.log_count[b] = L.log_count;
             for (int i = 0; i < L.n_dec; i++) mr->last[(L.log_count - L.n_dec + i) % EKF_MIRROR_DECISIONS] = L.dec_buf[i];

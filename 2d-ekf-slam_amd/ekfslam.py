@@ -17,7 +17,7 @@ NEW, OLD, IGNORE = 1, 2, 3
 # every symbol include/ekfslam_c.h declares
 ABI_SYMBOLS = [
     "ekf_last_error", "ekf_default_params", "ekf_create", "ekf_batch_create", "ekf_destroy", "ekf_batch_size",
-    "ekf_capacity", "ekf_propagate", "ekf_propagate_q", "ekf_update", "ekf_update_compass", "ekf_get_pose",
+    "ekf_capacity", "ekf_window", "ekf_propagate", "ekf_propagate_q", "ekf_update", "ekf_update_compass", "ekf_get_pose",
     "ekf_num_landmarks", "ekf_get_robot_cov", "ekf_get_x", "ekf_batch_propagate", "ekf_batch_propagate_q", "ekf_batch_update",
     "ekf_batch_update_compass", "ekf_batch_get_pose", "ekf_batch_num_landmarks", "ekf_get_state", "ekf_set_state",
     "ekf_broadcast_state", "ekf_script_load", "ekf_script_run", "ekf_sync", "ekf_flush", "ekf_timer_start",
@@ -71,6 +71,7 @@ def load():
     L.ekf_destroy.argtypes = [_H]
     L.ekf_batch_size.argtypes = [_H]
     L.ekf_capacity.argtypes = [_H]
+    L.ekf_window.argtypes = [_H]
     L.ekf_propagate.argtypes = [_H, ctypes.c_double, ctypes.c_double, ctypes.c_double]
     L.ekf_propagate_q.argtypes = [_H, ctypes.c_double, ctypes.c_double, _dp, ctypes.c_double]
     L.ekf_update.argtypes = [_H, _dp, _dp, ctypes.c_int, ctypes.POINTER(EkfDecision)]
@@ -140,6 +141,7 @@ class FilterBatch:
         _chk(self.L.ekf_batch_create(ctypes.byref(self.h), batch, capacity_landmarks, device, ctypes.byref(p)))
         self.batch = batch
         self.capacity = capacity_landmarks
+        self.window = int(self.L.ekf_window(self.h))  # effective max_pending
 
     def close(self):
         if self.h:

@@ -86,6 +86,7 @@ def main():
     # ---- inputs: built on the host, then moved to HBM (untimed) ------------------------------------
     lo, hi = mc.shard_range(B * world, rank, world)
     f = pkg.FilterBatch(B, N, device=dev_id, max_pending=args.max_pending, log_capacity=max(4096, (K + W) * M))
+    args.max_pending = f.window  # the library may shorten the window to fit its on-chip buffer
     scripts = []
     for b, g in enumerate(range(lo, hi)):
         x0, P0 = pkg.scenarios.injected_state(N, seed=mc.filter_seed(seed, g), extent=extent)

@@ -54,8 +54,8 @@ typedef struct ekf_params {
     double cond_limit;  /* 80    Update.cpp:131 */
     int max_pending;    /* measurements whose P_LL change is deferred into ONE dense pass over P_LL
                            (each is a rank-4 slot of that pass); 1 = a dense pass per measurement as the
-                           reference does (Update.cpp:188).  1..32, default 16.  Results do not depend on
-                           it beyond rounding; x, the robot rows and the landmark 2x2 blocks are always
+                           reference does (Update.cpp:188).  1..32, default 16; may be shortened at
+                           creation, see ekf_window().  Results do not depend on it beyond rounding; x, the robot rows and the landmark 2x2 blocks are always
                            current, and ekf_get_state / ekf_flush fold everything on demand. */
     int log_capacity;   /* decision-log entries kept per filter (ring) */
 } ekf_params;
@@ -85,6 +85,9 @@ int ekf_batch_create(ekf_handle *out, int batch, int capacity_landmarks, int dev
 int ekf_destroy(ekf_handle h);
 int ekf_batch_size(ekf_handle h);
 int ekf_capacity(ekf_handle h);
+/* The effective max_pending: the requested window, shortened when capacity_landmarks x window does not fit
+ * the on-chip buffer of the chain kernel (64 bytes per landmark and slot, about 148 KB per workgroup). */
+int ekf_window(ekf_handle h);
 
 /* ---- single-filter calls (batch must be 1) ------------------------------------------------ */
 

@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import __graft_entry__ as ge
 pkg = ge.load_package()
-NAMES = ["between meas", "sweep+wg argmin", "publish+barrier", "pick", "gate", "lo rows", "landmark part"]
+NAMES = ["other ops", "sweep+wg argmin", "publish+barrier", "pick", "stage+barrier", "apply | robot block", "end barrier"]
 
 def run(N, maxp, steps=32, warm=8, M=4):
     f = pkg.FilterBatch(1, N, max_pending=maxp)
@@ -15,14 +15,14 @@ def run(N, maxp, steps=32, warm=8, M=4):
     f.set_state(x0, P0)
     f.script_load(sc["ctrl"][:, None, :], sc["z"][:, :, None, :], sc["R"][:, :, None, :])
     f.script_run(0, warm); f.sync()
-    buf = (ctypes.c_longlong * 16)()
+    buf = (ctypes.c_longlong * 32)()
     f.L.ekf_debug_stamps.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_longlong), ctypes.c_int]
     f.L.ekf_debug_stamps(f.h, buf, 1)
     f.timer_start(); f.script_run(warm, steps); ms = f.timer_stop()
     f.L.ekf_debug_stamps(f.h, buf, 1)
     nm = steps * M
     print("N=%d maxp=%d G=%s: %.1f us/step; per measurement (us): " % (N, maxp, os.environ.get("EKF_CHAIN_WGS", "auto"), ms / steps * 1e3) +
-          ", ".join("%s %.2f" % (NAMES[i], buf[i] * 0.01 / nm) for i in range(7)) + "  | sum %.2f" % (sum(buf[i] for i in range(7)) * 0.01 / nm), flush=True)
+          ", ".join("%s %.2f/%.2f" % (NAMES[i], buf[i] * 0.01 / nm, buf[16 + i] * 0.01 / nm) for i in range(7)) + "  | sum %.2f/%.2f (control lane / first worker)" % (sum(buf[i] for i in range(7)) * 0.01 / nm, sum(buf[16 + i] for i in range(7)) * 0.01 / nm), flush=True)
     f.close()
 
 for N, maxp in ((4096, 4), (4096, 16), (1024, 4), (256, 4)):
