@@ -189,7 +189,7 @@ extern "C" int ekf_batch_create(ekf_handle *out, int batch, int capacity_landmar
     HIP_TRY(dev_alloc_zero(&dv.slot_active, B * 2 * dv.maxp, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.bar, B * 2, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.dbg, 32, &h->device_bytes, s));
-    HIP_TRY(dev_alloc_zero(&dv.part, B * 2 * dv.gmax * 24, &h->device_bytes, s));
+    HIP_TRY(dev_alloc_zero(&dv.part, B * 2 * dv.gmax * EKF_REC_DOUBLES, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.log, B * dv.logcap, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.log_count, B, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.stats, B, &h->device_bytes, s));

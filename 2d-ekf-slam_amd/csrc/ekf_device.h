@@ -30,6 +30,10 @@
 #define EKF_CHAIN_MAX_THREADS 256 /* one control wave + up to 192 workers: one wave per SIMD, 512-VGPR budget */
 #define EKF_CHAIN_MAX_WGS 32 /* workgroups sharing one filter in k_chain */
 #define EKF_CHAIN_MAX_OPS 64 /* operations per k_chain launch */
+// one workgroup's record of a cross-workgroup arg-min exchange (doubles): winner data [0,16), the winner's rows of
+// every slot [16, 16 + 8*maxp), head granules at EKF_REC_HEAD; padded to whole 128-byte lines
+#define EKF_REC_HEAD (16 + 8 * EKF_MAX_PENDING)
+#define EKF_REC_DOUBLES (EKF_REC_HEAD + 16)
 
 // op records: 8 doubles per (op, filter); r[7] is the type
 enum { OP_NOP = 0, OP_PROP = 1, OP_MEAS = 2, OP_COMPASS = 3, OP_TRUTH = 4, OP_SKIP_SLOT = 5 };
@@ -67,9 +71,9 @@ struct EkfDev {
     int *n_lm, *n_lm_sweep, *status;
     int *n_lm_flush;   // [B][2]: landmark count when set s was last written (sizes its dense pass)
     int *slot_active;  // [B][2][maxp]
-    int *bar;          // [B][2]: cross-workgroup barrier arrivals, exit count
+    int *bar;          // [B][2]: [0] = cross-workgroup exchanges done so far (tags of the records continue from it)
     long long *dbg;    // [32] diagnostics: tick counters of the control lane [0..7] and of the first worker [16..23] (EKF_CHAIN_STAMPS), first bad index [8..11] (EKF_CHAIN_CHECK)
-    double *part;      // [B][2][gmax][24]: per-workgroup arg-min records, double-buffered by barrier parity
+    double *part;      // [B][2][gmax][EKF_REC_DOUBLES]: per-workgroup arg-min records, double-buffered by exchange parity
     ekf_decision *log;
     long long *log_count;
     ekf_stats *stats;

@@ -61,8 +61,6 @@ struct ChainLds {
     // arg-min reduction
     double wd[EKF_CHAIN_MAX_THREADS / 64];
     int wi[EKF_CHAIN_MAX_THREADS / 64];
-    double gd;  // best Mahalanobis distance over all landmarks, EKF_INF when none
-    int gi;     // its landmark, 0x7fffffff when none
     // data of the winning landmark: res(2) S00,S01,S11 hcol(2) P_R,Lo(6) D(3)
     double w[16];
     // headers of the rare branches, written by the control lane before a workgroup barrier
@@ -305,8 +303,9 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
     double *FBc = dv.FB + ((size_t)b * 2 + set) * dv.f_stride;
     int *act_c = dv.slot_active + ((size_t)b * 2 + set) * dv.maxp;
     int *bar = dv.bar + (size_t)b * 2;
-    double *part = dv.part + (size_t)b * 2 * dv.gmax * 24;
-    int epoch = 0;  // cross-workgroup barriers passed in this launch
+    double *part = dv.part + (size_t)b * 2 * dv.gmax * EKF_REC_DOUBLES;
+    int epoch = 0;  // cross-workgroup exchanges done in this launch
+    const int ebase = bar[0];  // exchanges done by earlier launches: tags never repeat
 #ifdef EKF_CHAIN_STAMPS
     unsigned long long stamp_t;
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_t)::"memory");
@@ -637,44 +636,72 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
             int gi = L.wi[0];
             for (int wv = 1; wv < (bd >> 6); wv++)
                 if (cand_better(L.wd[wv], L.wi[wv], gd, gi)) gd = L.wd[wv], gi = L.wi[wv];
-            if (gi != 0x7fffffff && gi == best.lm)  // this thread owns the workgroup's winner
-                for (int i = 0; i < 16; i++) L.w[i] = best.w[i];
-            if (ctrl) L.gd = gd, L.gi = gi;
-            __syncthreads();  // (2)
-            STAMP(1);  // sweep + workgroup arg-min
+            gi = uni(gi);  // every thread of the workgroup holds the same local winner
+            STAMP(1);      // sweep + workgroup arg-min
+            int src = g;   // workgroup that owns the winner
             if (G > 1) {
-                // arg-min over the filter's workgroups: publish, barrier, pick (every workgroup picks the same)
-                double *mine = part + ((size_t)(epoch & 1) * dv.gmax + g) * 24;
-                if (tid < 16) mine[tid] = L.w[tid];
-                if (tid == 16) mine[16] = L.gd;
-                if (tid == 17) mine[17] = (double)L.gi;
-                filter_barrier(bar, (epoch + 1) * G, dv.status + b);
-                STAMP(2);  // publish + cross-workgroup barrier
-                if (tid < 64) {  // wave 0: one lane per workgroup record
-                    double d = EKF_INF;
-                    int i = 0x7fffffff, src = tid;
-                    if (tid < G) {
-                        const double *pr = part + ((size_t)(epoch & 1) * dv.gmax + tid) * 24;
-                        d = pr[16];
-                        i = (int)pr[17];
-                    }
-                    for (int off = 32; off > 0; off >>= 1) {
-                        double od = __shfl_down(d, off, 64);
-                        int oi = __shfl_down(i, off, 64), os = __shfl_down(src, off, 64);
-                        if (cand_better(od, oi, d, i)) d = od, i = oi, src = os;
-                    }
-                    d = __shfl(d, 0, 64), i = __shfl(i, 0, 64), src = __shfl(src, 0, 64);
-                    if (i != 0x7fffffff && tid < 16) L.w[tid] = part[((size_t)(epoch & 1) * dv.gmax + src) * 24 + tid];
-                    if (tid == 0) L.gd = d, L.gi = i;
+                // ---- arg-min over the filter's workgroups, without fences: every handed-off byte is written by an
+                // agent-scope (sc1, write-through) store and read by an sc1 load (MI355X_MICROARCH.md "Valid forms").
+                // A workgroup's record = body (winner data, the winner's rows of every live slot) + head (three
+                // self-validating 8-byte granules {d lo, tag} {d hi, tag} {landmark, tag}).  The body is drained
+                // (vmcnt(0) in every storing wave, then the workgroup barrier) before lane 0 stores the head; a reader
+                // that sees all three tags of this exchange may therefore read the body.  Records are double-buffered
+                // by exchange parity: a workgroup cannot publish exchange e+2 before every workgroup has read e.
+                const unsigned tag = (unsigned)(ebase + epoch + 1);
+                unsigned long long *rec = (unsigned long long *)(part + ((size_t)(epoch & 1) * dv.gmax + g) * EKF_REC_DOUBLES);
+                if (gi != 0x7fffffff) {
+                    if (gi == best.lm)  // the lane that owns the local winner
+                        for (int i = 0; i < 16; i++) __hip_atomic_store(rec + i, (unsigned long long)__double_as_longlong(best.w[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const double *wr = own_rows + (gi - own_lo);
+                    for (int q = tid; q < slot * 8; q += bd)
+                        if (L.slot_on[q >> 3])
+                            __hip_atomic_store(rec + 16 + q, (unsigned long long)__double_as_longlong(wr[(size_t)q * lpw_]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();  // (P) the body has left every wave
+                if (tid == 0) {
+                    const unsigned long long db = (unsigned long long)__double_as_longlong(gd);
+                    __hip_atomic_store(rec + EKF_REC_HEAD, ((unsigned long long)tag << 32) | (db & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(rec + EKF_REC_HEAD + 1, ((unsigned long long)tag << 32) | (db >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(rec + EKF_REC_HEAD + 2, ((unsigned long long)tag << 32) | (unsigned)gi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                // every wave polls the heads itself (lane l reads workgroup l's) and may then read the winner's body
+                const int lane = tid & 63;
+                const unsigned long long *hd = (const unsigned long long *)(part + ((size_t)(epoch & 1) * dv.gmax + (lane < G ? lane : 0)) * EKF_REC_DOUBLES) + EKF_REC_HEAD;
+                unsigned long long h0 = 0, h1 = 0, h2 = 0;
+                long spins = 0;
+                for (;;) {
+                    h0 = __hip_atomic_load(hd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    h1 = __hip_atomic_load(hd + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    h2 = __hip_atomic_load(hd + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const bool ok = lane >= G || ((unsigned)(h0 >> 32) == tag && (unsigned)(h1 >> 32) == tag && (unsigned)(h2 >> 32) == tag);
+                    if (__all(ok)) break;
+                    if (++spins > (1L << 22)) {  // bounded: a lost workgroup must not hang the GPU
+                        if (lane == 0) dv.status[b] = EKF_ERR_HIP;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                double d = EKF_INF;
+                int i = 0x7fffffff;
+                src = lane;
+                if (lane < G) {
+                    d = __longlong_as_double((long long)((h1 << 32) | (h0 & 0xffffffffull)));
+                    i = (int)(unsigned)(h2 & 0xffffffffull);
+                }
+                for (int off = 32; off > 0; off >>= 1) {
+                    double od = __shfl_down(d, off, 64);
+                    int oi = __shfl_down(i, off, 64), os = __shfl_down(src, off, 64);
+                    if (cand_better(od, oi, d, i)) d = od, i = oi, src = os;
+                }
+                gd = __shfl(d, 0, 64), gi = uni(__shfl(i, 0, 64)), src = uni(__shfl(src, 0, 64));
                 epoch++;
-                __syncthreads();
-                STAMP(3);  // pick over workgroups
+                STAMP(2);  // publish + poll + pick
             }
             // ---- gate, Update.cpp:152,181,191: a pure function of the winner, evaluated by every thread ----------
-            const int w_lo = uni(L.gi);
+            const int w_lo = gi;
             const bool have = (w_lo != 0x7fffffff);
-            const double mahal = have ? L.gd : EKF_INF;
+            const double mahal = have ? gd : EKF_INF;
             int hdr;
             if (!have || mahal > dv.gamma_max) hdr = (n_lm_before >= dv.Ncap) ? HDR_NEW_NOFIT : HDR_NEW;  // :152
             else if (mahal < dv.gamma_min) hdr = HDR_OLD;                                                // :181
@@ -712,15 +739,25 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
             if (hdr == HDR_OLD) {
                 // ---- Old, Update.cpp:181-189.  Workers: request the matched landmark's slot rows (into LDS) and their
                 // own P_LL entries and slot rows (into registers), barrier, fold, gain, store.  Control lane: robot block.
-                const int w_jo = 2 * w_lo;
                 const int hi = own_hi < n_lm_before ? own_hi : n_lm_before;
                 double pf_p[2][2] = {{0, 0}, {0, 0}};
-                if (worker) {
-                    if (lm0 < hi && lm0 != w_lo) load_old_inputs(lm0, w_lo, pf_p);  // in flight across the barrier
-                    for (int q = wtid; q < slot * 8; q += nw) {
-                        int sl = q >> 3, side = (q >> 2) & 1, e = (q >> 1) & 1, k = q & 1;
-                        L.lo_rows[q] = L.slot_on[sl] ? ((side == 0 ? FAb : FBb)[CK(off_c + pair_offset(rows_, w_jo + e, sl >> 1) + (sl & 1) * 2 + k, lim_F)]) : 0.0;
+                if (worker && lm0 < hi && lm0 != w_lo) load_old_inputs(lm0, w_lo, pf_p);  // in flight across the barrier
+                // winner record and the matched landmark's slot rows into LDS: from the owner's published record, or,
+                // with one workgroup per filter, straight from registers and the own-row cache
+                if (G > 1) {
+                    const unsigned long long *wrec = (const unsigned long long *)(part + ((size_t)((epoch - 1) & 1) * dv.gmax + src) * EKF_REC_DOUBLES);
+                    for (int q = tid; q < 16 + slot * 8; q += bd) {
+                        if (q >= 16 && !L.slot_on[(q - 16) >> 3]) continue;
+                        double v = __longlong_as_double((long long)__hip_atomic_load(wrec + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                        if (q < 16) L.w[q] = v;
+                        else L.lo_rows[q - 16] = v;
                     }
+                } else {
+                    if (w_lo == best.lm)
+                        for (int i = 0; i < 16; i++) L.w[i] = best.w[i];
+                    const double *wr = own_rows + (w_lo - own_lo);
+                    for (int q = tid; q < slot * 8; q += bd)
+                        if (L.slot_on[q >> 3]) L.lo_rows[q] = wr[(size_t)q * lpw_];
                 }
                 __syncthreads();  // (3) staged rows visible
                 STAMP(4);
@@ -935,14 +972,8 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
             mr->status = dv.status[b];
             mr->log_count = L.log_count;
         }
-        if (G > 1) {
-            // the last workgroup of this filter to leave re-arms the barrier for the next launch
-            int prev = __hip_atomic_fetch_add(bar + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (prev == G - 1) {
-                __hip_atomic_store(bar, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(bar + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
+        // (a workgroup can only get here after every workgroup of the filter has read ebase: it took part in each exchange)
+        if (lead && epoch > 0) bar[0] = ebase + epoch;
     }
 }
 
