@@ -30,10 +30,11 @@
 #define EKF_CHAIN_MAX_THREADS 256 /* one control wave + up to 192 workers: one wave per SIMD, 512-VGPR budget */
 #define EKF_CHAIN_MAX_WGS 32 /* workgroups sharing one filter in k_chain */
 #define EKF_CHAIN_MAX_OPS 64 /* operations per k_chain launch */
-// one workgroup's record of a cross-workgroup arg-min exchange (doubles): winner data [0,16), the winner's rows of
-// every slot [16, 16 + 8*maxp), head granules at EKF_REC_HEAD; padded to whole 128-byte lines
+// one workgroup's record of a cross-workgroup arg-min exchange.  Every value is two 8-byte granules
+// {32 payload bits, 32-bit tag}: winner data = values [0,16), the winner's rows of every slot = values
+// [16, 16 + 8*maxp), head {d, landmark} = values EKF_REC_HEAD, EKF_REC_HEAD + 1; padded to whole 128-byte lines
 #define EKF_REC_HEAD (16 + 8 * EKF_MAX_PENDING)
-#define EKF_REC_DOUBLES (EKF_REC_HEAD + 16)
+#define EKF_REC_DOUBLES (2 * EKF_REC_HEAD + 16)
 
 // op records: 8 doubles per (op, filter); r[7] is the type
 enum { OP_NOP = 0, OP_PROP = 1, OP_MEAS = 2, OP_COMPASS = 3, OP_TRUTH = 4, OP_SKIP_SLOT = 5 };

@@ -39,7 +39,7 @@ __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlan
 
 __device__ __forceinline__ bool cand_better(double da, int ia, double db, int ib) {
     // strict '>' with ascending scan order (Update.cpp:140): smaller d wins, ties -> lower index
-    return (da < db) || (da == db && ia < ib);
+    return (da < db) | ((da == db) & (ia < ib));  // bitwise: no short-circuit branches in the reductions
 }
 
 // The robot block and the landmark counts.  Two copies live in LDS: operations read rs[cur], the control lane
@@ -50,6 +50,36 @@ struct RobotState {
     double Prr[9];
     int n_lm, n_sweep;
 };
+
+// Wave-wide arg-min of (d, i) candidates with cand_better's order, on the DPP cross-lane path (row shifts, then
+// the gfx9 row broadcasts): the operation is idempotent, so the overlapping windows of the doubling steps are
+// harmless.  All 64 lanes must be active.  Returns the winner to every lane; `who` = the lane that held it.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void argmin_dpp_step(double &d, int &i, int &who) {
+    int dl = __double2loint(d), dh = __double2hiint(d);
+    int odl = __builtin_amdgcn_update_dpp(dl, dl, CTRL, ROW_MASK, 0xf, false);
+    int odh = __builtin_amdgcn_update_dpp(dh, dh, CTRL, ROW_MASK, 0xf, false);
+    int oi = __builtin_amdgcn_update_dpp(i, i, CTRL, ROW_MASK, 0xf, false);
+    int ow = __builtin_amdgcn_update_dpp(who, who, CTRL, ROW_MASK, 0xf, false);
+    double od = __hiloint2double(odh, odl);
+    const bool take = cand_better(od, oi, d, i);  // selects, not a branch
+    dl = take ? odl : dl, dh = take ? odh : dh;
+    d = __hiloint2double(dh, dl);
+    i = take ? oi : i;
+    who = take ? ow : who;
+}
+
+__device__ __forceinline__ void wave_argmin(double &d, int &i, int &who) {
+    argmin_dpp_step<0x111, 0xf>(d, i, who);  // row_shr:1
+    argmin_dpp_step<0x112, 0xf>(d, i, who);  // row_shr:2
+    argmin_dpp_step<0x114, 0xf>(d, i, who);  // row_shr:4
+    argmin_dpp_step<0x118, 0xf>(d, i, who);  // row_shr:8   -> lane 15 of every row holds the row's winner
+    argmin_dpp_step<0x142, 0xa>(d, i, who);  // row_bcast:15 -> lanes 31, 63 hold the winners of the two halves
+    argmin_dpp_step<0x143, 0xc>(d, i, who);  // row_bcast:31 -> lane 63 holds the wave's winner
+    d = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(d), 63), __builtin_amdgcn_readlane(__double2loint(d), 63));
+    i = __builtin_amdgcn_readlane(i, 63);
+    who = __builtin_amdgcn_readlane(who, 63);
+}
 
 struct ChainLds {
     RobotState rs[2];  // every workgroup of a filter holds an identical copy
@@ -68,9 +98,8 @@ struct ChainLds {
     double newx[2], newrc[6], newdd[3];  // New landmark: state, P_R,new (3x2), 2x2 block
     double KR[6], TR[6];                 // compass: rows 0..2 of K and of K*S in column 0 (kalmanfilter.cpp:118)
     double S0, invS, res0;               // compass: S, 1/S, residual
-    // rows of the matched landmark in every slot of the set being filled, [slot][side A/B][row e][k], and which slots are live
+    // rows of the matched landmark in every slot of the set being filled, [slot][side A/B][row e][k] (dead slots: zeros)
     double lo_rows[EKF_MAX_PENDING * 8];
-    int slot_on[EKF_MAX_PENDING];
 };
 
 // Header of the Old branch (Update.cpp:181-189): a pure function of the heading the sweep ran with and of the
@@ -366,7 +395,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
     // a slot that changes nothing (Ignore, masked, no room) still writes zeros: its pair partner may be live
     auto zero_slot_rows = [=](int slot, int n_now) {
         const int hi = own_hi < n_now ? own_hi : n_now;
-        for (int lm = lm0; lm < hi; lm += nw) write_slot(lm, slot, 0, 0, 0, 0, 0, 0, 0, 0);  // (the LDS copy is never read: slot_on = 0)
+        for (int lm = lm0; lm < hi; lm += nw) write_slot(lm, slot, 0, 0, 0, 0, 0, 0, 0, 0);  // zeros in HBM for the dense pass, zeros in LDS for the fold
     };
     // Old branch for one landmark (Update.cpp:186-188,193-194): K rows, x += K res, robot rows and own block of
     // P, the slot.  p = P[rows of lm, columns of the matched landmark]; Prr and wv are the robot block the sweep
@@ -453,13 +482,11 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
 
     // stage this filter's operation records in LDS (one trip to HBM / host memory for the whole list)
     for (int q = tid; q < nops * 8; q += bd) recs[q] = op_record(in, cursor, k0 + (q >> 3), dv.B, b)[q & 7];
-    for (int q = tid; q < slot0; q += bd) L.slot_on[q] = act_c[q];  // which slots of this set hold anything
     if (worker) {  // slots filled by earlier launches: own rows back into LDS
         const int n_now = dv.n_lm[b];
         const int hi = own_hi < n_now ? own_hi : n_now;
         for (int lm = lm0; lm < hi; lm += nw)
-            for (int sl = 0; sl < slot0; sl++) {
-                if (!act_c[sl]) continue;
+            for (int sl = 0; sl < slot0; sl++) {  // (dead slots hold zeros)
                 const size_t o = CK(off_c + pair_offset(rows_, 2 * lm, sl >> 1), lim_F - 7) + (sl & 1) * 2;
                 double *cr = own_rows + (size_t)sl * 8 * lpw_ + (lm - own_lo);
                 for (int a = 0; a < 2; a++)
@@ -493,8 +520,6 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
     //  * the robot block lives in L.rs[cur]; nobody writes it during an operation.  The control lane writes the
     //    complete next state into L.rs[cur ^ 1]; every state-changing operation ends with ONE workgroup barrier
     //    and then flips cur.
-    //  * slot_on[slot] of the slot being filled is written by the control lane while the workers read the flags
-    //    of the EARLIER slots only (a slot is not folded into itself).
     //  * everything a measurement's branch needs is a pure function of (L.rs[cur], the winner record L.w, L.gd,
     //    L.gi), so every thread evaluates the gate itself; in the Old branch the workers also rebuild the gain
     //    header themselves and update their landmarks WHILE the control lane updates the robot block.
@@ -586,7 +611,6 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
             // a masked measurement: consumes its slot, changes nothing
             if (ctrl) {
                 if (lead) act_c[slot] = 0;
-                L.slot_on[slot] = 0;
                 RN = RS;
                 if (rec[6] == 2.0) RN.n_sweep = RS.n_lm;
             }
@@ -621,12 +645,8 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
             }
             // workgroup arg-min with first-index tie-break
             double rd = best.d;
-            int ri = best.lm;
-            for (int off = 32; off > 0; off >>= 1) {
-                double od = __shfl_down(rd, off, 64);
-                int oi = __shfl_down(ri, off, 64);
-                if (cand_better(od, oi, rd, ri)) rd = od, ri = oi;
-            }
+            int ri = best.lm, rwho = 0;
+            wave_argmin(rd, ri, rwho);
             if ((tid & 63) == 0) {
                 L.wd[tid >> 6] = rd;
                 L.wi[tid >> 6] = ri;
@@ -640,41 +660,40 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
             STAMP(1);      // sweep + workgroup arg-min
             int src = g;   // workgroup that owns the winner
             if (G > 1) {
-                // ---- arg-min over the filter's workgroups, without fences: every handed-off byte is written by an
-                // agent-scope (sc1, write-through) store and read by an sc1 load (MI355X_MICROARCH.md "Valid forms").
-                // A workgroup's record = body (winner data, the winner's rows of every live slot) + head (three
-                // self-validating 8-byte granules {d lo, tag} {d hi, tag} {landmark, tag}).  The body is drained
-                // (vmcnt(0) in every storing wave, then the workgroup barrier) before lane 0 stores the head; a reader
-                // that sees all three tags of this exchange may therefore read the body.  Records are double-buffered
-                // by exchange parity: a workgroup cannot publish exchange e+2 before every workgroup has read e.
-                const unsigned tag = (unsigned)(ebase + epoch + 1);
+                // ---- arg-min over the filter's workgroups, without fences, drains or counters.  Every handed-off byte
+                // travels in a self-validating 8-byte granule {32 payload bits, 32-bit tag of this exchange} written by
+                // ONE agent-scope (sc1, write-through) store and read by ONE sc1 load (MI355X_MICROARCH.md, granules:
+                // no ordering needed between them; a reader re-reads a granule until it carries the tag).  A double is
+                // two granules.  A workgroup's record = winner data (16 doubles), the winner's rows of every slot of
+                // the window, and the head {d, landmark}.  Records are double-buffered by exchange parity: a workgroup
+                // cannot publish exchange e+2 before every workgroup has read e.
+                const unsigned long long tag = (unsigned long long)(unsigned)(ebase + epoch + 1) << 32;
                 unsigned long long *rec = (unsigned long long *)(part + ((size_t)(epoch & 1) * dv.gmax + g) * EKF_REC_DOUBLES);
+                auto put = [=](unsigned long long *at, double v) {
+                    const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+                    __hip_atomic_store(at, tag | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(at + 1, tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                };
+                if (tid == 0) {
+                    put(rec + 2 * EKF_REC_HEAD, gd);
+                    __hip_atomic_store(rec + 2 * EKF_REC_HEAD + 2, tag | (unsigned)gi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
                 if (gi != 0x7fffffff) {
                     if (gi == best.lm)  // the lane that owns the local winner
-                        for (int i = 0; i < 16; i++) __hip_atomic_store(rec + i, (unsigned long long)__double_as_longlong(best.w[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        for (int i = 0; i < 16; i++) put(rec + 2 * i, best.w[i]);
                     const double *wr = own_rows + (gi - own_lo);
-                    for (int q = tid; q < slot * 8; q += bd)
-                        if (L.slot_on[q >> 3])
-                            __hip_atomic_store(rec + 16 + q, (unsigned long long)__double_as_longlong(wr[(size_t)q * lpw_]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();  // (P) the body has left every wave
-                if (tid == 0) {
-                    const unsigned long long db = (unsigned long long)__double_as_longlong(gd);
-                    __hip_atomic_store(rec + EKF_REC_HEAD, ((unsigned long long)tag << 32) | (db & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(rec + EKF_REC_HEAD + 1, ((unsigned long long)tag << 32) | (db >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(rec + EKF_REC_HEAD + 2, ((unsigned long long)tag << 32) | (unsigned)gi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (int q = tid; q < slot * 8; q += bd) put(rec + 2 * (16 + q), wr[(size_t)q * lpw_]);  // dead slots hold zeros
                 }
                 // every wave polls the heads itself (lane l reads workgroup l's) and may then read the winner's body
                 const int lane = tid & 63;
-                const unsigned long long *hd = (const unsigned long long *)(part + ((size_t)(epoch & 1) * dv.gmax + (lane < G ? lane : 0)) * EKF_REC_DOUBLES) + EKF_REC_HEAD;
+                const unsigned long long *hd = (const unsigned long long *)(part + ((size_t)(epoch & 1) * dv.gmax + (lane < G ? lane : 0)) * EKF_REC_DOUBLES) + 2 * EKF_REC_HEAD;
                 unsigned long long h0 = 0, h1 = 0, h2 = 0;
                 long spins = 0;
                 for (;;) {
                     h0 = __hip_atomic_load(hd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     h1 = __hip_atomic_load(hd + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     h2 = __hip_atomic_load(hd + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const bool ok = lane >= G || ((unsigned)(h0 >> 32) == tag && (unsigned)(h1 >> 32) == tag && (unsigned)(h2 >> 32) == tag);
+                    const bool ok = lane >= G || (((h0 ^ tag) >> 32) == 0 && ((h1 ^ tag) >> 32) == 0 && ((h2 ^ tag) >> 32) == 0);
                     if (__all(ok)) break;
                     if (++spins > (1L << 22)) {  // bounded: a lost workgroup must not hang the GPU
                         if (lane == 0) dv.status[b] = EKF_ERR_HIP;
@@ -689,12 +708,8 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                     d = __longlong_as_double((long long)((h1 << 32) | (h0 & 0xffffffffull)));
                     i = (int)(unsigned)(h2 & 0xffffffffull);
                 }
-                for (int off = 32; off > 0; off >>= 1) {
-                    double od = __shfl_down(d, off, 64);
-                    int oi = __shfl_down(i, off, 64), os = __shfl_down(src, off, 64);
-                    if (cand_better(od, oi, d, i)) d = od, i = oi, src = os;
-                }
-                gd = __shfl(d, 0, 64), gi = uni(__shfl(i, 0, 64)), src = uni(__shfl(src, 0, 64));
+                wave_argmin(d, i, src);
+                gd = d, gi = i;
                 epoch++;
                 STAMP(2);  // publish + poll + pick
             }
@@ -711,7 +726,6 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
             const int n_lm_after = n_lm_before + (hdr == HDR_NEW ? 1 : 0);
             if (ctrl) {
                 // bookkeeping common to all branches
-                L.slot_on[slot] = on;
                 if (lead) {
                     ekf_stats *st = &L.st;  // written back at the end of the launch
                     if (hdr == HDR_OLD) {
@@ -746,9 +760,20 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                 // with one workgroup per filter, straight from registers and the own-row cache
                 if (G > 1) {
                     const unsigned long long *wrec = (const unsigned long long *)(part + ((size_t)((epoch - 1) & 1) * dv.gmax + src) * EKF_REC_DOUBLES);
+                    const unsigned long long tag = (unsigned long long)(unsigned)(ebase + epoch) << 32;  // of the exchange just done
                     for (int q = tid; q < 16 + slot * 8; q += bd) {
-                        if (q >= 16 && !L.slot_on[(q - 16) >> 3]) continue;
-                        double v = __longlong_as_double((long long)__hip_atomic_load(wrec + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                        unsigned long long g0, g1;
+                        long spins = 0;
+                        for (;;) {  // the body may trail the head: re-read until both granules carry the tag
+                            g0 = __hip_atomic_load(wrec + 2 * q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            g1 = __hip_atomic_load(wrec + 2 * q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if ((((g0 ^ tag) | (g1 ^ tag)) >> 32) == 0) break;
+                            if (++spins > (1L << 22)) {
+                                dv.status[b] = EKF_ERR_HIP;
+                                break;
+                            }
+                        }
+                        double v = __longlong_as_double((long long)((g1 << 32) | (g0 & 0xffffffffull)));
                         if (q < 16) L.w[q] = v;
                         else L.lo_rows[q - 16] = v;
                     }
@@ -756,8 +781,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                     if (w_lo == best.lm)
                         for (int i = 0; i < 16; i++) L.w[i] = best.w[i];
                     const double *wr = own_rows + (w_lo - own_lo);
-                    for (int q = tid; q < slot * 8; q += bd)
-                        if (L.slot_on[q >> 3]) L.lo_rows[q] = wr[(size_t)q * lpw_];
+                    for (int q = tid; q < slot * 8; q += bd) L.lo_rows[q] = wr[(size_t)q * lpw_];
                 }
                 __syncthreads();  // (3) staged rows visible
                 STAMP(4);
@@ -778,8 +802,8 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                             // the slots of this set are not in Bm yet: P[lm rows, lo cols] += sum_k A_lm[.,k] B_lo[.,k] (or B_lm A_lo)
                             const double *own = own_rows + (below ? 0 : 4 * lpw_) + (lm - own_lo);
                             const double *lr = L.lo_rows + (below ? 4 : 0);
-                            for (int sl = 0; sl < slot; sl++) {
-                                if (!uni(L.slot_on[sl])) continue;
+#pragma unroll 4
+                            for (int sl = 0; sl < slot; sl++) {  // dead slots contribute exact zeros
                                 const double *o = own + (size_t)sl * 8 * lpw_, *q = lr + sl * 8;
                                 const double o00 = o[0], o01 = o[lpw_], o10 = o[2 * lpw_], o11 = o[3 * lpw_];
                                 p[0][0] += o00 * q[0] + o01 * q[1];
@@ -928,7 +952,6 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                 L.S0 = S;
                 L.invS = invS;
                 L.res0 = res;
-                L.slot_on[slot] = 1;
                 if (lead) act_c[slot] = 1;
             }
             __syncthreads();
