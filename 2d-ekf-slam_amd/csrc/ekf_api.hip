@@ -162,7 +162,10 @@ extern "C" int ekf_batch_create(ekf_handle *out, int batch, int capacity_landmar
     h->chain_wgs = G;
     dv.gmax = G;
     dv.lpw = (capacity_landmarks + G - 1) / G;
-    if ((long)dv.lpw * maxp * 64 > lds_budget) maxp = (int)(lds_budget / ((long)dv.lpw * 64));
+    if ((long)dv.lpw * maxp * 64 > lds_budget) {
+        maxp = (int)(lds_budget / ((long)dv.lpw * 64));
+        if (maxp > 1) maxp &= ~1;  // whole slot pairs
+    }
     if (maxp < 1) return set_error(EKF_ERR_BAD_ARG, "capacity too large for this batch size (one window slot does not fit LDS)");
     h->params.max_pending = maxp;  // the effective window, see ekf_window()
     dv.maxp = maxp;
