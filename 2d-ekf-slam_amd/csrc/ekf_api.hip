@@ -54,7 +54,7 @@ struct ekf_batch {
     int pending;    // slots used in cur_set
     int buf_in;     // Bm buffer the NEXT dense pass reads
     int stagger_ns;       // EKF_FLUSH_STAGGER_NS: first-generation de-phasing delay of the dense pass, -1 = automatic
-    int flush_variant;    // EKF_FLUSH_VARIANT: 0 = one wave per 64x64 tile, 1 = one wave per 32x32 quadrant
+    int flush_variant;    // EKF_FLUSH_VARIANT: 2 (default) = row-block pipelined tile, 0 = slot-major tile, 1 = one wave per 32x32 quadrant
     bool dbg_skip_flush;  // EKF_DEBUG_SKIP_FLUSH=1: timing experiments only, results are wrong
     // immediate-mode input ring (host-mapped pinned)
     double *ring_h;
@@ -224,7 +224,7 @@ extern "C" int ekf_batch_create(ekf_handle *out, int batch, int capacity_landmar
     h->pending = 0;
     h->buf_in = 0;
     h->stagger_ns = getenv("EKF_FLUSH_STAGGER_NS") ? atoi(getenv("EKF_FLUSH_STAGGER_NS")) : -1;
-    h->flush_variant = getenv("EKF_FLUSH_VARIANT") ? atoi(getenv("EKF_FLUSH_VARIANT")) : 0;
+    h->flush_variant = getenv("EKF_FLUSH_VARIANT") ? atoi(getenv("EKF_FLUSH_VARIANT")) : 2;
     h->dbg_skip_flush = getenv("EKF_DEBUG_SKIP_FLUSH") && atoi(getenv("EKF_DEBUG_SKIP_FLUSH")) != 0;
     h->script_d = nullptr;
     h->script_steps = h->script_M = h->script_has_truth = 0;
@@ -299,9 +299,11 @@ static int close_set(ekf_batch *h) {
             hipEvent_t e0 = h->prof_pool[h->prof_used++], e1 = h->prof_pool[h->prof_used++];
             // start/stop events ride on the dispatch packet itself: no extra barrier packets
             if (h->flush_variant == 1) hipExtLaunchKernelGGL(k_flush_q, grid, dim3(256), 0, h->s_chain, e0, e1, 0, h->dv, nT_hi, h->cur_set, h->pending, h->buf_in);
+            else if (h->flush_variant == 2) hipExtLaunchKernelGGL(k_flush_rb, grid, dim3(256), 0, h->s_chain, e0, e1, 0, h->dv, nT_hi, h->cur_set, h->pending, h->buf_in);
             else hipExtLaunchKernelGGL(k_flush, grid, dim3(256), 0, h->s_chain, e0, e1, 0, h->dv, nT_hi, h->cur_set, h->pending, h->buf_in, stagger_ticks);
         } else {
             if (h->flush_variant == 1) hipLaunchKernelGGL(k_flush_q, grid, dim3(256), 0, h->s_chain, h->dv, nT_hi, h->cur_set, h->pending, h->buf_in);
+            else if (h->flush_variant == 2) hipLaunchKernelGGL(k_flush_rb, grid, dim3(256), 0, h->s_chain, h->dv, nT_hi, h->cur_set, h->pending, h->buf_in);
             else hipLaunchKernelGGL(k_flush, grid, dim3(256), 0, h->s_chain, h->dv, nT_hi, h->cur_set, h->pending, h->buf_in, stagger_ticks);
         }
     }

@@ -1107,6 +1107,149 @@ __global__ __launch_bounds__(256, 2) void k_flush(EkfDev dv, int nT_hi, int set,
     }
 }
 
+// One tile of the row-block dense pass with NP slot pairs resident (the caller pads the live list with the
+// all-zero pair): three row-blocks of the tile in flight, the fourth is requested into the registers of the
+// first once that has been stored.
+template <int NP>
+__device__ __forceinline__ void flush_tile_rb(double *tp, const double *FA, const double *FB, unsigned lo, unsigned live, int zero_slot, size_t slot_stride) {
+        // the common case (windows up to 16): three row-blocks of the tile in flight, the fourth is requested
+        // into the registers of the first once that has been stored
+        size_t mo[NP];
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+            int m = live ? __builtin_ctz(live) : zero_slot;
+            live &= live - 1;
+            mo[p] = (size_t)m * slot_stride;
+        }
+        double bq[NP][4], a[2][NP];
+        double4_t blk[3][4];
+#pragma unroll
+        for (int p = 0; p < NP; p++)
+#pragma unroll
+            for (int cc = 0; cc < 4; cc++) bq[p][cc] = (FB + mo[p] + cc * 64)[lo];
+#pragma unroll
+        for (int p = 0; p < NP; p++) a[0][p] = (FA + mo[p])[lo];
+#pragma unroll
+        for (int p = 0; p < NP; p++) a[1][p] = (FA + mo[p] + 64)[lo];
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int cc = 0; cc < 4; cc++) {
+                const int ch = r * 4 + cc;
+                double2_t l2 = *(const double2_t *)(tp + ch * 256);
+                double2_t h2 = *(const double2_t *)(tp + ch * 256 + 128);
+                blk[r][cc] = (double4_t){l2.x, l2.y, h2.x, h2.y};
+            }
+#pragma unroll
+        for (int rc = 0; rc < 4; rc++) {
+            const int k = rc % 3;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int p = 0; p < NP; p++)
+#pragma unroll
+                for (int cc = 0; cc < 4; cc++) blk[k][cc] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[rc & 1][p], bq[p][cc], blk[k][cc], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (rc + 2 < 4) {
+#pragma unroll
+                for (int p = 0; p < NP; p++) a[rc & 1][p] = (FA + mo[p] + (rc + 2) * 64)[lo];
+            }
+#pragma unroll
+            for (int cc = 0; cc < 4; cc++) {
+                const int ch = rc * 4 + cc;
+                *(double2_t *)(tp + ch * 256) = (double2_t){blk[k][cc].x, blk[k][cc].y};
+                *(double2_t *)(tp + ch * 256 + 128) = (double2_t){blk[k][cc].z, blk[k][cc].w};
+            }
+            if (rc == 0) {
+#pragma unroll
+                for (int cc = 0; cc < 4; cc++) {
+                    const int ch = 12 + cc;
+                    double2_t l2 = *(const double2_t *)(tp + ch * 256);
+                    double2_t h2 = *(const double2_t *)(tp + ch * 256 + 128);
+                    blk[0][cc] = (double4_t){l2.x, l2.y, h2.x, h2.y};
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+}
+
+// Row-block form of the dense pass (the default; EKF_FLUSH_VARIANT=0 selects k_flush): the same wave-per-tile mapping and the same
+// arithmetic, but the contraction runs row-block by row-block (16 rows x 64 columns = 4 chains) over ALL live
+// slot pairs, so that a row-block is stored as soon as it is finished: the stores of row-block r overlap the
+// MFMAs of r+1 instead of waiting behind the whole tile's contraction.  The B operands of up to 8 pairs stay in
+// registers (64), the A operands are double-buffered one row-block ahead (32), the tile is the accumulator
+// (128).  Every load that a later wait names is issued before the stores that precede that wait in program
+// order, except the A operands two row-blocks ahead (their wait is two MFMA blocks later).
+// More than 8 live pairs (windows above 16) fall back to the slot-major walk of k_flush.
+__global__ __launch_bounds__(256, 2) void k_flush_rb(EkfDev dv, int nT_hi, int set, int nslots, int buf) {
+    int b = blockIdx.y;
+    int lane = threadIdx.x & 63;
+    int u = blockIdx.x * 4 + (threadIdx.x >> 6);
+    int total = nT_hi * (nT_hi + 1) / 2;
+    if (u >= total) return;
+    int I = (int)(((2.0f * nT_hi + 1.0f) - sqrtf((2.0f * nT_hi + 1.0f) * (2.0f * nT_hi + 1.0f) - 8.0f * (float)u)) * 0.5f);
+    if (I < 0) I = 0;
+    if (I > nT_hi - 1) I = nT_hi - 1;
+    while (I > 0 && I * nT_hi - (I * (I - 1)) / 2 > u) I--;
+    while ((I + 1) * nT_hi - ((I + 1) * I) / 2 <= u) I++;
+    int J = I + (u - (I * nT_hi - (I * (I - 1)) / 2));
+    int nT = (2 * dv.n_lm_flush[(size_t)b * 2 + set] + 63) >> 6;
+    if (J >= nT) return;
+
+    const int *active = dv.slot_active + ((size_t)b * 2 + set) * dv.maxp;
+    size_t t = (size_t)I * dv.T - ((size_t)I * (I - 1)) / 2 + (size_t)(J - I);
+    double *tp = dv.Bm[buf] + (size_t)b * dv.bm_stride + t * 4096 + (size_t)lane * 2;
+    // uniform base (SGPRs) + one per-lane 32-bit offset shared by every operand load
+    const double *FA = dv.FA + ((size_t)b * 2 + set) * dv.f_stride + (size_t)64 * uni(I) * 4;
+    const double *FB = dv.FB + ((size_t)b * 2 + set) * dv.f_stride + (size_t)64 * uni(J) * 4;
+    const unsigned lo = (unsigned)((lane & 15) * 4 + (lane >> 4));
+    const size_t slot_stride = (size_t)dv.rows * 4;
+    const int zero_slot = dv.maxpairs;
+
+    unsigned live = 0;  // slot PAIRS with at least one live slot (a dead half holds zeros)
+    for (int m = 0; m < nslots; m++) live |= (active[m] ? 1u : 0u) << (m >> 1);
+    live = (unsigned)uni((int)live);  // wave-uniform: pair offsets live in SGPRs
+    const int npl = __builtin_popcount(live);
+
+    if (npl <= 8) {  // windows up to 16
+        if (npl <= 2) flush_tile_rb<2>(tp, FA, FB, lo, live, zero_slot, slot_stride);
+        else if (npl <= 4) flush_tile_rb<4>(tp, FA, FB, lo, live, zero_slot, slot_stride);
+        else flush_tile_rb<8>(tp, FA, FB, lo, live, zero_slot, slot_stride);
+        return;
+    }
+    // windows above 16: the slot-major walk of k_flush, two pairs per iteration
+    double4_t acc[16];
+#pragma unroll
+    for (int ch = 0; ch < 16; ch++) {
+        double2_t l2 = *(const double2_t *)(tp + ch * 256);
+        double2_t h2 = *(const double2_t *)(tp + ch * 256 + 128);
+        acc[ch] = (double4_t){l2.x, l2.y, h2.x, h2.y};
+    }
+    for (int it = 0; it < (npl + 1) / 2; it++) {
+        double a0[4], b0[4], a1[4], b1[4];
+        int m0 = live ? __builtin_ctz(live) : zero_slot;
+        live &= live - 1;
+        int m1 = live ? __builtin_ctz(live) : zero_slot;
+        live &= live - 1;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            a0[q] = (FA + (size_t)m0 * slot_stride + q * 64)[lo], b0[q] = (FB + (size_t)m0 * slot_stride + q * 64)[lo];
+            a1[q] = (FA + (size_t)m1 * slot_stride + q * 64)[lo], b1[q] = (FB + (size_t)m1 * slot_stride + q * 64)[lo];
+        }
+#pragma unroll
+        for (int rc = 0; rc < 4; rc++)
+#pragma unroll
+            for (int cc = 0; cc < 4; cc++) {
+                acc[rc * 4 + cc] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[rc], b0[cc], acc[rc * 4 + cc], 0, 0, 0);
+                acc[rc * 4 + cc] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[rc], b1[cc], acc[rc * 4 + cc], 0, 0, 0);
+            }
+    }
+#pragma unroll
+    for (int ch = 0; ch < 16; ch++) {
+        *(double2_t *)(tp + ch * 256) = (double2_t){acc[ch].x, acc[ch].y};
+        *(double2_t *)(tp + ch * 256 + 128) = (double2_t){acc[ch].z, acc[ch].w};
+    }
+}
+
 // Variant of the dense pass: one wave per 32x32 QUADRANT of a tile (4 chains, 8 KiB read + 8 KiB
 // written, 4 MFMAs per slot).  A quarter of the registers per wave, so up to 8 waves per SIMD cover
 // each other's HBM latency and MFMA time; costs twice the operand traffic from L2 per element.
