@@ -43,7 +43,14 @@ struct ekf_batch {
     EkfDev dv;
     ekf_params params;
     int device;
-    hipStream_t s_chain;  // the one stream: chain kernels and dense passes alternate on it
+    hipStream_t s_chain;  // chain kernels (and, without overlap, the dense passes too)
+    hipStream_t s_flush;  // overlap: the dense passes; == s_chain otherwise
+    bool overlap;         // a window's dense pass runs beside the next window's chain kernels (two slot sets, two Bm buffers)
+    int prev_pending;     // overlap: slots of the other set whose dense pass has been launched but is not in Bm[buf_in]
+    hipEvent_t ev_chain, ev_flush[2];
+    hipEvent_t ev_pass[2];  // the stop event actually attached to a pass: ev_flush[i] or a profiling event
+    int ev_idx;           // ev_flush[ev_idx] belongs to the dense pass launched last
+    bool chain_signalled; // the last chain launch carried ev_chain as its stop event
     int chain_wgs;        // k_chain workgroups per filter
     size_t chain_lds;     // dynamic LDS of a k_chain launch: the own-row cache
     size_t device_bytes;
@@ -52,7 +59,7 @@ struct ekf_batch {
     int n_lm_hi;    // upper bound on max_b n_lm[b]
     int cur_set;    // slot set being filled
     int pending;    // slots used in cur_set
-    int buf_in;     // Bm buffer the NEXT dense pass reads
+    int buf_in;     // Bm buffer the chain kernels read (complete up to the sets still open or in flight)
     int stagger_ns;       // EKF_FLUSH_STAGGER_NS: first-generation de-phasing delay of the dense pass, -1 = automatic
     int flush_variant;    // EKF_FLUSH_VARIANT: 2 (default) = row-block pipelined tile, 0 = slot-major tile, 1 = one wave per 32x32 quadrant
     bool dbg_skip_flush;  // EKF_DEBUG_SKIP_FLUSH=1: timing experiments only, results are wrong
@@ -91,6 +98,7 @@ extern "C" void ekf_default_params(ekf_params *p) {
     p->cond_limit = 80.0;
     p->max_pending = 16;
     p->log_capacity = 4096;
+    p->overlap = -1;
 }
 
 template <typename T>
@@ -151,8 +159,24 @@ extern "C" int ekf_batch_create(ekf_handle *out, int batch, int capacity_landmar
     const long lds_budget = (long)prop.sharedMemPerBlock - 12288;
     if (lds_budget < 64 * 64) return set_error(EKF_ERR_NO_DEVICE, "device reports too little LDS per workgroup");
     int maxp = h->params.max_pending;
+    // overlap (params.overlap, EKF_OVERLAP overrides): automatic = on when two windows of every landmark's slot rows fit
+    // the LDS of at most 64 resident workgroups per filter, i.e. when it does not cost window length
+    int want_overlap = getenv("EKF_OVERLAP") ? atoi(getenv("EKF_OVERLAP")) : h->params.overlap;
+    if (want_overlap < 0) {
+        int g_max = EKF_CHAIN_MAX_WGS < 256 / batch ? EKF_CHAIN_MAX_WGS : 256 / batch;
+        if (g_max < 1) g_max = 1;
+        long lpw_min = (capacity_landmarks + g_max - 1) / g_max;
+        want_overlap = (lpw_min * maxp * 2 * 64 <= lds_budget) ? 1 : 0;
+        // ... and when a dense pass is long enough to be worth hiding (P_LL of the whole batch >= 128 MB, a pass of
+        // about 45 us): below that the chain kernels dominate and the second window's bookkeeping only costs
+        size_t T = (2 * (size_t)capacity_landmarks + 63) / 64;
+        if ((size_t)batch * (T * (T + 1) / 2) * 4096 * sizeof(double) < ((size_t)128 << 20)) want_overlap = 0;
+    }
+    h->overlap = want_overlap != 0;
+    h->params.overlap = h->overlap ? 1 : 0;
+    const int sets_in_lds = h->overlap ? 2 : 1;  // overlap: the set being folded by the dense pass in flight is still needed
     int G = (capacity_landmarks + max_workers - 1) / max_workers;
-    int G_lds = (int)(((long)capacity_landmarks * maxp * 64 + lds_budget - 1) / lds_budget);
+    int G_lds = (int)(((long)capacity_landmarks * maxp * sets_in_lds * 64 + lds_budget - 1) / lds_budget);
     if (G_lds > G) G = G_lds;
     if (G > EKF_CHAIN_MAX_WGS) G = EKF_CHAIN_MAX_WGS;
     if (G * batch > 256) G = 256 / batch;
@@ -162,8 +186,8 @@ extern "C" int ekf_batch_create(ekf_handle *out, int batch, int capacity_landmar
     h->chain_wgs = G;
     dv.gmax = G;
     dv.lpw = (capacity_landmarks + G - 1) / G;
-    if ((long)dv.lpw * maxp * 64 > lds_budget) {
-        maxp = (int)(lds_budget / ((long)dv.lpw * 64));
+    if ((long)dv.lpw * maxp * sets_in_lds * 64 > lds_budget) {
+        maxp = (int)(lds_budget / ((long)dv.lpw * sets_in_lds * 64));
         if (maxp > 1) maxp &= ~1;  // whole slot pairs
     }
     if (maxp < 1) return set_error(EKF_ERR_BAD_ARG, "capacity too large for this batch size (one window slot does not fit LDS)");
@@ -171,7 +195,7 @@ extern "C" int ekf_batch_create(ekf_handle *out, int batch, int capacity_landmar
     dv.maxp = maxp;
     dv.maxpairs = (dv.maxp + 1) / 2;
     dv.f_stride = (size_t)(dv.maxpairs + 1) * dv.rows * 4;
-    h->chain_lds = (size_t)dv.lpw * maxp * 64;
+    h->chain_lds = (size_t)dv.lpw * maxp * sets_in_lds * 64;
     HIP_TRY(hipFuncSetAttribute((const void *)k_chain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_budget));  // one setting for every handle
     int workers = (dv.lpw + 63) / 64 * 64;
     if (workers > max_workers) workers = max_workers;
@@ -182,7 +206,8 @@ extern "C" int ekf_batch_create(ekf_handle *out, int batch, int capacity_landmar
     HIP_TRY(dev_alloc_zero(&dv.R, B * 3 * dv.xs, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.D, B * 3 * dv.dn, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.Bm[0], B * dv.bm_stride, &h->device_bytes, s));
-    dv.Bm[1] = dv.Bm[0];  // one buffer: the dense pass runs in place (k_chain keeps its two-buffer interface)
+    if (h->overlap) HIP_TRY(dev_alloc_zero(&dv.Bm[1], B * dv.bm_stride, &h->device_bytes, s));  // the dense pass goes buffer to buffer
+    else dv.Bm[1] = dv.Bm[0];  // one buffer: the dense pass runs in place
     HIP_TRY(dev_alloc_zero(&dv.FA, B * 2 * dv.f_stride, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.FB, B * 2 * dv.f_stride, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.n_lm, B, &h->device_bytes, s));
@@ -223,6 +248,39 @@ extern "C" int ekf_batch_create(ekf_handle *out, int batch, int capacity_landmar
     h->cur_set = 0;
     h->pending = 0;
     h->buf_in = 0;
+    h->prev_pending = 0;
+    h->ev_idx = 0;
+    h->chain_signalled = false;
+    h->ev_pass[0] = h->ev_pass[1] = nullptr;
+    h->s_flush = h->s_chain;
+    if (h->overlap) {
+        // The chain kernel needs its workgroups' CUs the moment it is launched; a dense pass that owns every CU
+        // would make it queue behind whole tiles.  The dense pass therefore gets a stream restricted to the CUs
+        // the chain does not need (EKF_CHAIN_CUS overrides the number kept free).
+        int keep = getenv("EKF_CHAIN_CUS") ? atoi(getenv("EKF_CHAIN_CUS")) : (G * batch < 32 ? G * batch : 32);  // (measured: 32 beats 64 even for 64 workgroups)
+        int ncu = prop.multiProcessorCount;
+        if (keep > ncu / 2) keep = ncu / 2;
+        hipError_t em = hipErrorUnknown;
+        if (keep > 0) {
+            std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+            // CU i sits on XCD i % 8 (round-robin numbering): free the same share of every XCD
+            int per_xcd = (keep + 7) / 8, xcds = 8, freed[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int i = 0; i < ncu; i++) {
+                int xc = i % xcds;
+                bool chain_cu = freed[xc] < per_xcd;
+                if (chain_cu) freed[xc]++;
+                else mask[i / 32] |= 1u << (i % 32);
+            }
+            em = hipExtStreamCreateWithCUMask(&h->s_flush, (uint32_t)mask.size(), mask.data());
+        }
+        if (em != hipSuccess) {
+            (void)hipGetLastError();
+            HIP_TRY(hipStreamCreateWithFlags(&h->s_flush, hipStreamNonBlocking));
+        }
+        HIP_TRY(hipEventCreate(&h->ev_chain));  // (stop events of dispatch packets)
+        for (int i = 0; i < 2; i++) HIP_TRY(hipEventCreate(&h->ev_flush[i]));
+        h->chain_signalled = false;
+    }
     h->stagger_ns = getenv("EKF_FLUSH_STAGGER_NS") ? atoi(getenv("EKF_FLUSH_STAGGER_NS")) : -1;
     h->flush_variant = getenv("EKF_FLUSH_VARIANT") ? atoi(getenv("EKF_FLUSH_VARIANT")) : 2;
     h->dbg_skip_flush = getenv("EKF_DEBUG_SKIP_FLUSH") && atoi(getenv("EKF_DEBUG_SKIP_FLUSH")) != 0;
@@ -242,6 +300,12 @@ extern "C" int ekf_destroy(ekf_handle h) {
     if (!h) return EKF_OK;
     hipSetDevice(h->device);
     hipStreamSynchronize(h->s_chain);
+    if (h->overlap) {
+        hipStreamSynchronize(h->s_flush);
+        hipEventDestroy(h->ev_chain), hipEventDestroy(h->ev_flush[0]), hipEventDestroy(h->ev_flush[1]);
+        hipStreamDestroy(h->s_flush);
+        hipFree(h->dv.Bm[1]);
+    }
     for (auto &g : h->graphs) hipGraphExecDestroy(g.exec);
     EkfDev &dv = h->dv;
     hipFree(dv.x), hipFree(dv.R), hipFree(dv.D), hipFree(dv.Bm[0]), hipFree(dv.FA), hipFree(dv.FB);
@@ -262,6 +326,7 @@ extern "C" int ekf_destroy(ekf_handle h) {
 
 extern "C" int ekf_batch_size(ekf_handle h) { return h ? h->dv.B : EKF_ERR_BAD_ARG; }
 extern "C" int ekf_window(ekf_handle h) { return h ? h->dv.maxp : EKF_ERR_BAD_ARG; }
+extern "C" int ekf_overlap(ekf_handle h) { return h ? (h->overlap ? 1 : 0) : EKF_ERR_BAD_ARG; }
 
 extern "C" int ekf_capacity(ekf_handle h) { return h ? h->dv.Ncap : EKF_ERR_BAD_ARG; }
 extern "C" void *ekf_stream(ekf_handle h) { return h ? (void *)h->s_chain : nullptr; }
@@ -280,43 +345,70 @@ static int check_launch() {
 }
 
 // ---- chain / dense-pass alternation ------------------------------------------------------------------
-// Close the slot set being filled: one dense pass folds it into Bm in place, in stream order after
-// the chain kernels that wrote the set.  The chain continues into the other set.
+// Close the slot set being filled and hand it to a dense pass; the chain continues into the other set.
+//  * without overlap: the pass folds the set into Bm in place, in stream order behind the chain kernels.
+//  * with overlap: pass k runs on its own stream, Bm[fin] -> Bm[fin ^ 1], while the chain kernels of window
+//    k+1 read Bm[fin] and fold set k themselves (n_prev).  Pass k starts after the chain kernels of window k
+//    (ev_chain) and, by stream order, after pass k-1 whose output it reads; the chain kernels of window k+1
+//    start after pass k-1 (they read its output and overwrite the slot rows it read).
 static int close_set(ekf_batch *h) {
     if (h->pending == 0) return EKF_OK;
     int nT_hi = (2 * h->n_lm_hi + 63) / 64;
-    if (nT_hi > 0 && !h->dbg_skip_flush) {
+    const int fin = (h->overlap && h->prev_pending > 0) ? h->buf_in ^ 1 : h->buf_in;
+    const int fout = h->overlap ? fin ^ 1 : fin;
+    hipStream_t sf = h->s_flush;
+    if (h->overlap) {
+        if (!h->chain_signalled) HIP_TRY(hipEventRecord(h->ev_chain, h->s_chain));
+        h->chain_signalled = false;
+        HIP_TRY(hipStreamWaitEvent(sf, h->ev_chain, 0));
+    }
+    if ((nT_hi > 0 && !h->dbg_skip_flush) || h->overlap) {
+        if (nT_hi < 1) nT_hi = 1;
         int total = nT_hi * (nT_hi + 1) / 2;
-        dim3 grid(h->flush_variant == 1 ? total : cdiv(total, 4), h->dv.B);
+        const int variant = h->overlap ? 2 : h->flush_variant;  // only the row-block form goes buffer to buffer
+        dim3 grid(variant == 1 ? total : cdiv(total, 4), h->dv.B);
         // half a tile period: about 4 us of HBM share plus 0.24 us of MFMA per slot (EKF_FLUSH_STAGGER_NS overrides)
         int stagger_ticks = h->stagger_ns >= 0 ? h->stagger_ns / 10 : (400 + 12 * h->pending);
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (h->overlap) e1 = h->ev_flush[h->ev_idx ^ 1];  // pass k's completion, signalled by its own dispatch packet
         if (h->prof_flush) {
             while (h->prof_pool.size() < h->prof_used + 2) {
                 hipEvent_t e;
                 HIP_TRY(hipEventCreate(&e));
                 h->prof_pool.push_back(e);
             }
-            hipEvent_t e0 = h->prof_pool[h->prof_used++], e1 = h->prof_pool[h->prof_used++];
-            // start/stop events ride on the dispatch packet itself: no extra barrier packets
-            if (h->flush_variant == 1) hipExtLaunchKernelGGL(k_flush_q, grid, dim3(256), 0, h->s_chain, e0, e1, 0, h->dv, nT_hi, h->cur_set, h->pending, h->buf_in);
-            else if (h->flush_variant == 2) hipExtLaunchKernelGGL(k_flush_rb, grid, dim3(256), 0, h->s_chain, e0, e1, 0, h->dv, nT_hi, h->cur_set, h->pending, h->buf_in);
-            else hipExtLaunchKernelGGL(k_flush, grid, dim3(256), 0, h->s_chain, e0, e1, 0, h->dv, nT_hi, h->cur_set, h->pending, h->buf_in, stagger_ticks);
-        } else {
-            if (h->flush_variant == 1) hipLaunchKernelGGL(k_flush_q, grid, dim3(256), 0, h->s_chain, h->dv, nT_hi, h->cur_set, h->pending, h->buf_in);
-            else if (h->flush_variant == 2) hipLaunchKernelGGL(k_flush_rb, grid, dim3(256), 0, h->s_chain, h->dv, nT_hi, h->cur_set, h->pending, h->buf_in);
-            else hipLaunchKernelGGL(k_flush, grid, dim3(256), 0, h->s_chain, h->dv, nT_hi, h->cur_set, h->pending, h->buf_in, stagger_ticks);
+            e0 = h->prof_pool[h->prof_used++], e1 = h->prof_pool[h->prof_used++];
         }
+        h->ev_pass[h->ev_idx ^ 1] = e1;
+        // (start/stop events ride on the dispatch packet itself: no extra barrier packets)
+        if (variant == 1) hipExtLaunchKernelGGL(k_flush_q, grid, dim3(256), 0, sf, e0, e1, 0, h->dv, nT_hi, h->cur_set, h->pending, fin);
+        else if (variant == 2) hipExtLaunchKernelGGL(k_flush_rb, grid, dim3(256), 0, sf, e0, e1, 0, h->dv, nT_hi, h->cur_set, h->pending, fin, fout);
+        else hipExtLaunchKernelGGL(k_flush, grid, dim3(256), 0, sf, e0, e1, 0, h->dv, nT_hi, h->cur_set, h->pending, fin, stagger_ticks);
+    }
+    if (h->overlap) {
+        if (h->prev_pending > 0) HIP_TRY(hipStreamWaitEvent(h->s_chain, h->ev_pass[h->ev_idx], 0));  // pass k-1
+        h->ev_idx ^= 1;  // ev_flush[ev_idx] is pass k's stop event
+        if (getenv("EKF_OVERLAP_SERIAL")) HIP_TRY(hipStreamWaitEvent(h->s_chain, h->ev_pass[h->ev_idx], 0));  // experiment: no concurrency
+        h->buf_in = fin;
+        h->prev_pending = h->pending;
     }
     h->cur_set ^= 1;
     h->pending = 0;
     return check_launch();
 }
 
-// Everything folded into Bm[buf_in], stream idle.
+// Everything folded into Bm[buf_in], streams idle.
 static int settle(ekf_batch *h) {
     int rc = close_set(h);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(h->s_chain));
+    if (h->overlap) {
+        HIP_TRY(hipStreamSynchronize(h->s_flush));
+        if (h->prev_pending > 0) {
+            h->buf_in ^= 1;  // the last pass's output
+            h->prev_pending = 0;
+        }
+    }
     return EKF_OK;
 }
 
@@ -338,8 +430,12 @@ static int launch_ops(ekf_batch *h, const double *in, const int *cursor, int k0,
             if (rc) return rc;
             continue;
         }
-        hipLaunchKernelGGL(k_chain, dim3(h->chain_wgs, h->dv.B), dim3(h->chain_threads), h->chain_lds, h->s_chain, h->dv, in, cursor,
-                           k0 + start, i - start, h->pending, h->cur_set, h->buf_in);
+        // overlap: the launch that fills the set signals ev_chain from its own dispatch packet (no marker packet)
+        const bool closes = h->overlap && used == h->dv.maxp;
+        hipExtLaunchKernelGGL(k_chain, dim3(h->chain_wgs, h->dv.B), dim3(h->chain_threads), h->chain_lds, h->s_chain, nullptr,
+                              closes ? h->ev_chain : nullptr, 0, h->dv, in, cursor, k0 + start, i - start, h->pending, h->cur_set, h->buf_in,
+                              h->prev_pending);
+        h->chain_signalled = closes;
         h->pending = used;
         if (used == h->dv.maxp) {
             int rc = close_set(h);
@@ -514,6 +610,7 @@ extern "C" int ekf_sync(ekf_handle h) {
     if (!h) return set_error(EKF_ERR_BAD_ARG, "null handle");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->s_chain));
+    if (h->overlap) HIP_TRY(hipStreamSynchronize(h->s_flush));
     for (int b = 0; b < h->dv.B; b++)
         if (h->mirror_h[b].status != 0) return set_error(h->mirror_h[b].status, "a New landmark did not fit capacity_landmarks");
     return EKF_OK;
@@ -674,6 +771,7 @@ extern "C" int ekf_set_state(ekf_handle h, int index, const double *x, const dou
     if (e == hipSuccess) e = hipMemsetAsync(dv.R + b * 3 * dv.xs, 0, sizeof(double) * 3 * dv.xs, s);
     if (e == hipSuccess) e = hipMemsetAsync(dv.D + b * 3 * dv.dn, 0, sizeof(double) * 3 * dv.dn, s);
     if (e == hipSuccess) e = hipMemsetAsync(dv.Bm[0] + b * dv.bm_stride, 0, sizeof(double) * dv.bm_stride, s);
+    if (e == hipSuccess && h->overlap) e = hipMemsetAsync(dv.Bm[1] + b * dv.bm_stride, 0, sizeof(double) * dv.bm_stride, s);
     if (e == hipSuccess) e = hipMemsetAsync(dv.FA + b * 2 * dv.f_stride, 0, sizeof(double) * 2 * dv.f_stride, s);
     if (e == hipSuccess) e = hipMemsetAsync(dv.FB + b * 2 * dv.f_stride, 0, sizeof(double) * 2 * dv.f_stride, s);
     if (e == hipSuccess) {
@@ -698,7 +796,8 @@ extern "C" int ekf_broadcast_state(ekf_handle h) {
         HIP_TRY(hipMemcpyAsync(dv.x + (size_t)b * dv.xs, dv.x, sizeof(double) * dv.xs, hipMemcpyDeviceToDevice, s));
         HIP_TRY(hipMemcpyAsync(dv.R + (size_t)b * 3 * dv.xs, dv.R, sizeof(double) * 3 * dv.xs, hipMemcpyDeviceToDevice, s));
         HIP_TRY(hipMemcpyAsync(dv.D + (size_t)b * 3 * dv.dn, dv.D, sizeof(double) * 3 * dv.dn, hipMemcpyDeviceToDevice, s));
-        HIP_TRY(hipMemcpyAsync(dv.Bm[0] + (size_t)b * dv.bm_stride, dv.Bm[0], sizeof(double) * dv.bm_stride, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipMemcpyAsync(dv.Bm[h->buf_in] + (size_t)b * dv.bm_stride, dv.Bm[h->buf_in], sizeof(double) * dv.bm_stride, hipMemcpyDeviceToDevice, s));
+        if (h->overlap) HIP_TRY(hipMemsetAsync(dv.Bm[h->buf_in ^ 1] + (size_t)b * dv.bm_stride, 0, sizeof(double) * dv.bm_stride, s));  // no stale tiles beyond the copied map
         HIP_TRY(hipMemcpyAsync(dv.FA + (size_t)b * 2 * dv.f_stride, dv.FA, sizeof(double) * 2 * dv.f_stride, hipMemcpyDeviceToDevice, s));
         HIP_TRY(hipMemcpyAsync(dv.FB + (size_t)b * 2 * dv.f_stride, dv.FB, sizeof(double) * 2 * dv.f_stride, hipMemcpyDeviceToDevice, s));
         HIP_TRY(hipMemcpyAsync(dv.slot_active + (size_t)b * 2 * dv.maxp, dv.slot_active, sizeof(int) * 2 * dv.maxp, hipMemcpyDeviceToDevice, s));
@@ -791,7 +890,7 @@ extern "C" int ekf_script_run(ekf_handle h, int first_step, int n_steps, int use
     HIP_TRY(hipSetDevice(h->device));
     int ops = ops_per_step(h);
     int s = first_step, end = first_step + n_steps;
-    if (use_graph) {
+    if (use_graph && !h->overlap) {  // (the two-stream pipeline is not captured: plain launches)
         int S = graph_block_steps(h);
         if (end - s >= S) {
             // a graph starts from the settled state (its predecessor in the stream has fully finished)
@@ -864,6 +963,7 @@ extern "C" int ekf_timer_start(ekf_handle h) {
 extern "C" int ekf_timer_stop(ekf_handle h, double *ms_out) {
     if (!h || !ms_out) return set_error(EKF_ERR_BAD_ARG, "null argument");
     HIP_TRY(hipSetDevice(h->device));
+    if (h->overlap && h->prev_pending > 0) HIP_TRY(hipStreamWaitEvent(h->s_chain, h->ev_pass[h->ev_idx], 0));  // the pass in flight counts
     HIP_TRY(hipEventRecord(h->t1, h->s_chain));
     HIP_TRY(hipEventSynchronize(h->t1));
     float ms = 0;
@@ -882,6 +982,7 @@ extern "C" int ekf_flush_profile_read(ekf_handle h, long long *launches_out, dou
     if (!h) return set_error(EKF_ERR_BAD_ARG, "null handle");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->s_chain));
+    if (h->overlap) HIP_TRY(hipStreamSynchronize(h->s_flush));
     for (size_t i = 0; i + 1 < h->prof_used; i += 2) {
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, h->prof_pool[i], h->prof_pool[i + 1]));

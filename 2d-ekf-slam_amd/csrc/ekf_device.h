@@ -28,12 +28,12 @@
 #define EKF_MAX_PENDING 32
 #define EKF_MAX_PAIRS (EKF_MAX_PENDING / 2)
 #define EKF_CHAIN_MAX_THREADS 256 /* one control wave + up to 192 workers: one wave per SIMD, 512-VGPR budget */
-#define EKF_CHAIN_MAX_WGS 32 /* workgroups sharing one filter in k_chain */
+#define EKF_CHAIN_MAX_WGS 64 /* workgroups sharing one filter in k_chain: one lane of a wave polls each */
 #define EKF_CHAIN_MAX_OPS 64 /* operations per k_chain launch */
 // one workgroup's record of a cross-workgroup arg-min exchange.  Every value is two 8-byte granules
 // {32 payload bits, 32-bit tag}: winner data = values [0,16), the winner's rows of every slot = values
-// [16, 16 + 8*maxp), head {d, landmark} = values EKF_REC_HEAD, EKF_REC_HEAD + 1; padded to whole 128-byte lines
-#define EKF_REC_HEAD (16 + 8 * EKF_MAX_PENDING)
+// of both open windows [16, 16 + 8*2*maxp), head {d, landmark} = values EKF_REC_HEAD, EKF_REC_HEAD + 1; padded to whole 128-byte lines
+#define EKF_REC_HEAD (16 + 8 * 2 * EKF_MAX_PENDING)
 #define EKF_REC_DOUBLES (2 * EKF_REC_HEAD + 16)
 
 // op records: 8 doubles per (op, filter); r[7] is the type

@@ -99,7 +99,7 @@ struct ChainLds {
     double KR[6], TR[6];                 // compass: rows 0..2 of K and of K*S in column 0 (kalmanfilter.cpp:118)
     double S0, invS, res0;               // compass: S, 1/S, residual
     // rows of the matched landmark in every slot of the set being filled, [slot][side A/B][row e][k] (dead slots: zeros)
-    double lo_rows[EKF_MAX_PENDING * 8];
+    alignas(16) double lo_rows[2 * EKF_MAX_PENDING * 8];
 };
 
 // Header of the Old branch (Update.cpp:181-189): a pure function of the heading the sweep ran with and of the
@@ -217,6 +217,10 @@ __device__ __forceinline__ void filter_barrier(int *bar, int target, int *status
 // only workgroup 0 writes logs, statistics, slot flags and, at the end, the robot state.
 //   in/cursor/k0/nops : the operation list
 //   slot0             : first free slot of set `set`
+//   n_prev            : > 0 while the other set (its first n_prev slots) is being folded by a dense pass that
+//                       reads Bm[buf_read] and writes the other buffer: those slots are not in Bm[buf_read] either.
+//                       The LDS copy of the own rows and the exchanged rows cover n_prev + slot "virtual" slots,
+//                       the other set's first.
 //   buf_read          : Bm buffer to read P_LL columns from
 // Dynamic LDS: every landmark's own rows of every slot of the set being filled (64 bytes per landmark and
 // slot, component-major so that a wave reads one component of consecutive landmarks conflict-free); the fold
@@ -309,7 +313,7 @@ __device__ __forceinline__ void sweep_one(int lm, const LmState &st, double z0, 
 }
 
 __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, const double *in, const int *cursor, int k0,
-                                                                int nops, int slot0, int set, int buf_read) {
+                                                                int nops, int slot0, int set, int buf_read, int n_prev) {
     __shared__ ChainLds L;
     __shared__ double recs[EKF_CHAIN_MAX_OPS * 8];
     extern __shared__ double own_rows[];  // [slot][component 0..7 = A00 A01 A10 A11 B00 B01 B10 B11][local landmark]
@@ -377,7 +381,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
     auto write_slot = [=](int lm, int slot, double a00, double a01, double a10, double a11, double b00, double b01, double b10, double b11) {
         const size_t wo = CK(off_c + pair_offset(rows_, 2 * lm, slot >> 1), lim_F - 7) - off_c;
         double *fa = FAc + wo, *fb = FBc + wo;
-        double *cr = own_rows + (size_t)slot * 8 * lpw_ + (lm - own_lo);
+        double *cr = own_rows + (size_t)(n_prev + slot) * 8 * lpw_ + (lm - own_lo);
         cr[0] = a00, cr[lpw_] = a01, cr[2 * lpw_] = a10, cr[3 * lpw_] = a11;
         cr[4 * lpw_] = b00, cr[5 * lpw_] = b01, cr[6 * lpw_] = b10, cr[7 * lpw_] = b11;
         if ((slot & 1) == 0) {
@@ -475,7 +479,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
         for (int i = 0; i < 6; i++) st.rc[i] = L.newrc[i];
         st.dxx = L.newdd[0], st.dxy = L.newdd[1], st.dyy = L.newdd[2];
         lm_store(lm, st);
-        for (int sl = 0; sl < slot; sl++)  // the landmark did not exist in the earlier slots of this window
+        for (int sl = 0; sl < n_prev + slot; sl++)  // the landmark did not exist in the earlier slots of the open windows
             for (int cmp = 0; cmp < 8; cmp++) own_rows[((size_t)sl * 8 + cmp) * lpw_ + (lm - own_lo)] = 0.0;
         write_slot(lm, slot, 0, 0, 0, 0, 1, 0, 0, 1);
     };
@@ -486,9 +490,11 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
         const int n_now = dv.n_lm[b];
         const int hi = own_hi < n_now ? own_hi : n_now;
         for (int lm = lm0; lm < hi; lm += nw)
-            for (int sl = 0; sl < slot0; sl++) {  // (dead slots hold zeros)
-                const size_t o = CK(off_c + pair_offset(rows_, 2 * lm, sl >> 1), lim_F - 7) + (sl & 1) * 2;
-                double *cr = own_rows + (size_t)sl * 8 * lpw_ + (lm - own_lo);
+            for (int vs = 0; vs < n_prev + slot0; vs++) {  // (dead slots hold zeros)
+                const int sl = vs < n_prev ? vs : vs - n_prev;
+                const size_t so = vs < n_prev ? (size_t)(set ^ 1) * dv.f_stride : off_c;
+                const size_t o = CK(so + pair_offset(rows_, 2 * lm, sl >> 1), lim_F - 7) + (sl & 1) * 2;
+                double *cr = own_rows + (size_t)vs * 8 * lpw_ + (lm - own_lo);
                 for (int a = 0; a < 2; a++)
                     for (int k = 0; k < 2; k++) {
                         cr[(a * 2 + k) * lpw_] = FAb[o + a * 4 + k];
@@ -682,7 +688,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                     if (gi == best.lm)  // the lane that owns the local winner
                         for (int i = 0; i < 16; i++) put(rec + 2 * i, best.w[i]);
                     const double *wr = own_rows + (gi - own_lo);
-                    for (int q = tid; q < slot * 8; q += bd) put(rec + 2 * (16 + q), wr[(size_t)q * lpw_]);  // dead slots hold zeros
+                    for (int q = tid; q < slot * 8; q += bd) put(rec + 2 * (16 + q), wr[(size_t)(n_prev * 8 + q) * lpw_]);  // the open set's rows (dead slots hold zeros)
                 }
                 // every wave polls the heads itself (lane l reads workgroup l's) and may then read the winner's body
                 const int lane = tid & 63;
@@ -759,29 +765,53 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                 // winner record and the matched landmark's slot rows into LDS: from the owner's published record, or,
                 // with one workgroup per filter, straight from registers and the own-row cache
                 if (G > 1) {
+                    // rows of the set a dense pass is folding: unchanged since the launch began, plain loads from the slot arrays
+                    const size_t off_p = (size_t)(set ^ 1) * dv.f_stride;
+                    for (int q = tid; q < n_prev * 8; q += bd) {
+                        const int sl = q >> 3, side = (q >> 2) & 1, e = (q >> 1) & 1, k = q & 1;
+                        L.lo_rows[q] = (side == 0 ? FAb : FBb)[CK(off_p + pair_offset(rows_, 2 * w_lo + e, sl >> 1) + (sl & 1) * 2 + k, lim_F)];
+                    }
+                    // winner data and the open set's rows: the owner's record.  All of a thread's granules are requested
+                    // together (one trip) and re-read until every one carries the tag of the exchange just done.
                     const unsigned long long *wrec = (const unsigned long long *)(part + ((size_t)((epoch - 1) & 1) * dv.gmax + src) * EKF_REC_DOUBLES);
-                    const unsigned long long tag = (unsigned long long)(unsigned)(ebase + epoch) << 32;  // of the exchange just done
-                    for (int q = tid; q < 16 + slot * 8; q += bd) {
-                        unsigned long long g0, g1;
-                        long spins = 0;
-                        for (;;) {  // the body may trail the head: re-read until both granules carry the tag
-                            g0 = __hip_atomic_load(wrec + 2 * q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            g1 = __hip_atomic_load(wrec + 2 * q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            if ((((g0 ^ tag) | (g1 ^ tag)) >> 32) == 0) break;
-                            if (++spins > (1L << 22)) {
-                                dv.status[b] = EKF_ERR_HIP;
-                                break;
+                    const unsigned long long tag = (unsigned long long)(unsigned)(ebase + epoch) << 32;
+                    const int nq = 16 + slot * 8;
+                    unsigned long long g0[3], g1[3];  // 16 + 8 * EKF_MAX_PENDING items over >= 128 threads: at most 3 each
+                    long spins = 0;
+                    for (;;) {
+                        unsigned long long bad = 0;
+#pragma unroll
+                        for (int i = 0; i < 3; i++) {
+                            const int q = tid + i * bd;
+                            if (q < nq) {
+                                g0[i] = __hip_atomic_load(wrec + 2 * q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                g1[i] = __hip_atomic_load(wrec + 2 * q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            } else {
+                                g0[i] = g1[i] = tag;
                             }
                         }
-                        double v = __longlong_as_double((long long)((g1 << 32) | (g0 & 0xffffffffull)));
-                        if (q < 16) L.w[q] = v;
-                        else L.lo_rows[q - 16] = v;
+#pragma unroll
+                        for (int i = 0; i < 3; i++) bad |= (g0[i] ^ tag) | (g1[i] ^ tag);
+                        if ((bad >> 32) == 0) break;
+                        if (++spins > (1L << 22)) {  // bounded
+                            dv.status[b] = EKF_ERR_HIP;
+                            break;
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 3; i++) {
+                        const int q = tid + i * bd;
+                        if (q < nq) {
+                            const double v = __longlong_as_double((long long)((g1[i] << 32) | (g0[i] & 0xffffffffull)));
+                            if (q < 16) L.w[q] = v;
+                            else L.lo_rows[n_prev * 8 + q - 16] = v;
+                        }
                     }
                 } else {
                     if (w_lo == best.lm)
                         for (int i = 0; i < 16; i++) L.w[i] = best.w[i];
                     const double *wr = own_rows + (w_lo - own_lo);
-                    for (int q = tid; q < slot * 8; q += bd) L.lo_rows[q] = wr[(size_t)q * lpw_];
+                    for (int q = tid; q < (n_prev + slot) * 8; q += bd) L.lo_rows[q] = wr[(size_t)q * lpw_];
                 }
                 __syncthreads();  // (3) staged rows visible
                 STAMP(4);
@@ -802,15 +832,35 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                             // the slots of this set are not in Bm yet: P[lm rows, lo cols] += sum_k A_lm[.,k] B_lo[.,k] (or B_lm A_lo)
                             const double *own = own_rows + (below ? 0 : 4 * lpw_) + (lm - own_lo);
                             const double *lr = L.lo_rows + (below ? 4 : 0);
-#pragma unroll 4
-                            for (int sl = 0; sl < slot; sl++) {  // dead slots contribute exact zeros
+                            double pe[2][2] = {{0, 0}, {0, 0}}, po[2][2] = {{0, 0}, {0, 0}};  // even / odd slots: two dependency chains
+                            const int nvs = n_prev + slot;
+                            int sl = 0;
+                            for (; sl + 4 <= nvs; sl += 4) {  // four slots per trip: 24 LDS reads requested before the first multiply
+                                double ow[4][4];
+                                double2_t qa[4], qb[4];
+#pragma unroll
+                                for (int j = 0; j < 4; j++) {
+                                    const double *o = own + (size_t)(sl + j) * 8 * lpw_, *q = lr + (sl + j) * 8;
+                                    ow[j][0] = o[0], ow[j][1] = o[lpw_], ow[j][2] = o[2 * lpw_], ow[j][3] = o[3 * lpw_];
+                                    qa[j] = *(const double2_t *)q, qb[j] = *(const double2_t *)(q + 2);
+                                }
+#pragma unroll
+                                for (int j = 0; j < 4; j++) {
+                                    double(*acc)[2] = (j & 1) ? po : pe;
+                                    acc[0][0] = fma(ow[j][1], qa[j].y, fma(ow[j][0], qa[j].x, acc[0][0]));
+                                    acc[0][1] = fma(ow[j][1], qb[j].y, fma(ow[j][0], qb[j].x, acc[0][1]));
+                                    acc[1][0] = fma(ow[j][3], qa[j].y, fma(ow[j][2], qa[j].x, acc[1][0]));
+                                    acc[1][1] = fma(ow[j][3], qb[j].y, fma(ow[j][2], qb[j].x, acc[1][1]));
+                                }
+                            }
+                            for (; sl < nvs; sl++) {  // dead slots contribute exact zeros
                                 const double *o = own + (size_t)sl * 8 * lpw_, *q = lr + sl * 8;
                                 const double o00 = o[0], o01 = o[lpw_], o10 = o[2 * lpw_], o11 = o[3 * lpw_];
-                                p[0][0] += o00 * q[0] + o01 * q[1];
-                                p[0][1] += o00 * q[2] + o01 * q[3];
-                                p[1][0] += o10 * q[0] + o11 * q[1];
-                                p[1][1] += o10 * q[2] + o11 * q[3];
+                                pe[0][0] += o00 * q[0] + o01 * q[1], pe[0][1] += o00 * q[2] + o01 * q[3];
+                                pe[1][0] += o10 * q[0] + o11 * q[1], pe[1][1] += o10 * q[2] + o11 * q[3];
                             }
+                            for (int a = 0; a < 2; a++)
+                                for (int e = 0; e < 2; e++) p[a][e] += pe[a][e] + po[a][e];
                         }
                         apply_old(lm, st, p, slot, h, RS.Prr, L.w);
                     };
@@ -1111,7 +1161,7 @@ __global__ __launch_bounds__(256, 2) void k_flush(EkfDev dv, int nT_hi, int set,
 // all-zero pair): three row-blocks of the tile in flight, the fourth is requested into the registers of the
 // first once that has been stored.
 template <int NP>
-__device__ __forceinline__ void flush_tile_rb(double *tp, const double *FA, const double *FB, unsigned lo, unsigned live, int zero_slot, size_t slot_stride) {
+__device__ __forceinline__ void flush_tile_rb(const double *tp, double *tq, const double *FA, const double *FB, unsigned lo, unsigned live, int zero_slot, size_t slot_stride) {
         // the common case (windows up to 16): three row-blocks of the tile in flight, the fourth is requested
         // into the registers of the first once that has been stored
         size_t mo[NP];
@@ -1156,8 +1206,8 @@ __device__ __forceinline__ void flush_tile_rb(double *tp, const double *FA, cons
 #pragma unroll
             for (int cc = 0; cc < 4; cc++) {
                 const int ch = rc * 4 + cc;
-                *(double2_t *)(tp + ch * 256) = (double2_t){blk[k][cc].x, blk[k][cc].y};
-                *(double2_t *)(tp + ch * 256 + 128) = (double2_t){blk[k][cc].z, blk[k][cc].w};
+                *(double2_t *)(tq + ch * 256) = (double2_t){blk[k][cc].x, blk[k][cc].y};
+                *(double2_t *)(tq + ch * 256 + 128) = (double2_t){blk[k][cc].z, blk[k][cc].w};
             }
             if (rc == 0) {
 #pragma unroll
@@ -1180,7 +1230,7 @@ __device__ __forceinline__ void flush_tile_rb(double *tp, const double *FA, cons
 // (128).  Every load that a later wait names is issued before the stores that precede that wait in program
 // order, except the A operands two row-blocks ahead (their wait is two MFMA blocks later).
 // More than 8 live pairs (windows above 16) fall back to the slot-major walk of k_flush.
-__global__ __launch_bounds__(256, 2) void k_flush_rb(EkfDev dv, int nT_hi, int set, int nslots, int buf) {
+__global__ __launch_bounds__(256, 2) void k_flush_rb(EkfDev dv, int nT_hi, int set, int nslots, int buf, int buf_out) {
     int b = blockIdx.y;
     int lane = threadIdx.x & 63;
     int u = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1197,7 +1247,8 @@ __global__ __launch_bounds__(256, 2) void k_flush_rb(EkfDev dv, int nT_hi, int s
 
     const int *active = dv.slot_active + ((size_t)b * 2 + set) * dv.maxp;
     size_t t = (size_t)I * dv.T - ((size_t)I * (I - 1)) / 2 + (size_t)(J - I);
-    double *tp = dv.Bm[buf] + (size_t)b * dv.bm_stride + t * 4096 + (size_t)lane * 2;
+    const double *tp = dv.Bm[buf] + (size_t)b * dv.bm_stride + t * 4096 + (size_t)lane * 2;
+    double *tq = dv.Bm[buf_out] + (size_t)b * dv.bm_stride + t * 4096 + (size_t)lane * 2;  // == tp without overlap
     // uniform base (SGPRs) + one per-lane 32-bit offset shared by every operand load
     const double *FA = dv.FA + ((size_t)b * 2 + set) * dv.f_stride + (size_t)64 * uni(I) * 4;
     const double *FB = dv.FB + ((size_t)b * 2 + set) * dv.f_stride + (size_t)64 * uni(J) * 4;
@@ -1211,9 +1262,9 @@ __global__ __launch_bounds__(256, 2) void k_flush_rb(EkfDev dv, int nT_hi, int s
     const int npl = __builtin_popcount(live);
 
     if (npl <= 8) {  // windows up to 16
-        if (npl <= 2) flush_tile_rb<2>(tp, FA, FB, lo, live, zero_slot, slot_stride);
-        else if (npl <= 4) flush_tile_rb<4>(tp, FA, FB, lo, live, zero_slot, slot_stride);
-        else flush_tile_rb<8>(tp, FA, FB, lo, live, zero_slot, slot_stride);
+        if (npl <= 2) flush_tile_rb<2>(tp, tq, FA, FB, lo, live, zero_slot, slot_stride);
+        else if (npl <= 4) flush_tile_rb<4>(tp, tq, FA, FB, lo, live, zero_slot, slot_stride);
+        else flush_tile_rb<8>(tp, tq, FA, FB, lo, live, zero_slot, slot_stride);
         return;
     }
     // windows above 16: the slot-major walk of k_flush, two pairs per iteration
@@ -1245,8 +1296,8 @@ __global__ __launch_bounds__(256, 2) void k_flush_rb(EkfDev dv, int nT_hi, int s
     }
 #pragma unroll
     for (int ch = 0; ch < 16; ch++) {
-        *(double2_t *)(tp + ch * 256) = (double2_t){acc[ch].x, acc[ch].y};
-        *(double2_t *)(tp + ch * 256 + 128) = (double2_t){acc[ch].z, acc[ch].w};
+        *(double2_t *)(tq + ch * 256) = (double2_t){acc[ch].x, acc[ch].y};
+        *(double2_t *)(tq + ch * 256 + 128) = (double2_t){acc[ch].z, acc[ch].w};
     }
 }
 

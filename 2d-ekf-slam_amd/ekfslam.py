@@ -17,7 +17,7 @@ NEW, OLD, IGNORE = 1, 2, 3
 # every symbol include/ekfslam_c.h declares
 ABI_SYMBOLS = [
     "ekf_last_error", "ekf_default_params", "ekf_create", "ekf_batch_create", "ekf_destroy", "ekf_batch_size",
-    "ekf_capacity", "ekf_window", "ekf_propagate", "ekf_propagate_q", "ekf_update", "ekf_update_compass", "ekf_get_pose",
+    "ekf_capacity", "ekf_window", "ekf_overlap", "ekf_propagate", "ekf_propagate_q", "ekf_update", "ekf_update_compass", "ekf_get_pose",
     "ekf_num_landmarks", "ekf_get_robot_cov", "ekf_get_x", "ekf_batch_propagate", "ekf_batch_propagate_q", "ekf_batch_update",
     "ekf_batch_update_compass", "ekf_batch_get_pose", "ekf_batch_num_landmarks", "ekf_get_state", "ekf_set_state",
     "ekf_broadcast_state", "ekf_script_load", "ekf_script_run", "ekf_sync", "ekf_flush", "ekf_timer_start",
@@ -29,7 +29,7 @@ ABI_SYMBOLS = [
 class EkfParams(ctypes.Structure):
     _fields_ = [("sigma_v", ctypes.c_double), ("sigma_w", ctypes.c_double), ("gamma_max", ctypes.c_double),
                 ("gamma_min", ctypes.c_double), ("cond_limit", ctypes.c_double), ("max_pending", ctypes.c_int),
-                ("log_capacity", ctypes.c_int)]
+                ("log_capacity", ctypes.c_int), ("overlap", ctypes.c_int)]
 
 
 class EkfDecision(ctypes.Structure):
@@ -72,6 +72,7 @@ def load():
     L.ekf_batch_size.argtypes = [_H]
     L.ekf_capacity.argtypes = [_H]
     L.ekf_window.argtypes = [_H]
+    L.ekf_overlap.argtypes = [_H]
     L.ekf_propagate.argtypes = [_H, ctypes.c_double, ctypes.c_double, ctypes.c_double]
     L.ekf_propagate_q.argtypes = [_H, ctypes.c_double, ctypes.c_double, _dp, ctypes.c_double]
     L.ekf_update.argtypes = [_H, _dp, _dp, ctypes.c_int, ctypes.POINTER(EkfDecision)]
@@ -142,6 +143,7 @@ class FilterBatch:
         self.batch = batch
         self.capacity = capacity_landmarks
         self.window = int(self.L.ekf_window(self.h))  # effective max_pending
+        self.overlap = bool(self.L.ekf_overlap(self.h))
 
     def close(self):
         if self.h:

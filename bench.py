@@ -191,9 +191,9 @@ def main():
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": "%s: %d filter(s)/GPU, N=%d landmarks (n=%d, dense P %.1f MB fp64), M=%d Old updates/step, max_pending=%d, graph=%d"
-                               % (args.workload, B, N, 3 + 2 * N, (3 + 2 * N) ** 2 * 8 / 1e6, M, args.max_pending, args.graph),
-                   "N": N, "filters_per_gpu": B, "M": M, "max_pending": args.max_pending},
+        "config": {"workload": "%s: %d filter(s)/GPU, N=%d landmarks (n=%d, dense P %.1f MB fp64), M=%d Old updates/step, max_pending=%d, overlap=%d, graph=%d"
+                               % (args.workload, B, N, 3 + 2 * N, (3 + 2 * N) ** 2 * 8 / 1e6, M, args.max_pending, int(f.overlap), args.graph),
+                   "N": N, "filters_per_gpu": B, "M": M, "max_pending": args.max_pending, "overlap": int(f.overlap)},
         "device_ms_per_step": dev_ms / K,
         "roofline": roofline,
         "cpu_baseline": cpu,

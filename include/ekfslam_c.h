@@ -58,6 +58,10 @@ typedef struct ekf_params {
                            creation, see ekf_window().  Results do not depend on it beyond rounding; x, the robot rows and the landmark 2x2 blocks are always
                            current, and ekf_get_state / ekf_flush fold everything on demand. */
     int log_capacity;   /* decision-log entries kept per filter (ring) */
+    int overlap;        /* 1: a window's dense pass runs on its own HIP stream, buffer to buffer, beside the next
+                           window's chain kernels (twice the P_LL memory); 0: the pass runs in place between the
+                           windows; -1 (default): on when both windows fit the chain kernel's on-chip buffer
+                           without shortening max_pending.  Same results up to rounding. */
 } ekf_params;
 
 typedef struct ekf_decision {
@@ -88,6 +92,8 @@ int ekf_capacity(ekf_handle h);
 /* The effective max_pending: the requested window, shortened when capacity_landmarks x window does not fit
  * the on-chip buffer of the chain kernel (64 bytes per landmark and slot, about 148 KB per workgroup). */
 int ekf_window(ekf_handle h);
+/* 1 when the handle overlaps dense passes with chain kernels (ekf_params.overlap resolved), else 0. */
+int ekf_overlap(ekf_handle h);
 
 /* ---- single-filter calls (batch must be 1) ------------------------------------------------ */
 

@@ -29,3 +29,19 @@ def oc():
 def npo():
     from oracle import ekf_numpy
     return ekf_numpy
+
+
+def pytest_generate_tests(metafunc):
+    # every GPU test runs in both pipeline modes
+    if metafunc.definition.get_closest_marker("gpu") is not None and "pipeline_mode" in metafunc.fixturenames:
+        metafunc.parametrize("pipeline_mode", ["inplace", "overlap"], indirect=True)
+
+
+@pytest.fixture(autouse=True)
+def pipeline_mode(request, monkeypatch):
+    """GPU tests run twice: dense pass in place between the windows, and dense pass overlapped with the next
+    window's chain kernels (ekf_params.overlap; the environment variable overrides the parameter)."""
+    mode = getattr(request, "param", None)
+    if mode is not None:
+        monkeypatch.setenv("EKF_OVERLAP", "1" if mode == "overlap" else "0")
+    return mode
