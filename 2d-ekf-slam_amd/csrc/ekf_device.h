@@ -9,14 +9,15 @@
 //                                                           written ONLY by the dense pass (k_flush)
 // P_LL indices are "landmark space": i' = i - 3.
 //
-// Everything the chain kernel decides that changes P_LL is recorded as a rank-4 "slot"
-//       P_LL(i', j') += sum_k FA[i'][k] * FB[j'][k]          (i' <= j', different landmarks)
-// in arrays FA/FB [b][set][slot][row i'][k]: 16 rows x 4 k = one 512-byte A (or B) operand of
-// v_mfma_f64_16x16x4_f64, and one landmark's two rows = one 64-byte line for the chain kernel.  An Old-landmark update (Update.cpp:188,193-194) is the slot
-// FA = -0.5 [T | K], FB = [K | T] with T = K S; a New landmark (Update.cpp:169-177) is the slot
-// FA = [P_xL | 0], FB = unit rows at the new landmark.  The dense pass applies a whole set of slots
-// in one read of Bm[in] and one write of Bm[out]; two slot sets and two Bm buffers let the chain
-// kernel of the next step run while the dense pass of this step streams through HBM.
+// Everything the chain kernel decides that changes P_LL is recorded as a rank-2 "slot"
+//       P_LL(i', j') += sum_{e<2} FA[i'][e] * FB[j'][e]          (i' <= j', different landmarks)
+// Two consecutive slots share one row of FA/FB [b][set][pair][row i'][4] (slot 2p in [0..1], slot 2p+1 in
+// [2..3]): 16 rows x 4 = one 512-byte A (or B) operand of v_mfma_f64_16x16x4_f64, i.e. k = 4 carries two
+// measurements, and one landmark's two rows = one 64-byte line.  An Old-landmark update (Update.cpp:188,
+// 193-194) is the slot FA = -T, FB = K with T = K S; a New landmark (Update.cpp:169-177) is the slot
+// FA = P_xL, FB = unit rows at the new landmark.  The dense pass applies a whole set of slots in one read and
+// one write of Bm; with two slot sets (and, in overlap mode, two Bm buffers) the chain kernels of the next
+// window run while the dense pass of this window streams through HBM.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>

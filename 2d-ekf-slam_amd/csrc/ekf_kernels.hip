@@ -180,41 +180,19 @@ __device__ __forceinline__ size_t chk_idx(long long *dbg, int line, long long id
 #define CK(idx, limit) ((size_t)(idx))
 #endif
 
-// Barrier over the G workgroups of one filter (MI355X_MICROARCH.md "Valid forms": every storing wave
-// drains, workgroup barrier, lane-0 agent release, drained, relaxed agent add; one relaxed poll loop,
-// one agent acquire, drained, workgroup barrier, then plain loads).  bar counts arrivals
-// monotonically inside one launch; the last workgroup to leave the kernel zeroes it.  The spin is
-// bounded: on time-out the filter is marked failed instead of hanging the GPU.
-__device__ __forceinline__ void filter_barrier(int *bar, int target, int *status) {
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_fetch_add(bar, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        long spins = 0;
-        while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1L << 24)) {
-                *status = EKF_ERR_HIP;
-                break;
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __syncthreads();
-}
-
 // ---------------------------------------------------------------------------------------------
 // The chain kernel.  grid (G, B): G workgroups share one filter, workgroup g owns landmarks
 // [g*lpw, (g+1)*lpw) -- their x entries, their columns of the robot rows R, their 2x2 block D,
 // their slot rows.  Inside a workgroup wave 0 is the CONTROL wave (lane 0 runs the serial robot-block
-// arithmetic: propagate, gate, gain rows of the robot) and the other waves are WORKERS: worker w owns
+// arithmetic: propagate, robot rows of the gain, logs) and the other waves are WORKERS: worker w owns
 // landmarks own_lo + w, + nworkers, ...; the first of them lives in registers for the whole launch.
-// Sequential dependencies of the reference become: workgroup barriers around the arg-min and the
-// robot block, plus ONE cross-workgroup barrier per measurement (the arg-min over all landmarks).
-// Every workgroup keeps an identical copy of the robot state and recomputes the gate identically;
-// only workgroup 0 writes logs, statistics, slot flags and, at the end, the robot state.
+// One launch executes a LIST of operations.  Per measurement: sweep -> wave arg-min (DPP) -> workgroup
+// arg-min -> ONE exchange between the filter's workgroups (tagged write-through records, no fences) ->
+// every thread evaluates the gate from the winner -> Old: the workers fetch the matched landmark's slot rows,
+// fold the unflushed slots from LDS, rebuild the gain header and update their landmarks while the control lane
+// updates the robot block; New / Ignore / compass: the control lane prepares a header first.
+// Every workgroup keeps an identical copy of the robot state; only workgroup 0 writes logs, statistics,
+// slot flags and, at the end, the robot state and the host-mapped mirror.
 //   in/cursor/k0/nops : the operation list
 //   slot0             : first free slot of set `set`
 //   n_prev            : > 0 while the other set (its first n_prev slots) is being folded by a dense pass that

@@ -87,11 +87,13 @@ def main():
     lo, hi = mc.shard_range(B * world, rank, world)
     f = pkg.FilterBatch(B, N, device=dev_id, max_pending=args.max_pending, log_capacity=max(4096, (K + W) * M))
     args.max_pending = f.window  # the library may shorten the window to fit its on-chip buffer
+    win_steps = -(-f.window // M)   # steps that fill one window
+    tail_steps = 4 * win_steps      # untimed tail: dense passes measured one at a time, nothing beside them
     scripts = []
     for b, g in enumerate(range(lo, hi)):
         x0, P0 = pkg.scenarios.injected_state(N, seed=mc.filter_seed(seed, g), extent=extent)
         f.set_state(x0, P0, index=b)
-        scripts.append(pkg.scenarios.steady_script(x0, steps=W + K, M=M, seed=mc.filter_seed(seed + 7919, g)))
+        scripts.append(pkg.scenarios.steady_script(x0, steps=W + K + tail_steps, M=M, seed=mc.filter_seed(seed + 7919, g)))
         del P0
     ctrl = np.stack([s["ctrl"] for s in scripts], axis=1)
     z = np.stack([s["z"] for s in scripts], axis=2)
@@ -132,11 +134,20 @@ def main():
     launches, flush_ms = f.flush_profile_read()
     for b in range(B if B <= 4 else 4):
         dec = f.decisions(b, K * M)
-        want = [3 + 2 * int(t) for t in scripts[b]["target"][W:].ravel()]
+        want = [3 + 2 * int(t) for t in scripts[b]["target"][W:W + K].ravel()]
         assert len(dec) == K * M and all(d[0] == pkg.ekfslam.OLD for d in dec), "filter %d left the Old branch" % b
         assert [d[1] for d in dec] == want, "filter %d matched an unintended landmark" % b
     st = f.stats()
     assert all(s["n_old"] == K * M and s["n_new"] == 0 and s["n_ignore"] == 0 for s in st)
+    # the same dense pass with the GPU to itself (in overlap mode the timed passes share HBM with the chain kernels)
+    alone_launches, alone_ms = 0, 0.0
+    if not args.no_flush_profile:
+        for r in range(4):
+            f.script_run(W + K + r * win_steps, win_steps)
+            f.sync()   # chain kernels finished: the pass below runs alone
+            f.flush()
+            f.sync()
+        alone_launches, alone_ms = f.flush_profile_read()
 
     if rank != 0:
         if dist is not None:
@@ -164,6 +175,11 @@ def main():
         roofline["mfma"]["achieved"] = flops_per_launch / avg_s / 1e12
         roofline["mfma"]["frac"] = roofline["mfma"]["achieved"] / FP64_MFMA_PEAK_TFLOPS
         roofline["share_of_step_time"] = flush_ms / (dev_ms if dev_ms > 0 else 1.0)
+        roofline["concurrent_with"] = "k_chain of the next window (overlap)" if f.overlap else None
+    if alone_launches:
+        a_s = alone_ms / 1e3 / alone_launches
+        roofline["alone"] = {"avg_launch_us": a_s * 1e6, "achieved": bytes_per_launch / a_s / 1e9, "frac": bytes_per_launch / a_s / 1e9 / HBM_PEAK_GBS,
+                             "launches": int(alone_launches), "note": "same pass, nothing else on the GPU, outside the timed region"}
     tfile = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
     if os.path.exists(tfile):  # PMC-derived HBM bytes per launch (rocprofv3 passes of the same command, see profiles/)
         tj = json.load(open(tfile))

@@ -53,7 +53,7 @@ typedef struct ekf_params {
     double gamma_min;   /* 10    kalmanfilter.cpp:68 (int there) */
     double cond_limit;  /* 80    Update.cpp:131 */
     int max_pending;    /* measurements whose P_LL change is deferred into ONE dense pass over P_LL
-                           (each is a rank-4 slot of that pass); 1 = a dense pass per measurement as the
+                           (each is a rank-2 slot of that pass); 1 = a dense pass per measurement as the
                            reference does (Update.cpp:188).  1..32, default 16; may be shortened at
                            creation, see ekf_window().  Results do not depend on it beyond rounding; x, the robot rows and the landmark 2x2 blocks are always
                            current, and ekf_get_state / ekf_flush fold everything on demand. */
