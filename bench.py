@@ -164,7 +164,7 @@ def main():
     slots_per_launch = min(args.max_pending, K * M)
     flops_per_launch = B * tiles * ((slots_per_launch + 1) // 2) * 16 * 2048  # 16 v_mfma_f64_16x16x4_f64 per tile and PAIR of measurements
     roofline = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
-                "kernel": "k_flush", "bytes_per_launch": bytes_per_launch, "launches": int(launches), "avg_launch_us": None,
+                "kernel": "k_flush_rb", "bytes_per_launch": bytes_per_launch, "launches": int(launches), "avg_launch_us": None,
                 "measurements_per_launch": slots_per_launch,
                 "mfma": {"achieved": None, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None, "flops_per_launch": flops_per_launch}}
     if launches:

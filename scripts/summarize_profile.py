@@ -7,7 +7,7 @@ dst = "profiles"
 os.makedirs(dst, exist_ok=True)
 ks = glob.glob(os.path.join(src, "trace/runc/*_kernel_stats.csv"))[0]
 shutil.copy(ks, os.path.join(dst, tag + "_kernel_stats.csv"))
-summary = {"command": "rocprofv3 --kernel-trace --stats | --pmc FETCH_SIZE | --pmc WRITE_SIZE | --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE  -- python3 bench.py --no-cpu-baseline --steps 64 --warmup 8 (scripts/profile_r01.sh)",
+summary = {"command": "rocprofv3 --kernel-trace --stats | --pmc FETCH_SIZE | --pmc WRITE_SIZE | --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE  -- python3 bench.py --no-cpu-baseline --steps 64 --warmup 8 [+ args] (scripts/profile_r01.sh, scripts/collect_r01.sh for the tag-specific arguments and EKF_OVERLAP)",
            "kernels": {}, "bench_lines": {}}
 for row in csv.DictReader(open(ks)):
     summary["kernels"][row["Name"].split("(")[0]] = {"calls": int(row["Calls"]), "avg_us": float(row["AverageNs"]) / 1e3, "pct": float(row["Percentage"])}
@@ -27,7 +27,7 @@ for n in ("trace", "fetch", "write", "mfma"):
     if os.path.exists(p) and os.path.getsize(p):
         d = json.load(open(p))
         summary["bench_lines"][n] = {"value": d["value"], "flush_avg_launch_us_events": d["roofline"]["avg_launch_us"], "frac": d["roofline"]["frac"]}
-fl = summary["kernels"].get("k_flush", {})
+fl = summary["kernels"].get("k_flush_rb") or summary["kernels"].get("k_flush", {})
 if "FETCH_SIZE_mean_per_dispatch" in fl and "WRITE_SIZE_mean_per_dispatch" in fl:
     # rocprofv3 reports KB.  gfx950: FETCH_SIZE tallies the 128-byte requests of a 16 B/lane stream at 64 B
     # (MI355X_MICROARCH.md, HBM): the tile stream (= WRITE_SIZE bytes, read once, written once) is doubled,
@@ -38,4 +38,4 @@ if "FETCH_SIZE_mean_per_dispatch" in fl and "WRITE_SIZE_mean_per_dispatch" in fl
     summary["traffic"] = {"fetch_size_kb": f_kb, "write_size_kb": w_kb, "tile_read_bytes": tile_read, "operand_read_bytes": operand,
                           "hbm_bytes_per_launch": tile_read + operand + w_kb * 1024.0}
 json.dump(summary, open(os.path.join(dst, tag + "_summary.json"), "w"), indent=1)
-print(json.dumps(summary, indent=1))
+
