@@ -10,6 +10,7 @@
 #include <string.h>
 
 #include <string>
+#include <mutex>
 #include <vector>
 
 #include "ekf_device.h"
@@ -48,9 +49,9 @@ struct ekf_batch {
     bool overlap;         // a window's dense pass runs beside the next window's chain kernels (two slot sets, two Bm buffers)
     int prev_pending;     // overlap: slots of the other set whose dense pass has been launched but is not in Bm[buf_in]
     hipEvent_t ev_chain, ev_flush[2];
-    hipEvent_t ev_pass[2];  // the stop event actually attached to a pass: ev_flush[i] or a profiling event
     int ev_idx;           // ev_flush[ev_idx] belongs to the dense pass launched last
     bool chain_signalled; // the last chain launch carried ev_chain as its stop event
+    int flush_keep;       // pool key of s_flush: CUs kept free for the chain, -1 = unmasked
     int chain_wgs;        // k_chain workgroups per filter
     size_t chain_lds;     // dynamic LDS of a k_chain launch: the own-row cache
     size_t device_bytes;
@@ -101,6 +102,48 @@ extern "C" void ekf_default_params(ekf_params *p) {
     p->overlap = -1;
 }
 
+// EKF_TRACE=1: progress marks of handle creation / destruction on stderr (diagnostic)
+static bool trace_on() {
+    static int on = -1;
+    if (on < 0) on = getenv("EKF_TRACE") ? atoi(getenv("EKF_TRACE")) : 0;
+    return on != 0;
+}
+#define TRACE(msg)                                          \
+    do {                                                    \
+        if (trace_on()) {                                   \
+            fprintf(stderr, "[ekf] %s\n", msg);             \
+            fflush(stderr);                                 \
+        }                                                   \
+    } while (0)
+
+// Streams are recycled through a process-wide pool and never destroyed: hipStreamCreateWithFlags and
+// hipExtStreamCreateWithCUMask were seen to block forever once in a few thousand create/destroy cycles (ROCm 7.2;
+// scripts/stress_create.py), which a test suite that opens hundreds of handles does reach.  A handle takes an
+// idle stream of the right kind (device, CUs kept free: -1 = unmasked) or creates one; ekf_destroy returns it
+// after synchronising.
+struct PooledStream {
+    int device, keep;
+    hipStream_t s;
+};
+static std::mutex g_pool_mu;
+static std::vector<PooledStream> g_pool;
+
+static bool pool_take(int device, int keep, hipStream_t *out) {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (size_t i = 0; i < g_pool.size(); i++)
+        if (g_pool[i].device == device && g_pool[i].keep == keep) {
+            *out = g_pool[i].s;
+            g_pool.erase(g_pool.begin() + i);
+            return true;
+        }
+    return false;
+}
+
+static void pool_give(int device, int keep, hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    g_pool.push_back({device, keep, s});
+}
+
 template <typename T>
 static hipError_t dev_alloc_zero(T **p, size_t count, size_t *total, hipStream_t s) {
     size_t bytes = count * sizeof(T);
@@ -135,7 +178,11 @@ extern "C" int ekf_batch_create(ekf_handle *out, int batch, int capacity_landmar
     if (h->params.log_capacity < 16) h->params.log_capacity = 16;
     h->device = device_id;
     h->device_bytes = 0;
-    HIP_TRY(hipStreamCreateWithFlags(&h->s_chain, hipStreamNonBlocking));
+    if (!pool_take(device_id, -1, &h->s_chain)) {
+        TRACE("create: stream");
+        HIP_TRY(hipStreamCreateWithFlags(&h->s_chain, hipStreamNonBlocking));
+        TRACE("create: stream done");
+    }
 
     EkfDev &dv = h->dv;
     memset(&dv, 0, sizeof dv);
@@ -223,6 +270,7 @@ extern "C" int ekf_batch_create(ekf_handle *out, int batch, int capacity_landmar
     HIP_TRY(dev_alloc_zero(&dv.stats, B, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&h->cursor_d, 1, &h->device_bytes, s));
 
+    TRACE("create: device buffers queued");
     HIP_TRY(hipHostMalloc((void **)&h->mirror_h, B * sizeof(EkfMirror), hipHostMallocMapped));
     memset(h->mirror_h, 0, B * sizeof(EkfMirror));
     HIP_TRY(hipHostGetDevicePointer((void **)&dv.mirror, h->mirror_h, 0));
@@ -251,7 +299,6 @@ extern "C" int ekf_batch_create(ekf_handle *out, int batch, int capacity_landmar
     h->prev_pending = 0;
     h->ev_idx = 0;
     h->chain_signalled = false;
-    h->ev_pass[0] = h->ev_pass[1] = nullptr;
     h->s_flush = h->s_chain;
     if (h->overlap) {
         // The chain kernel needs its workgroups' CUs the moment it is launched; a dense pass that owns every CU
@@ -260,22 +307,27 @@ extern "C" int ekf_batch_create(ekf_handle *out, int batch, int capacity_landmar
         int keep = getenv("EKF_CHAIN_CUS") ? atoi(getenv("EKF_CHAIN_CUS")) : (G * batch < 32 ? G * batch : 32);  // (measured: 32 beats 64 even for 64 workgroups)
         int ncu = prop.multiProcessorCount;
         if (keep > ncu / 2) keep = ncu / 2;
-        hipError_t em = hipErrorUnknown;
-        if (keep > 0) {
-            std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
-            // CU i sits on XCD i % 8 (round-robin numbering): free the same share of every XCD
-            int per_xcd = (keep + 7) / 8, xcds = 8, freed[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            for (int i = 0; i < ncu; i++) {
-                int xc = i % xcds;
-                bool chain_cu = freed[xc] < per_xcd;
-                if (chain_cu) freed[xc]++;
-                else mask[i / 32] |= 1u << (i % 32);
+        h->flush_keep = keep > 0 ? keep : -1;
+        if (!pool_take(device_id, h->flush_keep, &h->s_flush)) {
+            hipError_t em = hipErrorUnknown;
+            if (keep > 0) {
+                std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+                // CU i sits on XCD i % 8 (round-robin numbering): free the same share of every XCD
+                int per_xcd = (keep + 7) / 8, xcds = 8, freed[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (int i = 0; i < ncu; i++) {
+                    int xc = i % xcds;
+                    bool chain_cu = freed[xc] < per_xcd;
+                    if (chain_cu) freed[xc]++;
+                    else mask[i / 32] |= 1u << (i % 32);
+                }
+                TRACE("create: cu-mask stream");
+                em = hipExtStreamCreateWithCUMask(&h->s_flush, (uint32_t)mask.size(), mask.data());
+                TRACE("create: cu-mask stream done");
             }
-            em = hipExtStreamCreateWithCUMask(&h->s_flush, (uint32_t)mask.size(), mask.data());
-        }
-        if (em != hipSuccess) {
-            (void)hipGetLastError();
-            HIP_TRY(hipStreamCreateWithFlags(&h->s_flush, hipStreamNonBlocking));
+            if (em != hipSuccess) {
+                (void)hipGetLastError();
+                HIP_TRY(hipStreamCreateWithFlags(&h->s_flush, hipStreamNonBlocking));
+            }
         }
         HIP_TRY(hipEventCreate(&h->ev_chain));  // (stop events of dispatch packets)
         for (int i = 0; i < 2; i++) HIP_TRY(hipEventCreate(&h->ev_flush[i]));
@@ -287,7 +339,9 @@ extern "C" int ekf_batch_create(ekf_handle *out, int batch, int capacity_landmar
     h->script_d = nullptr;
     h->script_steps = h->script_M = h->script_has_truth = 0;
     h->h_int.resize(B);
+    TRACE("create: final sync");
     HIP_TRY(hipStreamSynchronize(h->s_chain));
+    TRACE("create: done");
     *out = h;
     return EKF_OK;
 }
@@ -299,11 +353,12 @@ extern "C" int ekf_create(ekf_handle *out, int capacity_landmarks, int device_id
 extern "C" int ekf_destroy(ekf_handle h) {
     if (!h) return EKF_OK;
     hipSetDevice(h->device);
+    TRACE("destroy: sync");
     hipStreamSynchronize(h->s_chain);
     if (h->overlap) {
         hipStreamSynchronize(h->s_flush);
         hipEventDestroy(h->ev_chain), hipEventDestroy(h->ev_flush[0]), hipEventDestroy(h->ev_flush[1]);
-        hipStreamDestroy(h->s_flush);
+        pool_give(h->device, h->flush_keep, h->s_flush);
         hipFree(h->dv.Bm[1]);
     }
     for (auto &g : h->graphs) hipGraphExecDestroy(g.exec);
@@ -319,8 +374,10 @@ extern "C" int ekf_destroy(ekf_handle h) {
     for (int i = 0; i < 2; i++) hipEventDestroy(h->ring_ev[i]);
     hipEventDestroy(h->t0), hipEventDestroy(h->t1);
     for (auto e : h->prof_pool) hipEventDestroy(e);
-    hipStreamDestroy(h->s_chain);
+    TRACE("destroy: streams");
+    pool_give(h->device, -1, h->s_chain);
     delete h;
+    TRACE("destroy: done");
     return EKF_OK;
 }
 
@@ -377,18 +434,18 @@ static int close_set(ekf_batch *h) {
                 HIP_TRY(hipEventCreate(&e));
                 h->prof_pool.push_back(e);
             }
-            e0 = h->prof_pool[h->prof_used++], e1 = h->prof_pool[h->prof_used++];
+            e0 = h->prof_pool[h->prof_used++], e1 = h->prof_pool[h->prof_used++];  // (recycled after a read: never used for dependencies)
         }
-        h->ev_pass[h->ev_idx ^ 1] = e1;
         // (start/stop events ride on the dispatch packet itself: no extra barrier packets)
         if (variant == 1) hipExtLaunchKernelGGL(k_flush_q, grid, dim3(256), 0, sf, e0, e1, 0, h->dv, nT_hi, h->cur_set, h->pending, fin);
         else if (variant == 2) hipExtLaunchKernelGGL(k_flush_rb, grid, dim3(256), 0, sf, e0, e1, 0, h->dv, nT_hi, h->cur_set, h->pending, fin, fout);
         else hipExtLaunchKernelGGL(k_flush, grid, dim3(256), 0, sf, e0, e1, 0, h->dv, nT_hi, h->cur_set, h->pending, fin, stagger_ticks);
     }
     if (h->overlap) {
-        if (h->prev_pending > 0) HIP_TRY(hipStreamWaitEvent(h->s_chain, h->ev_pass[h->ev_idx], 0));  // pass k-1
-        h->ev_idx ^= 1;  // ev_flush[ev_idx] is pass k's stop event
-        if (getenv("EKF_OVERLAP_SERIAL")) HIP_TRY(hipStreamWaitEvent(h->s_chain, h->ev_pass[h->ev_idx], 0));  // experiment: no concurrency
+        if (h->prev_pending > 0) HIP_TRY(hipStreamWaitEvent(h->s_chain, h->ev_flush[h->ev_idx], 0));  // pass k-1
+        h->ev_idx ^= 1;  // ev_flush[ev_idx] is pass k's completion: its stop event, or, when profiling took that, a marker
+        if (h->prof_flush) HIP_TRY(hipEventRecord(h->ev_flush[h->ev_idx], sf));
+        if (getenv("EKF_OVERLAP_SERIAL")) HIP_TRY(hipStreamWaitEvent(h->s_chain, h->ev_flush[h->ev_idx], 0));  // experiment: no concurrency
         h->buf_in = fin;
         h->prev_pending = h->pending;
     }
@@ -963,7 +1020,7 @@ extern "C" int ekf_timer_start(ekf_handle h) {
 extern "C" int ekf_timer_stop(ekf_handle h, double *ms_out) {
     if (!h || !ms_out) return set_error(EKF_ERR_BAD_ARG, "null argument");
     HIP_TRY(hipSetDevice(h->device));
-    if (h->overlap && h->prev_pending > 0) HIP_TRY(hipStreamWaitEvent(h->s_chain, h->ev_pass[h->ev_idx], 0));  // the pass in flight counts
+    if (h->overlap && h->prev_pending > 0) HIP_TRY(hipStreamWaitEvent(h->s_chain, h->ev_flush[h->ev_idx], 0));  // the pass in flight counts
     HIP_TRY(hipEventRecord(h->t1, h->s_chain));
     HIP_TRY(hipEventSynchronize(h->t1));
     float ms = 0;

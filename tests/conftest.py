@@ -45,3 +45,19 @@ def pipeline_mode(request, monkeypatch):
     if mode is not None:
         monkeypatch.setenv("EKF_OVERLAP", "1" if mode == "overlap" else "0")
     return mode
+
+
+@pytest.fixture(autouse=True)
+def hang_watchdog(request):
+    """EKF_TEST_WATCHDOG=<seconds>: a test stuck inside a native call dumps all Python stacks to stderr and exits
+    (pytest-timeout cannot interrupt a thread that is blocked in C)."""
+    secs = os.environ.get("EKF_TEST_WATCHDOG")
+    if not secs:
+        yield
+        return
+    import faulthandler
+    sys.stderr.write("[test] %s\n" % request.node.nodeid)
+    sys.stderr.flush()
+    faulthandler.dump_traceback_later(float(secs), exit=True)
+    yield
+    faulthandler.cancel_dump_traceback_later()

@@ -72,3 +72,13 @@ def test_hbm_index_maps_are_bijections(tmp_path):
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-O1", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "cpp", "layout_check.cpp")])
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0 and "layout ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_generated_assembly_passes_the_exec_mask_lint(built):
+    """The build's guard against the live-range-split miscompile: no run of register copies directly
+    in front of an exec-widening s_or_b64 in any kernel."""
+    import subprocess
+    csrc = os.path.join(ROOT, "2d-ekf-slam_amd", "csrc")
+    r = subprocess.run(["make", "-C", csrc, "lint"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "0 suspicious site(s)" in r.stdout

@@ -418,3 +418,28 @@ def test_lifecycle_with_multi_workgroup_capacity(pkg, oc):
     xg, Pg = kf.state()
     assert_state_close(xg, Pg, x, P, "capacity 1000")
     assert_bitwise_symmetric(Pg)
+
+
+def test_long_run_window_16_matches_eager(pkg):
+    """Soak: 240 steps (960 measurements, 60 windows) at N=2048 spread over many workgroups, default window,
+    against a dense pass per measurement.  Exercises every cross-workgroup exchange and, in overlap mode, every
+    hand-over between the dense-pass stream and the chain stream; a stale or torn read anywhere would leave a
+    trace in P that the rounding-level tolerance below cannot hide."""
+    N, M, steps = 2048, 4, 240
+    x0, P0 = pkg.scenarios.injected_state(N, seed=31)
+    sc = pkg.scenarios.steady_script(x0, steps=steps, M=M, seed=32)
+    outs = []
+    for max_pending in (1, 16):
+        f = pkg.FilterBatch(1, N, max_pending=max_pending)
+        f.set_state(x0, P0)
+        load_script(f, sc)
+        f.script_run(0, steps)
+        f.sync()
+        outs.append(f.get_state() + (f.decisions(0, steps * M),))
+        f.close()
+    (xe, Pe, de), (xd, Pd, dd) = outs
+    assert [(d[0], d[1]) for d in de] == [(d[0], d[1]) for d in dd]
+    assert [d[1] for d in dd] == [3 + 2 * int(t) for t in sc["target"].ravel()]
+    assert np.abs(xe - xd).max() <= 1e-10 * np.abs(xe).max()
+    assert np.abs(Pe - Pd).max() <= 1e-10 * np.abs(Pe).max()
+    assert_bitwise_symmetric(Pd)
