@@ -213,7 +213,7 @@ extern "C" int ekf_batch_create(ekf_handle *out, int batch, int capacity_landmar
         int g_max = EKF_CHAIN_MAX_WGS < 256 / batch ? EKF_CHAIN_MAX_WGS : 256 / batch;
         if (g_max < 1) g_max = 1;
         long lpw_min = (capacity_landmarks + g_max - 1) / g_max;
-        want_overlap = (lpw_min * maxp * 2 * 64 <= lds_budget) ? 1 : 0;
+        want_overlap = (lpw_min * maxp * 2 * 32 <= lds_budget) ? 1 : 0;
         // ... and when a dense pass is long enough to be worth hiding (P_LL of the whole batch >= 128 MB, a pass of
         // about 45 us): below that the chain kernels dominate and the second window's bookkeeping only costs
         size_t T = (2 * (size_t)capacity_landmarks + 63) / 64;
@@ -223,7 +223,7 @@ extern "C" int ekf_batch_create(ekf_handle *out, int batch, int capacity_landmar
     h->params.overlap = h->overlap ? 1 : 0;
     const int sets_in_lds = h->overlap ? 2 : 1;  // overlap: the set being folded by the dense pass in flight is still needed
     int G = (capacity_landmarks + max_workers - 1) / max_workers;
-    int G_lds = (int)(((long)capacity_landmarks * maxp * sets_in_lds * 64 + lds_budget - 1) / lds_budget);
+    int G_lds = (int)(((long)capacity_landmarks * maxp * sets_in_lds * 32 + lds_budget - 1) / lds_budget);
     if (G_lds > G) G = G_lds;
     if (G > EKF_CHAIN_MAX_WGS) G = EKF_CHAIN_MAX_WGS;
     if (G * batch > 256) G = 256 / batch;
@@ -233,8 +233,8 @@ extern "C" int ekf_batch_create(ekf_handle *out, int batch, int capacity_landmar
     h->chain_wgs = G;
     dv.gmax = G;
     dv.lpw = (capacity_landmarks + G - 1) / G;
-    if ((long)dv.lpw * maxp * sets_in_lds * 64 > lds_budget) {
-        maxp = (int)(lds_budget / ((long)dv.lpw * sets_in_lds * 64));
+    if ((long)dv.lpw * maxp * sets_in_lds * 32 > lds_budget) {
+        maxp = (int)(lds_budget / ((long)dv.lpw * sets_in_lds * 32));
         if (maxp > 1) maxp &= ~1;  // whole slot pairs
     }
     if (maxp < 1) return set_error(EKF_ERR_BAD_ARG, "capacity too large for this batch size (one window slot does not fit LDS)");
@@ -242,7 +242,7 @@ extern "C" int ekf_batch_create(ekf_handle *out, int batch, int capacity_landmar
     dv.maxp = maxp;
     dv.maxpairs = (dv.maxp + 1) / 2;
     dv.f_stride = (size_t)(dv.maxpairs + 1) * dv.rows * 4;
-    h->chain_lds = (size_t)dv.lpw * maxp * sets_in_lds * 64;
+    h->chain_lds = (size_t)dv.lpw * maxp * sets_in_lds * 32;
     HIP_TRY(hipFuncSetAttribute((const void *)k_chain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_budget));  // one setting for every handle
     int workers = (dv.lpw + 63) / 64 * 64;
     if (workers > max_workers) workers = max_workers;
@@ -262,6 +262,7 @@ extern "C" int ekf_batch_create(ekf_handle *out, int batch, int capacity_landmar
     HIP_TRY(dev_alloc_zero(&dv.n_lm_flush, B * 2, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.status, B, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.slot_active, B * 2 * dv.maxp, &h->device_bytes, s));
+    HIP_TRY(dev_alloc_zero(&dv.slot_meta, B * 2 * dv.maxp, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.bar, B * 2, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.dbg, 32, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.part, B * 2 * dv.gmax * EKF_REC_DOUBLES, &h->device_bytes, s));
@@ -364,7 +365,7 @@ extern "C" int ekf_destroy(ekf_handle h) {
     for (auto &g : h->graphs) hipGraphExecDestroy(g.exec);
     EkfDev &dv = h->dv;
     hipFree(dv.x), hipFree(dv.R), hipFree(dv.D), hipFree(dv.Bm[0]), hipFree(dv.FA), hipFree(dv.FB);
-    hipFree(dv.n_lm), hipFree(dv.n_lm_sweep), hipFree(dv.n_lm_flush), hipFree(dv.status), hipFree(dv.slot_active);
+    hipFree(dv.n_lm), hipFree(dv.n_lm_sweep), hipFree(dv.n_lm_flush), hipFree(dv.status), hipFree(dv.slot_active), hipFree(dv.slot_meta);
     hipFree(dv.bar), hipFree(dv.part), hipFree(dv.dbg);
     hipFree(dv.log), hipFree(dv.log_count), hipFree(dv.stats);
     hipFree(h->cursor_d);

@@ -42,6 +42,14 @@ enum { OP_NOP = 0, OP_PROP = 1, OP_MEAS = 2, OP_COMPASS = 3, OP_TRUTH = 4, OP_SK
 // header decisions (internal)
 enum { HDR_NONE = 0, HDR_NEW = 1, HDR_OLD = 2, HDR_IGNORE = 3, HDR_COMPASS = 4, HDR_NEW_NOFIT = 5 };
 
+// What kind of slot a measurement left behind, for the chain kernel's fold of the not-yet-flushed slots: an Old or
+// compass slot contributes -K_i S K_j^T (S kept here), a New slot the column pair of landmark ln.
+enum { SLOT_DEAD = 0, SLOT_OLD = 1, SLOT_NEW = 2 };
+struct SlotMeta {
+    int type, ln;
+    double S00, S01, S11;
+};
+
 // What the host wants to see after every call (kalmanfilter.h:24-27 mirrors, sticky status, the newest
 // gate decisions), written by k_chain into host-mapped pinned memory so that an API call needs no
 // device-to-host copy: synchronise the stream, then read.
@@ -73,6 +81,7 @@ struct EkfDev {
     int *n_lm, *n_lm_sweep, *status;
     int *n_lm_flush;   // [B][2]: landmark count when set s was last written (sizes its dense pass)
     int *slot_active;  // [B][2][maxp]
+    SlotMeta *slot_meta;  // [B][2][maxp], written with the slot
     int *bar;          // [B][2]: [0] = cross-workgroup exchanges done so far (tags of the records continue from it)
     long long *dbg;    // [32] diagnostics: tick counters of the control lane [0..7] and of the first worker [16..23] (EKF_CHAIN_STAMPS), first bad index [8..11] (EKF_CHAIN_CHECK)
     double *part;      // [B][2][gmax][EKF_REC_DOUBLES]: per-workgroup arg-min records, double-buffered by exchange parity

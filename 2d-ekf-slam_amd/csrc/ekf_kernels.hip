@@ -99,7 +99,12 @@ struct ChainLds {
     double KR[6], TR[6];                 // compass: rows 0..2 of K and of K*S in column 0 (kalmanfilter.cpp:118)
     double S0, invS, res0;               // compass: S, 1/S, residual
     // rows of the matched landmark in every slot of the set being filled, [slot][side A/B][row e][k] (dead slots: zeros)
-    alignas(16) double lo_rows[2 * EKF_MAX_PENDING * 8];
+    // per virtual slot (the set a dense pass is folding first, then the open set): what kind of slot it is, the matched
+    // landmark's cached rows loC (K rows of an Old slot, P_xL rows of a New one) and the 2x2 matrix M with
+    // P[own rows, matched columns] += own cached rows * M   (Old: M = -S K_lo^T; New: identity when the matched landmark is the new one)
+    SlotMeta sm[2 * EKF_MAX_PENDING];
+    alignas(16) double loC[2 * EKF_MAX_PENDING * 4];
+    alignas(16) double loM[2 * EKF_MAX_PENDING * 4];
 };
 
 // Header of the Old branch (Update.cpp:181-189): a pure function of the heading the sweep ran with and of the
@@ -294,7 +299,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                                                                 int nops, int slot0, int set, int buf_read, int n_prev) {
     __shared__ ChainLds L;
     __shared__ double recs[EKF_CHAIN_MAX_OPS * 8];
-    extern __shared__ double own_rows[];  // [slot][component 0..7 = A00 A01 A10 A11 B00 B01 B10 B11][local landmark]
+    extern __shared__ double own_rows[];  // [virtual slot][component 00 01 10 11][local landmark]: K rows (Old, compass), P_xL rows (New), zeros (dead)
     const int g = blockIdx.x, G = gridDim.x;
     const int b = blockIdx.y;
     const int tid = threadIdx.x;
@@ -356,12 +361,11 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
     // One landmark's two rows of a measurement's rank-2 slot: A rows (a00 a01 / a10 a11), B rows likewise.
     // Slots are stored in pairs (one k=4 MFMA operand): an even slot writes whole 32-byte rows and
     // zeroes its partner's half, an odd slot fills that half.
-    auto write_slot = [=](int lm, int slot, double a00, double a01, double a10, double a11, double b00, double b01, double b10, double b11) {
+    auto write_slot = [=](int lm, int slot, double a00, double a01, double a10, double a11, double b00, double b01, double b10, double b11, bool cache_a) {
         const size_t wo = CK(off_c + pair_offset(rows_, 2 * lm, slot >> 1), lim_F - 7) - off_c;
         double *fa = FAc + wo, *fb = FBc + wo;
-        double *cr = own_rows + (size_t)(n_prev + slot) * 8 * lpw_ + (lm - own_lo);
-        cr[0] = a00, cr[lpw_] = a01, cr[2 * lpw_] = a10, cr[3 * lpw_] = a11;
-        cr[4 * lpw_] = b00, cr[5 * lpw_] = b01, cr[6 * lpw_] = b10, cr[7 * lpw_] = b11;
+        double *cr = own_rows + (size_t)(n_prev + slot) * 4 * lpw_ + (lm - own_lo);  // the fold needs one side only: K S K^T is symmetric
+        cr[0] = cache_a ? a00 : b00, cr[lpw_] = cache_a ? a01 : b01, cr[2 * lpw_] = cache_a ? a10 : b10, cr[3 * lpw_] = cache_a ? a11 : b11;
         if ((slot & 1) == 0) {
             *(double4_t *)fa = (double4_t){a00, a01, 0, 0};
             *(double4_t *)(fa + 4) = (double4_t){a10, a11, 0, 0};
@@ -377,7 +381,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
     // a slot that changes nothing (Ignore, masked, no room) still writes zeros: its pair partner may be live
     auto zero_slot_rows = [=](int slot, int n_now) {
         const int hi = own_hi < n_now ? own_hi : n_now;
-        for (int lm = lm0; lm < hi; lm += nw) write_slot(lm, slot, 0, 0, 0, 0, 0, 0, 0, 0);  // zeros in HBM for the dense pass, zeros in LDS for the fold
+        for (int lm = lm0; lm < hi; lm += nw) write_slot(lm, slot, 0, 0, 0, 0, 0, 0, 0, 0, false);  // zeros in HBM for the dense pass, zeros in LDS for the fold
     };
     // Old branch for one landmark (Update.cpp:186-188,193-194): K rows, x += K res, robot rows and own block of
     // P, the slot.  p = P[rows of lm, columns of the matched landmark]; Prr and wv are the robot block the sweep
@@ -416,7 +420,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
         st.dyy -= sym_u(Tt[1][0], Tt[1][1], K[1][0], K[1][1], Tt[1][0], Tt[1][1], K[1][0], K[1][1]);
         lm_store(lm, st);
         // slot: P_LL -= T K^T (rank 2; K S K^T is symmetric, only one triangle is stored).  A = -T, B = K.
-        write_slot(lm, slot, -Tt[0][0], -Tt[0][1], -Tt[1][0], -Tt[1][1], K[0][0], K[0][1], K[1][0], K[1][1]);
+        write_slot(lm, slot, -Tt[0][0], -Tt[0][1], -Tt[1][0], -Tt[1][1], K[0][0], K[0][1], K[1][0], K[1][1], false);
     };
     // compass branch for one landmark (kalmanfilter.cpp:118-124): K = (1/S) P[:,2], header from LDS
     auto apply_compass = [=](int lm, LmState &st, int slot) {
@@ -434,7 +438,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
         st.dxy -= sym_u(Tt[0], 0, K[0], 0, Tt[1], 0, K[1], 0);
         st.dyy -= sym_u(Tt[1], 0, K[1], 0, Tt[1], 0, K[1], 0);
         lm_store(lm, st);
-        write_slot(lm, slot, -Tt[0], -0.0, -Tt[1], -0.0, K[0], 0, K[1], 0);
+        write_slot(lm, slot, -Tt[0], -0.0, -Tt[1], -0.0, K[0], 0, K[1], 0, false);
     };
     // New branch, an existing landmark lm < ln: its slot rows carry the new covariance column pair
     auto apply_new_column = [=](int lm, const LmState &st, int slot, double c, double s) {
@@ -449,7 +453,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
             v[a][0] = u0 * c + u1 * (-s);
             v[a][1] = u0 * s + u1 * c;
         }
-        write_slot(lm, slot, v[0][0], v[0][1], v[1][0], v[1][1], 0, 0, 0, 0);
+        write_slot(lm, slot, v[0][0], v[0][1], v[1][0], v[1][1], 0, 0, 0, 0, true);
     };
     // New branch, the appended landmark itself: state from the header, unit B rows
     auto apply_new_self = [=](int lm, LmState &st, int slot) {
@@ -458,26 +462,43 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
         st.dxx = L.newdd[0], st.dxy = L.newdd[1], st.dyy = L.newdd[2];
         lm_store(lm, st);
         for (int sl = 0; sl < n_prev + slot; sl++)  // the landmark did not exist in the earlier slots of the open windows
-            for (int cmp = 0; cmp < 8; cmp++) own_rows[((size_t)sl * 8 + cmp) * lpw_ + (lm - own_lo)] = 0.0;
-        write_slot(lm, slot, 0, 0, 0, 0, 1, 0, 0, 1);
+            for (int cmp = 0; cmp < 4; cmp++) own_rows[((size_t)sl * 4 + cmp) * lpw_ + (lm - own_lo)] = 0.0;
+        write_slot(lm, slot, 0, 0, 0, 0, 1, 0, 0, 1, true);  // (its own P_xL rows are zero: the 2x2 block lives in D)
+    };
+
+    // the control lane records what kind of slot the operation leaves (every workgroup in LDS, workgroup 0 also in HBM
+    // for later launches)
+    auto note_slot = [=](int slot, int type, int ln, double S00, double S01, double S11) {
+        SlotMeta m;
+        m.type = type, m.ln = ln, m.S00 = S00, m.S01 = S01, m.S11 = S11;
+        L.sm[n_prev + slot] = m;
+        if (lead) dv.slot_meta[((size_t)b * 2 + set) * dv.maxp + slot] = m;
     };
 
     // stage this filter's operation records in LDS (one trip to HBM / host memory for the whole list)
     for (int q = tid; q < nops * 8; q += bd) recs[q] = op_record(in, cursor, k0 + (q >> 3), dv.B, b)[q & 7];
-    if (worker) {  // slots filled by earlier launches: own rows back into LDS
+    // slots filled by earlier launches: their kinds, then the own rows back into LDS
+    for (int q = tid; q < n_prev + slot0; q += bd)
+        L.sm[q] = dv.slot_meta[((size_t)b * 2 + (q < n_prev ? (set ^ 1) : set)) * dv.maxp + (q < n_prev ? q : q - n_prev)];
+    __syncthreads();
+    unsigned long long new_mask = 0;  // virtual slots that appended a landmark (wave-uniform, kept by every thread)
+    for (int q = 0; q < n_prev + slot0; q++) new_mask |= (uni(L.sm[q].type) == SLOT_NEW ? 1ull : 0ull) << q;
+    if (worker) {
         const int n_now = dv.n_lm[b];
         const int hi = own_hi < n_now ? own_hi : n_now;
         for (int lm = lm0; lm < hi; lm += nw)
-            for (int vs = 0; vs < n_prev + slot0; vs++) {  // (dead slots hold zeros)
+            for (int vs = 0; vs < n_prev + slot0; vs++) {
                 const int sl = vs < n_prev ? vs : vs - n_prev;
+                const int type = uni(L.sm[vs].type);
+                double *cr = own_rows + (size_t)vs * 4 * lpw_ + (lm - own_lo);
+                if (type == SLOT_DEAD) {
+                    cr[0] = cr[lpw_] = cr[2 * lpw_] = cr[3 * lpw_] = 0.0;
+                    continue;
+                }
                 const size_t so = vs < n_prev ? (size_t)(set ^ 1) * dv.f_stride : off_c;
                 const size_t o = CK(so + pair_offset(rows_, 2 * lm, sl >> 1), lim_F - 7) + (sl & 1) * 2;
-                double *cr = own_rows + (size_t)vs * 8 * lpw_ + (lm - own_lo);
-                for (int a = 0; a < 2; a++)
-                    for (int k = 0; k < 2; k++) {
-                        cr[(a * 2 + k) * lpw_] = FAb[o + a * 4 + k];
-                        cr[(4 + a * 2 + k) * lpw_] = FBb[o + a * 4 + k];
-                    }
+                const double *F = type == SLOT_NEW ? FAb : FBb;
+                cr[0] = F[o], cr[lpw_] = F[o + 1], cr[2 * lpw_] = F[o + 4], cr[3 * lpw_] = F[o + 5];
             }
     }
     if (tid == 0) {
@@ -595,6 +616,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
             // a masked measurement: consumes its slot, changes nothing
             if (ctrl) {
                 if (lead) act_c[slot] = 0;
+                note_slot(slot, SLOT_DEAD, 0, 0, 0, 0);
                 RN = RS;
                 if (rec[6] == 2.0) RN.n_sweep = RS.n_lm;
             }
@@ -666,7 +688,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                     if (gi == best.lm)  // the lane that owns the local winner
                         for (int i = 0; i < 16; i++) put(rec + 2 * i, best.w[i]);
                     const double *wr = own_rows + (gi - own_lo);
-                    for (int q = tid; q < slot * 8; q += bd) put(rec + 2 * (16 + q), wr[(size_t)(n_prev * 8 + q) * lpw_]);  // the open set's rows (dead slots hold zeros)
+                    for (int q = tid; q < slot * 4; q += bd) put(rec + 2 * (16 + q), wr[(size_t)(n_prev * 4 + q) * lpw_]);  // the open set's cached rows (dead slots hold zeros)
                 }
                 // every wave polls the heads itself (lane l reads workgroup l's) and may then read the winner's body
                 const int lane = tid & 63;
@@ -742,54 +764,62 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                 if (worker && lm0 < hi && lm0 != w_lo) load_old_inputs(lm0, w_lo, pf_p);  // in flight across the barrier
                 // winner record and the matched landmark's slot rows into LDS: from the owner's published record, or,
                 // with one workgroup per filter, straight from registers and the own-row cache
-                if (G > 1) {
-                    // rows of the set a dense pass is folding: unchanged since the launch began, plain loads from the slot arrays
-                    const size_t off_p = (size_t)(set ^ 1) * dv.f_stride;
-                    for (int q = tid; q < n_prev * 8; q += bd) {
-                        const int sl = q >> 3, side = (q >> 2) & 1, e = (q >> 1) & 1, k = q & 1;
-                        L.lo_rows[q] = (side == 0 ? FAb : FBb)[CK(off_p + pair_offset(rows_, 2 * w_lo + e, sl >> 1) + (sl & 1) * 2 + k, lim_F)];
-                    }
-                    // winner data and the open set's rows: the owner's record.  All of a thread's granules are requested
-                    // together (one trip) and re-read until every one carries the tag of the exchange just done.
-                    const unsigned long long *wrec = (const unsigned long long *)(part + ((size_t)((epoch - 1) & 1) * dv.gmax + src) * EKF_REC_DOUBLES);
-                    const unsigned long long tag = (unsigned long long)(unsigned)(ebase + epoch) << 32;
-                    const int nq = 16 + slot * 8;
-                    unsigned long long g0[3], g1[3];  // 16 + 8 * EKF_MAX_PENDING items over >= 128 threads: at most 3 each
-                    long spins = 0;
-                    for (;;) {
-                        unsigned long long bad = 0;
+                // The matched landmark's cached rows of every unflushed slot -> loC, and from them the slot's 2x2 matrix M
+                // (one thread per virtual slot); the winner data -> L.w (threads 64..79).  With several workgroups per
+                // filter the open set's rows and the winner data come from the owner's record (all of a thread's granules
+                // requested together and re-read until every one carries the tag of the exchange just done); the rows of
+                // the set a dense pass is folding are unchanged since the launch began: plain loads from the slot arrays.
+                const int nvs = n_prev + slot;
+                {
+                    const bool slot_thread = tid < nvs;
+                    double c4[4] = {0, 0, 0, 0};
+                    if (G > 1) {
+                        const bool cur_thread = slot_thread && tid >= n_prev, w_thread = (tid >= 64 && tid < 80);  // (virtual slots: at most 2 * 32 threads)
+                        if (slot_thread && !cur_thread && L.sm[tid].type != SLOT_DEAD) {
+                            const size_t off_p = (size_t)(set ^ 1) * dv.f_stride;
+                            const double *F = (L.sm[tid].type == SLOT_NEW ? FAb : FBb) + CK(off_p + pair_offset(rows_, 2 * w_lo, tid >> 1), lim_F - 7) + (tid & 1) * 2;
+                            c4[0] = F[0], c4[1] = F[1], c4[2] = F[4], c4[3] = F[5];
+                        }
+                        const unsigned long long *wrec = (const unsigned long long *)(part + ((size_t)((epoch - 1) & 1) * dv.gmax + src) * EKF_REC_DOUBLES);
+                        const unsigned long long tag = (unsigned long long)(unsigned)(ebase + epoch) << 32;
+                        const unsigned long long *gp = cur_thread ? wrec + 2 * (16 + (tid - n_prev) * 4) : wrec + 2 * (tid - 64);
+                        const int ng = cur_thread ? 8 : (w_thread ? 2 : 0);
+                        unsigned long long g[8];
+                        long spins = 0;
+                        for (;;) {
+                            unsigned long long bad = 0;
 #pragma unroll
-                        for (int i = 0; i < 3; i++) {
-                            const int q = tid + i * bd;
-                            if (q < nq) {
-                                g0[i] = __hip_atomic_load(wrec + 2 * q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                g1[i] = __hip_atomic_load(wrec + 2 * q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            } else {
-                                g0[i] = g1[i] = tag;
+                            for (int i = 0; i < 8; i++) {
+                                g[i] = tag;
+                                if (i < ng) g[i] = __hip_atomic_load(gp + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                bad |= g[i] ^ tag;
+                            }
+                            if ((bad >> 32) == 0) break;
+                            if (++spins > (1L << 22)) {  // bounded
+                                dv.status[b] = EKF_ERR_HIP;
+                                break;
                             }
                         }
-#pragma unroll
-                        for (int i = 0; i < 3; i++) bad |= (g0[i] ^ tag) | (g1[i] ^ tag);
-                        if ((bad >> 32) == 0) break;
-                        if (++spins > (1L << 22)) {  // bounded
-                            dv.status[b] = EKF_ERR_HIP;
-                            break;
-                        }
+                        if (cur_thread)
+                            for (int j = 0; j < 4; j++) c4[j] = __longlong_as_double((long long)((g[2 * j + 1] << 32) | (g[2 * j] & 0xffffffffull)));
+                        if (w_thread) L.w[tid - 64] = __longlong_as_double((long long)((g[1] << 32) | (g[0] & 0xffffffffull)));
+                    } else {
+                        if (w_lo == best.lm)
+                            for (int i = 0; i < 16; i++) L.w[i] = best.w[i];
+                        if (slot_thread)
+                            for (int j = 0; j < 4; j++) c4[j] = own_rows[((size_t)tid * 4 + j) * lpw_ + (w_lo - own_lo)];
                     }
-#pragma unroll
-                    for (int i = 0; i < 3; i++) {
-                        const int q = tid + i * bd;
-                        if (q < nq) {
-                            const double v = __longlong_as_double((long long)((g1[i] << 32) | (g0[i] & 0xffffffffull)));
-                            if (q < 16) L.w[q] = v;
-                            else L.lo_rows[n_prev * 8 + q - 16] = v;
+                    if (slot_thread) {
+                        const SlotMeta m = L.sm[tid];
+                        double M[4] = {0, 0, 0, 0};  // M[k*2+e]
+                        if (m.type == SLOT_OLD) {   // -S K_lo^T, K_lo rows e = c4[2e], c4[2e+1]
+                            M[0] = -(m.S00 * c4[0] + m.S01 * c4[1]), M[1] = -(m.S00 * c4[2] + m.S01 * c4[3]);
+                            M[2] = -(m.S01 * c4[0] + m.S11 * c4[1]), M[3] = -(m.S01 * c4[2] + m.S11 * c4[3]);
+                        } else if (m.type == SLOT_NEW && m.ln == w_lo) {
+                            M[0] = 1.0, M[3] = 1.0;
                         }
+                        for (int j = 0; j < 4; j++) L.loC[tid * 4 + j] = c4[j], L.loM[tid * 4 + j] = M[j];
                     }
-                } else {
-                    if (w_lo == best.lm)
-                        for (int i = 0; i < 16; i++) L.w[i] = best.w[i];
-                    const double *wr = own_rows + (w_lo - own_lo);
-                    for (int q = tid; q < (n_prev + slot) * 8; q += bd) L.lo_rows[q] = wr[(size_t)q * lpw_];
                 }
                 __syncthreads();  // (3) staged rows visible
                 STAMP(4);
@@ -800,42 +830,47 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                         if (lm == w_lo) {
                             p[0][0] = st.dxx, p[0][1] = st.dxy, p[1][0] = st.dxy, p[1][1] = st.dyy;
                         } else {
-                            const bool below = lm < w_lo;  // stored as (row of the older landmark, column of the newer)
                             if (prefetched) {
                                 for (int a = 0; a < 2; a++)
                                     for (int e = 0; e < 2; e++) p[a][e] = pf_p[a][e];
                             } else {
                                 load_old_inputs(lm, w_lo, p);
                             }
-                            // the slots of this set are not in Bm yet: P[lm rows, lo cols] += sum_k A_lm[.,k] B_lo[.,k] (or B_lm A_lo)
-                            const double *own = own_rows + (below ? 0 : 4 * lpw_) + (lm - own_lo);
-                            const double *lr = L.lo_rows + (below ? 4 : 0);
+                            // the unflushed slots are not in Bm yet: P[lm rows, lo cols] += (own cached rows) * M_slot
+                            const double *own = own_rows + (lm - own_lo);
                             double pe[2][2] = {{0, 0}, {0, 0}}, po[2][2] = {{0, 0}, {0, 0}};  // even / odd slots: two dependency chains
-                            const int nvs = n_prev + slot;
                             int sl = 0;
-                            for (; sl + 4 <= nvs; sl += 4) {  // four slots per trip: 24 LDS reads requested before the first multiply
+                            for (; sl + 4 <= nvs; sl += 4) {  // four slots per trip: every LDS read requested before the first multiply
                                 double ow[4][4];
-                                double2_t qa[4], qb[4];
+                                double2_t ma[4], mb[4];
 #pragma unroll
                                 for (int j = 0; j < 4; j++) {
-                                    const double *o = own + (size_t)(sl + j) * 8 * lpw_, *q = lr + (sl + j) * 8;
+                                    const double *o = own + (size_t)(sl + j) * 4 * lpw_, *q = L.loM + (sl + j) * 4;
                                     ow[j][0] = o[0], ow[j][1] = o[lpw_], ow[j][2] = o[2 * lpw_], ow[j][3] = o[3 * lpw_];
-                                    qa[j] = *(const double2_t *)q, qb[j] = *(const double2_t *)(q + 2);
+                                    ma[j] = *(const double2_t *)q, mb[j] = *(const double2_t *)(q + 2);
                                 }
 #pragma unroll
                                 for (int j = 0; j < 4; j++) {
                                     double(*acc)[2] = (j & 1) ? po : pe;
-                                    acc[0][0] = fma(ow[j][1], qa[j].y, fma(ow[j][0], qa[j].x, acc[0][0]));
-                                    acc[0][1] = fma(ow[j][1], qb[j].y, fma(ow[j][0], qb[j].x, acc[0][1]));
-                                    acc[1][0] = fma(ow[j][3], qa[j].y, fma(ow[j][2], qa[j].x, acc[1][0]));
-                                    acc[1][1] = fma(ow[j][3], qb[j].y, fma(ow[j][2], qb[j].x, acc[1][1]));
+                                    acc[0][0] = fma(ow[j][1], mb[j].x, fma(ow[j][0], ma[j].x, acc[0][0]));
+                                    acc[0][1] = fma(ow[j][1], mb[j].y, fma(ow[j][0], ma[j].y, acc[0][1]));
+                                    acc[1][0] = fma(ow[j][3], mb[j].x, fma(ow[j][2], ma[j].x, acc[1][0]));
+                                    acc[1][1] = fma(ow[j][3], mb[j].y, fma(ow[j][2], ma[j].y, acc[1][1]));
                                 }
                             }
-                            for (; sl < nvs; sl++) {  // dead slots contribute exact zeros
-                                const double *o = own + (size_t)sl * 8 * lpw_, *q = lr + sl * 8;
+                            for (; sl < nvs; sl++) {
+                                const double *o = own + (size_t)sl * 4 * lpw_, *q = L.loM + sl * 4;
                                 const double o00 = o[0], o01 = o[lpw_], o10 = o[2 * lpw_], o11 = o[3 * lpw_];
-                                pe[0][0] += o00 * q[0] + o01 * q[1], pe[0][1] += o00 * q[2] + o01 * q[3];
-                                pe[1][0] += o10 * q[0] + o11 * q[1], pe[1][1] += o10 * q[2] + o11 * q[3];
+                                pe[0][0] += o00 * q[0] + o01 * q[2], pe[0][1] += o00 * q[1] + o01 * q[3];
+                                pe[1][0] += o10 * q[0] + o11 * q[2], pe[1][1] += o10 * q[1] + o11 * q[3];
+                            }
+                            // a landmark appended in one of these slots holds its column pair in the OTHER landmarks' rows
+                            for (unsigned long long nm = new_mask; nm; nm &= nm - 1) {
+                                const int vs = __builtin_ctzll(nm);
+                                if (uni(L.sm[vs].ln) == lm) {
+                                    const double *c = L.loC + vs * 4;  // rows e of the matched landmark, components k of the new one
+                                    pe[0][0] += c[0], pe[0][1] += c[2], pe[1][0] += c[1], pe[1][1] += c[3];
+                                }
                             }
                             for (int a = 0; a < 2; a++)
                                 for (int e = 0; e < 2; e++) p[a][e] += pe[a][e] + po[a][e];
@@ -863,12 +898,14 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                     sincos(RN.pose[2], &RN.s, &RN.c);
                     RN.n_lm = n_lm_before;
                     RN.n_sweep = (rec[6] == 2.0) ? n_lm_before : n_sweep;  // last measurement of the chunk
+                    note_slot(slot, SLOT_OLD, 0, h.S00, h.S01, h.S11);
                 }
                 STAMP(5);  // landmark part (workers) / robot block (control lane)
             } else {
                 // ---- New (Update.cpp:152-178), Ignore (:191), no room: rare, the control lane goes first ------------
                 if (ctrl) {
                     RN = RS;
+                    note_slot(slot, hdr == HDR_NEW ? SLOT_NEW : SLOT_DEAD, n_lm_before, 0, 0, 0);
                     if (hdr == HDR_NEW) {
                         const double c = RS.c, s = RS.s, px = RS.pose[0], py = RS.pose[1];
                         double Prr[9];
@@ -937,6 +974,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                     }
                 }
             }
+            if (hdr == HDR_NEW) new_mask |= 1ull << (n_prev + slot);
             __syncthreads();  // end of the measurement
             STAMP(6);
             cur ^= 1;
@@ -978,6 +1016,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                     L.TR[r * 2] = TR[r], L.TR[r * 2 + 1] = 0;
                 }
                 L.S0 = S;
+                note_slot(slot, SLOT_OLD, 0, S, 0, 0);  // K's second column is zero
                 L.invS = invS;
                 L.res0 = res;
                 if (lead) act_c[slot] = 1;

@@ -16,22 +16,25 @@ import sys
 
 COPY = re.compile(r"^\s*(v_mov_b32_e32|v_mov_b64_e32|v_accvgpr_write_b32|v_accvgpr_mov_b32)\s+[va]\[?\d+(:\d+)?\]?, [va]\[?\d+(:\d+)?\]?\s*$")
 WIDEN = re.compile(r"^\s*s_or_b64 exec, exec, s\[\d+:\d+\]")
+SAVEEXEC = re.compile(r"^\s*s_(and|andn2|or)_saveexec_b64 ")
 
 
 def main():
     path = sys.argv[1]
     min_copies = int(sys.argv[2]) if len(sys.argv) > 2 else 8  # a few copies are ordinary phi moves of the region itself
     lines = [l for l in open(path) if not re.match(r"^\s*(\.loc|;|\.Ltmp|\.cfi)", l)]
-    func, bad, run = None, [], 0
+    func, bad, run, body_only = None, [], 0, False
     for i, l in enumerate(lines):
         m = re.match(r"^(_Z\w+):", l)
         if m:
             func, run = m.group(1), 0
             continue
         if COPY.match(l):
+            if run == 0:  # copies that are the WHOLE body of a narrowed region are a predicated select, not a split
+                body_only = i > 0 and SAVEEXEC.match(lines[i - 1]) is not None
             run += 1
             continue
-        if WIDEN.match(l) and run >= min_copies:
+        if WIDEN.match(l) and run >= min_copies and not body_only:
             bad.append((func, i + 1, run))
         run = 0
     for f, ln, n in bad:
