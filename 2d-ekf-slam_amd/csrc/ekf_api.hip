@@ -420,7 +420,7 @@ static int close_set(ekf_batch *h) {
         h->chain_signalled = false;
         HIP_TRY(hipStreamWaitEvent(sf, h->ev_chain, 0));
     }
-    if ((nT_hi > 0 && !h->dbg_skip_flush) || h->overlap) {
+    if (!h->dbg_skip_flush && (nT_hi > 0 || h->overlap)) {
         if (nT_hi < 1) nT_hi = 1;
         int total = nT_hi * (nT_hi + 1) / 2;
         const int variant = h->overlap ? 2 : h->flush_variant;  // only the row-block form goes buffer to buffer

@@ -98,6 +98,7 @@ struct ChainLds {
     double newx[2], newrc[6], newdd[3];  // New landmark: state, P_R,new (3x2), 2x2 block
     double KR[6], TR[6];                 // compass: rows 0..2 of K and of K*S in column 0 (kalmanfilter.cpp:118)
     double S0, invS, res0;               // compass: S, 1/S, residual
+    double pa, pb;                       // Phi_R(0,2), Phi_R(1,2) of the Propagate the control lane has just done
     // rows of the matched landmark in every slot of the set being filled, [slot][side A/B][row e][k] (dead slots: zeros)
     // per virtual slot (the set a dense pass is folding first, then the open set): what kind of slot it is, the matched
     // landmark's cached rows loC (K rows of an Old slot, P_xL rows of a New one) and the 2x2 matrix M with
@@ -484,21 +485,27 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
     unsigned long long new_mask = 0;  // virtual slots that appended a landmark (wave-uniform, kept by every thread)
     for (int q = 0; q < n_prev + slot0; q++) new_mask |= (uni(L.sm[q].type) == SLOT_NEW ? 1ull : 0ull) << q;
     if (worker) {
+        // eight slots per trip, every load requested before the first LDS write (a dead slot's rows are zeros in HBM too)
         const int n_now = dv.n_lm[b];
         const int hi = own_hi < n_now ? own_hi : n_now;
+        const int nv0 = n_prev + slot0;
         for (int lm = lm0; lm < hi; lm += nw)
-            for (int vs = 0; vs < n_prev + slot0; vs++) {
-                const int sl = vs < n_prev ? vs : vs - n_prev;
-                const int type = uni(L.sm[vs].type);
-                double *cr = own_rows + (size_t)vs * 4 * lpw_ + (lm - own_lo);
-                if (type == SLOT_DEAD) {
-                    cr[0] = cr[lpw_] = cr[2 * lpw_] = cr[3 * lpw_] = 0.0;
-                    continue;
+            for (int v0 = 0; v0 < nv0; v0 += 8) {
+                double2_t lo2[8], hi2[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int vs = v0 + j < nv0 ? v0 + j : v0;  // (the tail re-reads the first slot of the trip)
+                    const int sl = vs < n_prev ? vs : vs - n_prev;
+                    const size_t so = vs < n_prev ? (size_t)(set ^ 1) * dv.f_stride : off_c;
+                    const double *F = ((new_mask >> vs) & 1 ? FAb : FBb) + CK(so + pair_offset(rows_, 2 * lm, sl >> 1), lim_F - 7) + (sl & 1) * 2;
+                    lo2[j] = *(const double2_t *)F, hi2[j] = *(const double2_t *)(F + 4);
                 }
-                const size_t so = vs < n_prev ? (size_t)(set ^ 1) * dv.f_stride : off_c;
-                const size_t o = CK(so + pair_offset(rows_, 2 * lm, sl >> 1), lim_F - 7) + (sl & 1) * 2;
-                const double *F = type == SLOT_NEW ? FAb : FBb;
-                cr[0] = F[o], cr[lpw_] = F[o + 1], cr[2 * lpw_] = F[o + 4], cr[3 * lpw_] = F[o + 5];
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                    if (v0 + j < nv0) {
+                        double *cr = own_rows + (size_t)(v0 + j) * 4 * lpw_ + (lm - own_lo);
+                        cr[0] = lo2[j].x, cr[lpw_] = lo2[j].y, cr[2 * lpw_] = hi2[j].x, cr[3 * lpw_] = hi2[j].y;
+                    }
             }
     }
     if (tid == 0) {
@@ -528,6 +535,58 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
     //  * everything a measurement's branch needs is a pure function of (L.rs[cur], the winner record L.w, L.gd,
     //    L.gi), so every thread evaluates the gate itself; in the Old branch the workers also rebuild the gain
     //    header themselves and update their landmarks WHILE the control lane updates the robot block.
+    // robot block of Propagate.cpp:15-75 (control lane); rec = (v, w, dt, q00, q10, q01, q11).  in and out may alias.
+    auto propagate_robot = [&](const RobotState &in, RobotState &out, const double *rec) {
+        const double v = rec[0], w = rec[1], dt = rec[2];
+        const double so = in.s, co = in.c;
+        const double pa = -dt * v * so, pb = dt * v * co;  // Phi_R = [[1,0,pa],[0,1,pb],[0,0,1]], :42-44
+        double Q[4] = {rec[3], rec[5], rec[4], rec[6]};  // row-major from column-major
+        double Prr[9], pose[3];
+        for (int i = 0; i < 9; i++) Prr[i] = in.Prr[i];
+        for (int i = 0; i < 3; i++) pose[i] = in.pose[i];
+        out.pose[0] = pose[0] + dt * (v * co);  // :33-38
+        out.pose[1] = pose[1] + dt * (v * so);
+        out.pose[2] = pose[2] + dt * w;
+        double Phi[9] = {1, 0, pa, 0, 1, pb, 0, 0, 1};
+        double Gm[6] = {-dt * co, 0, -dt * so, 0, 0, -dt};  // :46-48
+        double t1[9], t2[9], GQ[6], Pn[9];
+        // (Phi * P_RR) * Phi^T + (G * Q) * G^T, :53
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) t1[i * 3 + j] = Phi[i * 3] * Prr[j] + Phi[i * 3 + 1] * Prr[3 + j] + Phi[i * 3 + 2] * Prr[6 + j];
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) t2[i * 3 + j] = t1[i * 3] * Phi[j * 3] + t1[i * 3 + 1] * Phi[j * 3 + 1] + t1[i * 3 + 2] * Phi[j * 3 + 2];
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 2; j++) GQ[i * 2 + j] = Gm[i * 2] * Q[j] + Gm[i * 2 + 1] * Q[2 + j];
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) Pn[i * 3 + j] = t2[i * 3 + j] + (GQ[i * 2] * Gm[j * 2] + GQ[i * 2 + 1] * Gm[j * 2 + 1]);
+        // 0.5 (P + P^T), :66-67 (a no-op outside this block: P enters bitwise symmetric)
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) out.Prr[i * 3 + j] = 0.5 * (Pn[i * 3 + j] + Pn[j * 3 + i]);
+        sincos(out.pose[2], &out.s, &out.c);
+        const int n_lm = in.n_lm, n_sw = in.n_sweep;
+        out.n_lm = n_lm, out.n_sweep = n_sw;
+        L.pa = pa, L.pb = pb;
+    };
+    // NEES sample e^T P_RR^-1 e against rec = (x, y, phi); control lane of workgroup 0
+    auto nees_sample = [&](const RobotState &R, const double *rec) {
+        double e0 = R.pose[0] - rec[0], e1 = R.pose[1] - rec[1], e2 = R.pose[2] - rec[2];
+        e2 -= 6.283185307179586 * floor((e2 + 3.141592653589793) / 6.283185307179586);
+        double a = R.Prr[0], bb = R.Prr[1], c = R.Prr[2], d = R.Prr[4], e = R.Prr[5], f = R.Prr[8];
+        double A = d * f - e * e, Bc = c * e - bb * f, Cc = bb * e - c * d;
+        double det = a * A + bb * Bc + c * Cc;
+        double Dd = a * f - c * c, Ee = bb * c - a * e, Ff = a * d - bb * bb;
+        double q = e0 * (A * e0 + Bc * e1 + Cc * e2) + e1 * (Bc * e0 + Dd * e1 + Ee * e2) + e2 * (Cc * e0 + Ee * e1 + Ff * e2);
+        double nees = q / det;
+        if (det > 0.0 && nees >= 0.0 && nees < EKF_INF) {  // a fresh filter has P_RR = 0: no sample then
+            L.st.nees_sum += nees;
+            L.st.nees_count++;
+        }
+    };
+    // Look-ahead: when an Old measurement is followed by [truth samples and] a Propagate, the control lane does those
+    // robot-block operations under the workers' landmark update; ahead_prop = index of that Propagate (workers then only
+    // touch their own rows, no barrier), operations before it are skipped.  Wave-uniform, kept by every thread.
+    int ahead_prop = -1;
+
     int slot = slot0;
     int cur = 0;
     for (int op = 0; op < nops; op++) {
@@ -536,37 +595,17 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
         const RobotState &RS = L.rs[cur];
         RobotState &RN = L.rs[cur ^ 1];
 
+        if (op < ahead_prop) continue;  // truth samples the control lane has already taken
         if (type == OP_PROP) {
-            // ---- Propagate.cpp:15-75; rec = (v, w, dt, q00, q10, q01, q11) -------------------------
-            const double v = rec[0], dt = rec[2];
-            const double so = RS.s, co = RS.c;
-            const double pa = -dt * v * so, pb = dt * v * co;  // Phi_R = [[1,0,pa],[0,1,pb],[0,0,1]], :42-44
-            if (ctrl) {
-                double w = rec[1];
-                double Q[4] = {rec[3], rec[5], rec[4], rec[6]};  // row-major from column-major
-                double Prr[9];
-                for (int i = 0; i < 9; i++) Prr[i] = RS.Prr[i];
-                RN.pose[0] = RS.pose[0] + dt * (v * co);  // :33-38
-                RN.pose[1] = RS.pose[1] + dt * (v * so);
-                RN.pose[2] = RS.pose[2] + dt * w;
-                double Phi[9] = {1, 0, pa, 0, 1, pb, 0, 0, 1};
-                double Gm[6] = {-dt * co, 0, -dt * so, 0, 0, -dt};  // :46-48
-                double t1[9], t2[9], GQ[6], Pn[9];
-                // (Phi * P_RR) * Phi^T + (G * Q) * G^T, :53
-                for (int i = 0; i < 3; i++)
-                    for (int j = 0; j < 3; j++) t1[i * 3 + j] = Phi[i * 3] * Prr[j] + Phi[i * 3 + 1] * Prr[3 + j] + Phi[i * 3 + 2] * Prr[6 + j];
-                for (int i = 0; i < 3; i++)
-                    for (int j = 0; j < 3; j++)
-                        t2[i * 3 + j] = t1[i * 3] * Phi[j * 3] + t1[i * 3 + 1] * Phi[j * 3 + 1] + t1[i * 3 + 2] * Phi[j * 3 + 2];
-                for (int i = 0; i < 3; i++)
-                    for (int j = 0; j < 2; j++) GQ[i * 2 + j] = Gm[i * 2] * Q[j] + Gm[i * 2 + 1] * Q[2 + j];
-                for (int i = 0; i < 3; i++)
-                    for (int j = 0; j < 3; j++) Pn[i * 3 + j] = t2[i * 3 + j] + (GQ[i * 2] * Gm[j * 2] + GQ[i * 2 + 1] * Gm[j * 2 + 1]);
-                // 0.5 (P + P^T), :66-67 (a no-op outside this block: P enters bitwise symmetric)
-                for (int i = 0; i < 3; i++)
-                    for (int j = 0; j < 3; j++) RN.Prr[i * 3 + j] = 0.5 * (Pn[i * 3 + j] + Pn[j * 3 + i]);
-                sincos(RN.pose[2], &RN.s, &RN.c);
-                RN.n_lm = RS.n_lm, RN.n_sweep = RS.n_sweep;
+            // ---- Propagate.cpp:15-75 -----------------------------------------------------------------
+            const bool done_ahead = (op == ahead_prop);  // robot block already in rs[cur], Phi_R's entries in L.pa / L.pb
+            ahead_prop = -1;
+            double pa, pb;
+            if (done_ahead) {
+                pa = L.pa, pb = L.pb;
+            } else {
+                pa = -rec[2] * rec[0] * RS.s, pb = rec[2] * rec[0] * RS.c;  // Phi_R = [[1,0,pa],[0,1,pb],[0,0,1]], :42-44
+                if (ctrl) propagate_robot(RS, RN, rec);
             }
             // P_RL <- Phi_R P_RL (:56); P_LR is the same storage.  Needs only the OLD heading: no waiting.
             if (worker) {
@@ -588,27 +627,15 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                         Rj[xs] = Rj[xs] + pb * p2;
                     }
             }
-            __syncthreads();
-            cur ^= 1;
+            if (!done_ahead) {
+                __syncthreads();
+                cur ^= 1;
+            }
             continue;
         }
 
         if (type == OP_TRUTH) {
-            // NEES sample e^T P_RR^-1 e against rec = (x, y, phi); control lane of workgroup 0 only, no barrier
-            if (ctrl && lead) {
-                double e0 = RS.pose[0] - rec[0], e1 = RS.pose[1] - rec[1], e2 = RS.pose[2] - rec[2];
-                e2 -= 6.283185307179586 * floor((e2 + 3.141592653589793) / 6.283185307179586);
-                double a = RS.Prr[0], bb = RS.Prr[1], c = RS.Prr[2], d = RS.Prr[4], e = RS.Prr[5], f = RS.Prr[8];
-                double A = d * f - e * e, Bc = c * e - bb * f, Cc = bb * e - c * d;
-                double det = a * A + bb * Bc + c * Cc;
-                double Dd = a * f - c * c, Ee = bb * c - a * e, Ff = a * d - bb * bb;
-                double q = e0 * (A * e0 + Bc * e1 + Cc * e2) + e1 * (Bc * e0 + Dd * e1 + Ee * e2) + e2 * (Cc * e0 + Ee * e1 + Ff * e2);
-                double nees = q / det;
-                if (det > 0.0 && nees >= 0.0 && nees < EKF_INF) {  // a fresh filter has P_RR = 0: no sample then
-                    L.st.nees_sum += nees;
-                    L.st.nees_count++;
-                }
-            }
+            if (ctrl && lead) nees_sample(RS, rec);  // control lane of workgroup 0 only, no barrier
             continue;
         }
 
@@ -757,6 +784,12 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
             }
 
             if (hdr == HDR_OLD) {
+                ahead_prop = -1;
+                {
+                    int k = op + 1;
+                    while (k < nops && uni((int)recs[k * 8 + 7]) == OP_TRUTH) k++;
+                    if (k < nops && uni((int)recs[k * 8 + 7]) == OP_PROP) ahead_prop = k;
+                }
                 // ---- Old, Update.cpp:181-189.  Workers: request the matched landmark's slot rows (into LDS) and their
                 // own P_LL entries and slot rows (into registers), barrier, fold, gain, store.  Control lane: robot block.
                 const int hi = own_hi < n_lm_before ? own_hi : n_lm_before;
@@ -899,6 +932,11 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                     RN.n_lm = n_lm_before;
                     RN.n_sweep = (rec[6] == 2.0) ? n_lm_before : n_sweep;  // last measurement of the chunk
                     note_slot(slot, SLOT_OLD, 0, h.S00, h.S01, h.S11);
+                    if (ahead_prop >= 0) {  // the robot block of the coming Propagate, and the truth samples before it
+                        for (int k = op + 1; k < ahead_prop; k++)
+                            if (lead) nees_sample(RN, recs + k * 8);
+                        propagate_robot(RN, RN, recs + ahead_prop * 8);
+                    }
                 }
                 STAMP(5);  // landmark part (workers) / robot block (control lane)
             } else {
