@@ -139,8 +139,23 @@ static bool pool_take(int device, int keep, hipStream_t *out) {
     return false;
 }
 
-static void pool_give(int device, int keep, hipStream_t s) {
+// Idle streams are destroyed when the process exits, before the HIP runtime's own teardown (atexit handlers run in
+// reverse order of registration, and the runtime was loaded first): streams left alive crashed rocprofv3's finalisation.
+static void pool_drain() {
     std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (auto &p : g_pool) {
+        if (hipSetDevice(p.device) == hipSuccess) hipStreamDestroy(p.s);
+    }
+    g_pool.clear();
+}
+
+static void pool_give(int device, int keep, hipStream_t s) {
+    static bool registered = false;
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    if (!registered) {
+        atexit(pool_drain);
+        registered = true;
+    }
     g_pool.push_back({device, keep, s});
 }
 
