@@ -99,6 +99,8 @@ struct ChainLds {
     double KR[6], TR[6];                 // compass: rows 0..2 of K and of K*S in column 0 (kalmanfilter.cpp:118)
     double S0, invS, res0;               // compass: S, 1/S, residual
     double pa, pb;                       // Phi_R(0,2), Phi_R(1,2) of the Propagate the control lane has just done
+    double xd;                           // the filter-wide pick of the exchange: distance, landmark, owning workgroup
+    int xi, xsrc;
     // rows of the matched landmark in every slot of the set being filled, [slot][side A/B][row e][k] (dead slots: zeros)
     // per virtual slot (the set a dense pass is folding first, then the open set): what kind of slot it is, the matched
     // landmark's cached rows loC (K rows of an Old slot, P_xL rows of a New one) and the 2x2 matrix M with
@@ -717,32 +719,43 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                     const double *wr = own_rows + (gi - own_lo);
                     for (int q = tid; q < slot * 4; q += bd) put(rec + 2 * (16 + q), wr[(size_t)(n_prev * 4 + q) * lpw_]);  // the open set's cached rows (dead slots hold zeros)
                 }
-                // every wave polls the heads itself (lane l reads workgroup l's) and may then read the winner's body
+                // The control wave polls the heads (lane l reads workgroup l's), picks, and hands the result to the workers
+                // through LDS and one workgroup barrier: a third of the polling loads of "every wave for itself", and the
+                // control wave has nothing else to do here.  (EKF_POLL_ALL builds keep the every-wave form.)
                 const int lane = tid & 63;
-                const unsigned long long *hd = (const unsigned long long *)(part + ((size_t)(epoch & 1) * dv.gmax + (lane < G ? lane : 0)) * EKF_REC_DOUBLES) + 2 * EKF_REC_HEAD;
-                unsigned long long h0 = 0, h1 = 0, h2 = 0;
-                long spins = 0;
-                for (;;) {
-                    h0 = __hip_atomic_load(hd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    h1 = __hip_atomic_load(hd + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    h2 = __hip_atomic_load(hd + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const bool ok = lane >= G || (((h0 ^ tag) >> 32) == 0 && ((h1 ^ tag) >> 32) == 0 && ((h2 ^ tag) >> 32) == 0);
-                    if (__all(ok)) break;
-                    if (++spins > (1L << 22)) {  // bounded: a lost workgroup must not hang the GPU
-                        if (lane == 0) dv.status[b] = EKF_ERR_HIP;
-                        break;
+#ifndef EKF_POLL_ALL
+                if (!worker) {
+#endif
+                    const unsigned long long *hd = (const unsigned long long *)(part + ((size_t)(epoch & 1) * dv.gmax + (lane < G ? lane : 0)) * EKF_REC_DOUBLES) + 2 * EKF_REC_HEAD;
+                    unsigned long long h0 = 0, h1 = 0, h2 = 0;
+                    long spins = 0;
+                    for (;;) {
+                        h0 = __hip_atomic_load(hd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        h1 = __hip_atomic_load(hd + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        h2 = __hip_atomic_load(hd + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const bool ok = lane >= G || (((h0 ^ tag) >> 32) == 0 && ((h1 ^ tag) >> 32) == 0 && ((h2 ^ tag) >> 32) == 0);
+                        if (__all(ok)) break;
+                        if (++spins > (1L << 22)) {  // bounded: a lost workgroup must not hang the GPU
+                            if (lane == 0) dv.status[b] = EKF_ERR_HIP;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(1);
                     }
-                    __builtin_amdgcn_s_sleep(1);
+                    double d = EKF_INF;
+                    int i = 0x7fffffff;
+                    src = lane;
+                    if (lane < G) {
+                        d = __longlong_as_double((long long)((h1 << 32) | (h0 & 0xffffffffull)));
+                        i = (int)(unsigned)(h2 & 0xffffffffull);
+                    }
+                    wave_argmin(d, i, src);
+                    gd = d, gi = i;
+#ifndef EKF_POLL_ALL
+                    if (lane == 0) L.xd = d, L.xi = i, L.xsrc = src;
                 }
-                double d = EKF_INF;
-                int i = 0x7fffffff;
-                src = lane;
-                if (lane < G) {
-                    d = __longlong_as_double((long long)((h1 << 32) | (h0 & 0xffffffffull)));
-                    i = (int)(unsigned)(h2 & 0xffffffffull);
-                }
-                wave_argmin(d, i, src);
-                gd = d, gi = i;
+                __syncthreads();  // (X) the pick is known to every wave
+                gd = L.xd, gi = uni(L.xi), src = uni(L.xsrc);
+#endif
                 epoch++;
                 STAMP(2);  // publish + poll + pick
             }
