@@ -443,3 +443,45 @@ def test_long_run_window_16_matches_eager(pkg):
     assert np.abs(xe - xd).max() <= 1e-10 * np.abs(xe).max()
     assert np.abs(Pe - Pd).max() <= 1e-10 * np.abs(Pe).max()
     assert_bitwise_symmetric(Pd)
+
+
+@pytest.mark.parametrize("wgs,N", [(1, 500), (2, 700)])
+def test_several_landmarks_per_worker_thread(pkg, oc, monkeypatch, wgs, N):
+    """More landmarks than worker threads in a workgroup (EKF_CHAIN_WGS forces few workgroups): the second and third
+    landmark of a thread live in memory, not in registers -- sweep, gain, New column and the LDS copy take their loop
+    forms.  A scripted lifecycle (New / Old / Ignore) on a small map and a steady run on a map that fills the threads."""
+    monkeypatch.setenv("EKF_CHAIN_WGS", str(wgs))
+    # steady state, every thread owns two or three landmarks
+    M, steps = 4, 10
+    x0, P0 = pkg.scenarios.injected_state(N, seed=77)
+    sc = pkg.scenarios.steady_script(x0, steps=steps, M=M, seed=78)
+    f = pkg.FilterBatch(1, N, max_pending=8)
+    f.set_state(x0, P0)
+    load_script(f, sc)
+    f.script_run(0, steps)
+    f.sync()
+    xg, Pg = f.get_state()
+    xo, Po, decs = run_oracle_script(oc, x0, P0, sc, steps, M)
+    assert [(d[0], d[1]) for d in f.decisions(0, steps * M)] == decs
+    assert_state_close(xg, Pg, xo, Po, "N=%d on %d workgroup(s)" % (N, wgs))
+    assert_bitwise_symmetric(Pg)
+    f.close()
+    # growth from the empty map inside the same geometry
+    steps, M = 120, 3
+    script, ctrl, z, R, valid = lifecycle_as_script(pkg, steps, M)
+    f = pkg.FilterBatch(1, N, max_pending=6, log_capacity=1024)
+    f.script_load(ctrl, z, R, valid=valid)
+    f.script_run(0, steps)
+    f.sync()
+    x, P = np.zeros(3), np.zeros((3, 3))
+    decs = []
+    for st in script:
+        x, P = oc.propagate(x, P, st["v"], st["w"], oc.make_Q(st["v"]), st["dt"])
+        for fx, fy in st["feats_mm"]:
+            zz, RR = oc.make_measurement(fx, fy)
+            x, P, dec, mat, _ = oc.update(x, P, zz.reshape(2, 1), RR)
+            decs.append((dec[0], mat[0]))
+    assert [(d[0], d[1]) for d in f.decisions(0, len(decs))] == decs
+    xg, Pg = f.get_state()
+    assert_state_close(xg, Pg, x, P, "lifecycle, capacity %d on %d workgroup(s)" % (N, wgs))
+    f.close()
