@@ -8,6 +8,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <string>
 #include <mutex>
@@ -51,6 +52,8 @@ struct ekf_batch {
     hipEvent_t ev_chain, ev_flush[2];
     int ev_idx;           // ev_flush[ev_idx] belongs to the dense pass launched last
     bool chain_signalled; // the last chain launch carried ev_chain as its stop event
+    long long chain_seq;  // chain launches so far; the kernel stores it into the host mirror when it is done
+    bool mirror_by_chain; // the newest writer of the host mirror is chain launch number chain_seq (else: some other kernel, synchronise)
     int flush_keep;       // pool key of s_flush: CUs kept free for the chain, -1 = unmasked
     int chain_wgs;        // k_chain workgroups per filter
     size_t chain_lds;     // dynamic LDS of a k_chain launch: the own-row cache
@@ -315,6 +318,8 @@ extern "C" int ekf_batch_create(ekf_handle *out, int batch, int capacity_landmar
     h->prev_pending = 0;
     h->ev_idx = 0;
     h->chain_signalled = false;
+    h->chain_seq = 0;
+    h->mirror_by_chain = false;
     h->s_flush = h->s_chain;
     if (h->overlap) {
         // The chain kernel needs its workgroups' CUs the moment it is launched; a dense pass that owns every CU
@@ -507,7 +512,8 @@ static int launch_ops(ekf_batch *h, const double *in, const int *cursor, int k0,
         const bool closes = h->overlap && used == h->dv.maxp;
         hipExtLaunchKernelGGL(k_chain, dim3(h->chain_wgs, h->dv.B), dim3(h->chain_threads), h->chain_lds, h->s_chain, nullptr,
                               closes ? h->ev_chain : nullptr, 0, h->dv, in, cursor, k0 + start, i - start, h->pending, h->cur_set, h->buf_in,
-                              h->prev_pending);
+                              h->prev_pending, ++h->chain_seq);
+        h->mirror_by_chain = true;
         h->chain_signalled = closes;
         h->pending = used;
         if (used == h->dv.maxp) {
@@ -543,8 +549,35 @@ static int ring_reserve(ekf_batch *h, int count, double **rec, int *k_out) {
     return EKF_OK;
 }
 
-static int refresh_bounds(ekf_batch *h) {  // synchronises the stream, then reads the host-mapped mirror
-    HIP_TRY(hipStreamSynchronize(h->s_chain));
+// Wait until the newest chain launch has written the host-mapped mirror, then read it.  When that launch is the
+// newest writer the host spins on the mirror's sequence number (stored last by the kernel, system scope) for up to
+// a millisecond -- a stream synchronise costs 10-20 us of wake-up latency per call, which is most of an
+// immediate-mode call -- and falls back to the synchronise.  full = true always synchronises (callers that go on to
+// read device memory written by the whole launch).
+static int refresh_bounds(ekf_batch *h, bool full = true) {
+    bool done = false;
+    if (!full && h->mirror_by_chain && h->chain_seq > 0) {
+        timespec t0, t1;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        for (long spin = 0;; spin++) {
+            bool all = true;
+            for (int b = 0; b < h->dv.B; b++)
+                if (__atomic_load_n(&h->mirror_h[b].seq, __ATOMIC_ACQUIRE) < h->chain_seq) {
+                    all = false;
+                    break;
+                }
+            if (all) {
+                done = true;
+                break;
+            }
+            if ((spin & 255) == 255) {
+                clock_gettime(CLOCK_MONOTONIC, &t1);
+                if ((t1.tv_sec - t0.tv_sec) * 1000000000L + (t1.tv_nsec - t0.tv_nsec) > 1000000L) break;
+            }
+            __builtin_ia32_pause();
+        }
+    }
+    if (!done) HIP_TRY(hipStreamSynchronize(h->s_chain));
     int mx = 0;
     for (int b = 0; b < h->dv.B; b++) {
         h->h_int[b] = h->mirror_h[b].n_lm;
@@ -698,7 +731,7 @@ extern "C" int ekf_flush(ekf_handle h) {
 extern "C" int ekf_batch_get_pose(ekf_handle h, double *pose_out) {
     if (!h || !pose_out) return set_error(EKF_ERR_BAD_ARG, "null argument");
     HIP_TRY(hipSetDevice(h->device));
-    int rc = refresh_bounds(h);
+    int rc = refresh_bounds(h, false);
     if (rc) return rc;
     for (int b = 0; b < h->dv.B; b++)
         for (int i = 0; i < 3; i++) pose_out[3 * b + i] = h->mirror_h[b].pose[i];
@@ -713,7 +746,7 @@ extern "C" int ekf_get_pose(ekf_handle h, double pose_out[3]) {
 extern "C" int ekf_batch_num_landmarks(ekf_handle h, int *n_out) {
     if (!h || !n_out) return set_error(EKF_ERR_BAD_ARG, "null argument");
     HIP_TRY(hipSetDevice(h->device));
-    int rc = refresh_bounds(h);
+    int rc = refresh_bounds(h, false);
     if (rc) return rc;
     for (int b = 0; b < h->dv.B; b++) n_out[b] = h->h_int[b];
     return EKF_OK;
@@ -750,7 +783,7 @@ static int fetch_decisions(ekf_batch *h, int n_z, ekf_decision *out) {
     // [batch][n_z]: the last entries of every filter's log.  Masked measurements leave no entry, so a
     // filter with fewer real entries gets zeroed records in front.
     int B = h->dv.B;
-    int rc = refresh_bounds(h);  // synchronises
+    int rc = refresh_bounds(h, false);  // synchronises
     if (rc) return rc;
     for (int b = 0; b < B; b++) {
         long long cnt = h->mirror_h[b].log_count;
@@ -850,6 +883,7 @@ extern "C" int ekf_set_state(ekf_handle h, int index, const double *x, const dou
     if (e == hipSuccess) {
         hipLaunchKernelGGL(k_import, dim3(cdiv(n, 256), n), dim3(256), 0, s, dv, index, h->buf_in, (const double *)xd, (const double *)stage, n, n);
         hipLaunchKernelGGL(k_set_meta, dim3(1), dim3(64), 0, s, dv, index, N);
+        h->mirror_by_chain = false;
         e = hipStreamSynchronize(s);
     }
     hipFree(stage);
@@ -882,6 +916,7 @@ extern "C" int ekf_broadcast_state(ekf_handle h) {
     }
     HIP_TRY(hipStreamSynchronize(s));
     for (int b = 1; b < dv.B; b++) hipLaunchKernelGGL(k_set_meta, dim3(1), dim3(64), 0, s, dv, b, h->mirror_h[0].n_lm);  // also refreshes the host mirror
+    h->mirror_by_chain = false;
     return refresh_bounds(h);
 }
 

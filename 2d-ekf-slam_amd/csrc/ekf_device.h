@@ -59,6 +59,7 @@ struct EkfMirror {
     int n_lm;
     int status;
     long long log_count;
+    long long seq;  // number of the chain launch that wrote this mirror last (stored last, system scope): the host may spin on it
     ekf_decision last[EKF_MIRROR_DECISIONS];  // entry i of the log lives at last[i % 64]
 };
 

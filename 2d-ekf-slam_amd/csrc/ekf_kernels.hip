@@ -299,7 +299,7 @@ __device__ __forceinline__ void sweep_one(int lm, const LmState &st, double z0, 
 }
 
 __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, const double *in, const int *cursor, int k0,
-                                                                int nops, int slot0, int set, int buf_read, int n_prev) {
+                                                                int nops, int slot0, int set, int buf_read, int n_prev, long long launch_seq) {
     __shared__ ChainLds L;
     __shared__ double recs[EKF_CHAIN_MAX_OPS * 8];
     extern __shared__ double own_rows[];  // [virtual slot][component 00 01 10 11][local landmark]: K rows (Old, compass), P_xL rows (New), zeros (dead)
@@ -1112,6 +1112,9 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
             for (int i = 0; i < L.n_dec; i++) mr->last[(L.log_count - L.n_dec + i) % EKF_MIRROR_DECISIONS] = L.dec_buf[i];
             mr->status = dv.status[b];
             mr->log_count = L.log_count;
+            // everything above is in host memory before the sequence number is: a host thread spinning on seq reads a complete mirror
+            __atomic_thread_fence(__ATOMIC_RELEASE);
+            __hip_atomic_store(&mr->seq, launch_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         // (a workgroup can only get here after every workgroup of the filter has read ebase: it took part in each exchange)
         if (lead && epoch > 0) bar[0] = ebase + epoch;
