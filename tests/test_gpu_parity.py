@@ -485,3 +485,25 @@ def test_several_landmarks_per_worker_thread(pkg, oc, monkeypatch, wgs, N):
     xg, Pg = f.get_state()
     assert_state_close(xg, Pg, x, P, "lifecycle, capacity %d on %d workgroup(s)" % (N, wgs))
     f.close()
+
+
+def test_window_and_overlap_resolution(pkg, monkeypatch):
+    """ekf_window / ekf_overlap report what the handle really does: the window is shortened when capacity x window
+    does not fit the chain kernel's LDS (32 bytes per landmark and slot), ekf_params.overlap is honoured when the
+    environment does not override it, and the automatic setting leaves small covariances in place."""
+    monkeypatch.delenv("EKF_OVERLAP", raising=False)
+    f = pkg.FilterBatch(1, 300, max_pending=16)
+    assert f.window == 16 and not f.overlap  # automatic: P_LL far below 128 MB
+    f.close()
+    f = pkg.FilterBatch(1, 300, max_pending=16, overlap=1)
+    assert f.overlap and f.window == 16
+    f.close()
+    f = pkg.FilterBatch(1, 300, max_pending=16, overlap=0)
+    assert not f.overlap
+    f.close()
+    f = pkg.FilterBatch(256, 512, max_pending=16)  # one workgroup per filter: 512 landmarks x 16 slots x 32 B > 148 KB
+    assert f.window == 8 and not f.overlap
+    f.close()
+    f = pkg.FilterBatch(1, 1, max_pending=1)
+    assert f.window == 1
+    f.close()
