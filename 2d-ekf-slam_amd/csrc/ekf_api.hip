@@ -57,6 +57,7 @@ struct ekf_batch {
     int flush_keep;       // pool key of s_flush: CUs kept free for the chain, -1 = unmasked
     int chain_wgs;        // k_chain workgroups per filter
     size_t chain_lds;     // dynamic LDS of a k_chain launch: the own-row cache
+    double *bm1_base;     // allocation behind dv.Bm[1] (overlap mode)
     size_t device_bytes;
     int chain_threads;
     // host-side tracking
@@ -271,7 +272,13 @@ extern "C" int ekf_batch_create(ekf_handle *out, int batch, int capacity_landmar
     HIP_TRY(dev_alloc_zero(&dv.R, B * 3 * dv.xs, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.D, B * 3 * dv.dn, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.Bm[0], B * dv.bm_stride, &h->device_bytes, s));
-    if (h->overlap) HIP_TRY(dev_alloc_zero(&dv.Bm[1], B * dv.bm_stride, &h->device_bytes, s));  // the dense pass goes buffer to buffer
+    if (h->overlap) {  // the dense pass goes buffer to buffer
+        // The second buffer is shifted by 4 KB against the first so that a tile's source and destination differ in DRAM
+        // channel/bank phase: 107-108 us per pass instead of 110-111 (scripts/exp_skew.sh; EKF_BM_SKEW overrides, bytes)
+        size_t skew = (getenv("EKF_BM_SKEW") ? (size_t)atol(getenv("EKF_BM_SKEW")) : (size_t)4096) / sizeof(double);
+        HIP_TRY(dev_alloc_zero(&h->bm1_base, B * dv.bm_stride + skew, &h->device_bytes, s));
+        dv.Bm[1] = h->bm1_base + skew;
+    }
     else dv.Bm[1] = dv.Bm[0];  // one buffer: the dense pass runs in place
     HIP_TRY(dev_alloc_zero(&dv.FA, B * 2 * dv.f_stride, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.FB, B * 2 * dv.f_stride, &h->device_bytes, s));
@@ -380,7 +387,7 @@ extern "C" int ekf_destroy(ekf_handle h) {
         hipStreamSynchronize(h->s_flush);
         hipEventDestroy(h->ev_chain), hipEventDestroy(h->ev_flush[0]), hipEventDestroy(h->ev_flush[1]);
         pool_give(h->device, h->flush_keep, h->s_flush);
-        hipFree(h->dv.Bm[1]);
+        hipFree(h->bm1_base);
     }
     for (auto &g : h->graphs) hipGraphExecDestroy(g.exec);
     EkfDev &dv = h->dv;
