@@ -52,6 +52,8 @@ struct ekf_batch {
     hipEvent_t ev_chain, ev_flush[2];
     int ev_idx;           // ev_flush[ev_idx] belongs to the dense pass launched last
     bool chain_signalled; // the last chain launch carried ev_chain as its stop event
+    int pass_seq;         // dense passes launched so far (overlap mode); k_mark stores it into dv.pass_flag behind each pass
+    int need_pass;        // the pass the next chain launches have to wait for in-kernel, 0 = none
     long long chain_seq;  // chain launches so far; the kernel stores it into the host mirror when it is done
     bool mirror_by_chain; // the newest writer of the host mirror is chain launch number chain_seq (else: some other kernel, synchronise)
     int flush_keep;       // pool key of s_flush: CUs kept free for the chain, -1 = unmasked
@@ -288,6 +290,7 @@ extern "C" int ekf_batch_create(ekf_handle *out, int batch, int capacity_landmar
     HIP_TRY(dev_alloc_zero(&dv.status, B, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.slot_active, B * 2 * dv.maxp, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.slot_meta, B * 2 * dv.maxp, &h->device_bytes, s));
+    HIP_TRY(dev_alloc_zero(&dv.pass_flag, 1, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.bar, B * 2, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.dbg, 32, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.part, B * 2 * dv.gmax * EKF_REC_DOUBLES, &h->device_bytes, s));
@@ -326,6 +329,8 @@ extern "C" int ekf_batch_create(ekf_handle *out, int batch, int capacity_landmar
     h->ev_idx = 0;
     h->chain_signalled = false;
     h->chain_seq = 0;
+    h->pass_seq = 0;
+    h->need_pass = 0;
     h->mirror_by_chain = false;
     h->s_flush = h->s_chain;
     if (h->overlap) {
@@ -392,7 +397,7 @@ extern "C" int ekf_destroy(ekf_handle h) {
     for (auto &g : h->graphs) hipGraphExecDestroy(g.exec);
     EkfDev &dv = h->dv;
     hipFree(dv.x), hipFree(dv.R), hipFree(dv.D), hipFree(dv.Bm[0]), hipFree(dv.FA), hipFree(dv.FB);
-    hipFree(dv.n_lm), hipFree(dv.n_lm_sweep), hipFree(dv.n_lm_flush), hipFree(dv.status), hipFree(dv.slot_active), hipFree(dv.slot_meta);
+    hipFree(dv.n_lm), hipFree(dv.n_lm_sweep), hipFree(dv.n_lm_flush), hipFree(dv.status), hipFree(dv.slot_active), hipFree(dv.slot_meta), hipFree(dv.pass_flag);
     hipFree(dv.bar), hipFree(dv.part), hipFree(dv.dbg);
     hipFree(dv.log), hipFree(dv.log_count), hipFree(dv.stats);
     hipFree(h->cursor_d);
@@ -470,7 +475,10 @@ static int close_set(ekf_batch *h) {
         else hipExtLaunchKernelGGL(k_flush, grid, dim3(256), 0, sf, e0, e1, 0, h->dv, nT_hi, h->cur_set, h->pending, fin, stagger_ticks);
     }
     if (h->overlap) {
-        if (h->prev_pending > 0) HIP_TRY(hipStreamWaitEvent(h->s_chain, h->ev_flush[h->ev_idx], 0));  // pass k-1
+        // the chain kernels of the next window depend on pass k-1 (they read its output and overwrite the slot rows it
+        // read): they wait for its number in dv.pass_flag themselves
+        h->need_pass = h->prev_pending > 0 ? h->pass_seq : 0;  // pass_seq still names pass k-1 here
+        hipLaunchKernelGGL(k_mark, dim3(1), dim3(64), 0, sf, h->dv.pass_flag, ++h->pass_seq);  // pass k
         h->ev_idx ^= 1;  // ev_flush[ev_idx] is pass k's completion: its stop event, or, when profiling took that, a marker
         if (h->prof_flush) HIP_TRY(hipEventRecord(h->ev_flush[h->ev_idx], sf));
         if (getenv("EKF_OVERLAP_SERIAL")) HIP_TRY(hipStreamWaitEvent(h->s_chain, h->ev_flush[h->ev_idx], 0));  // experiment: no concurrency
@@ -519,7 +527,7 @@ static int launch_ops(ekf_batch *h, const double *in, const int *cursor, int k0,
         const bool closes = h->overlap && used == h->dv.maxp;
         hipExtLaunchKernelGGL(k_chain, dim3(h->chain_wgs, h->dv.B), dim3(h->chain_threads), h->chain_lds, h->s_chain, nullptr,
                               closes ? h->ev_chain : nullptr, 0, h->dv, in, cursor, k0 + start, i - start, h->pending, h->cur_set, h->buf_in,
-                              h->prev_pending, ++h->chain_seq);
+                              h->prev_pending, ++h->chain_seq, h->need_pass);
         h->mirror_by_chain = true;
         h->chain_signalled = closes;
         h->pending = used;

@@ -208,6 +208,9 @@ __device__ __forceinline__ size_t chk_idx(long long *dbg, int line, long long id
 //                       The LDS copy of the own rows and the exchanged rows cover n_prev + slot "virtual" slots,
 //                       the other set's first.
 //   buf_read          : Bm buffer to read P_LL columns from
+//   need_pass         : > 0: dense pass number need_pass wrote Bm[buf_read] and read the slot rows this launch is about to
+//                       overwrite; the launch waits for dv.pass_flag to reach it before touching either (an in-kernel
+//                       wait instead of a cross-stream event: the event's barrier packet cost 6 us per window)
 // Dynamic LDS: every landmark's own rows of every slot of the set being filled (64 bytes per landmark and
 // slot, component-major so that a wave reads one component of consecutive landmarks conflict-free); the fold
 // of the not-yet-flushed slots into P[own rows, matched columns] then needs no trip to memory.  The host sizes
@@ -299,7 +302,7 @@ __device__ __forceinline__ void sweep_one(int lm, const LmState &st, double z0, 
 }
 
 __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, const double *in, const int *cursor, int k0,
-                                                                int nops, int slot0, int set, int buf_read, int n_prev, long long launch_seq) {
+                                                                int nops, int slot0, int set, int buf_read, int n_prev, long long launch_seq, int need_pass) {
     __shared__ ChainLds L;
     __shared__ double recs[EKF_CHAIN_MAX_OPS * 8];
     extern __shared__ double own_rows[];  // [virtual slot][component 00 01 10 11][local landmark]: K rows (Old, compass), P_xL rows (New), zeros (dead)
@@ -468,6 +471,24 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
             for (int cmp = 0; cmp < 4; cmp++) own_rows[((size_t)sl * 4 + cmp) * lpw_ + (lm - own_lo)] = 0.0;
         write_slot(lm, slot, 0, 0, 0, 0, 1, 0, 0, 1, true);  // (its own P_xL rows are zero: the 2x2 block lives in D)
     };
+
+    // Overlap mode: wait for the dense pass this launch depends on (MI355X_MICROARCH.md consumer form: one relaxed poll,
+    // one agent acquire, vmcnt(0), workgroup barrier, then plain loads).  Normally the pass finished long ago.
+    if (need_pass > 0) {
+        if (tid == 0) {
+            long spins = 0;
+            while ((int)(__hip_atomic_load(dv.pass_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - need_pass) < 0) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > (1L << 24)) {  // bounded
+                    dv.status[b] = EKF_ERR_HIP;
+                    break;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+    }
 
     // the control lane records what kind of slot the operation leaves (every workgroup in LDS, workgroup 0 also in HBM
     // for later launches)
@@ -1530,6 +1551,11 @@ __global__ void k_set_meta(EkfDev dv, int b, int n_lm) {
     mr->status = 0;
     mr->log_count = dv.log_count[b];
     for (int m = 0; m < 2 * dv.maxp; m++) dv.slot_active[(size_t)b * 2 * dv.maxp + m] = 0;
+}
+
+// stored behind a dense pass on its stream: the pass's writes are in memory (kernel boundary) before the flag is
+__global__ void k_mark(int *flag, int value) {
+    if (threadIdx.x == 0) __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __global__ void k_advance(int *cursor, int by) {

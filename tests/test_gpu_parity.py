@@ -507,3 +507,32 @@ def test_window_and_overlap_resolution(pkg, monkeypatch):
     f = pkg.FilterBatch(1, 1, max_pending=1)
     assert f.window == 1
     f.close()
+
+
+def test_overlap_equals_inplace_when_the_pass_is_the_longer_leg(pkg, monkeypatch, pipeline_mode):
+    """N=4096 with a window of 4: the dense pass (about 100 us) outlasts the chain kernels of a window (about 30 us), so in
+    overlap mode every chain launch really waits in-kernel for the pass before it, reads that pass's output the
+    moment it is complete and overwrites the slot rows it has just read.  Any stale or early read shows up against
+    the in-place run of the same script."""
+    if pipeline_mode != "overlap":
+        pytest.skip("one comparison covers both modes")
+    N, M, steps = 4096, 4, 48
+    x0, P0 = pkg.scenarios.injected_state(N, seed=20260003)
+    sc = pkg.scenarios.steady_script(x0, steps=steps, M=M, seed=41)
+    outs = []
+    for ov in ("0", "1"):
+        monkeypatch.setenv("EKF_OVERLAP", ov)
+        f = pkg.FilterBatch(1, N, max_pending=4)
+        assert f.overlap == (ov == "1")
+        f.set_state(x0, P0)
+        load_script(f, sc)
+        f.script_run(0, steps)
+        f.sync()
+        outs.append(f.get_state() + (f.decisions(0, steps * M),))
+        f.close()
+    (xi, Pi, di), (xo, Po, do) = outs
+    assert [(d[0], d[1]) for d in di] == [(d[0], d[1]) for d in do]
+    assert [d[1] for d in do] == [3 + 2 * int(t) for t in sc["target"].ravel()]
+    assert np.abs(xi - xo).max() <= 1e-11 * np.abs(xi).max()
+    assert np.abs(Pi - Po).max() <= 1e-11 * np.abs(Pi).max()
+    assert_bitwise_symmetric(Po)
