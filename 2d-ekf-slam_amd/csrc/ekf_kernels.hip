@@ -610,6 +610,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
     // touch their own rows, no barrier), operations before it are skipped.  Wave-uniform, kept by every thread.
     int ahead_prop = -1;
 
+    STAMP(7);  // launch prologue: pass wait, records, slot kinds, LDS refill, robot state
     int slot = slot0;
     int cur = 0;
     for (int op = 0; op < nops; op++) {
