@@ -54,6 +54,7 @@ struct ekf_batch {
     bool chain_signalled; // the last chain launch carried ev_chain as its stop event
     int pass_seq;         // dense passes launched so far (overlap mode); k_mark stores it into dv.pass_flag behind each pass
     int need_pass;        // the pass the next chain launches have to wait for in-kernel, 0 = none
+    bool inkernel_wait;   // chain kernels wait for their pass in-kernel (kernels of two streams run side by side), else by event
     long long chain_seq;  // chain launches so far; the kernel stores it into the host mirror when it is done
     bool mirror_by_chain; // the newest writer of the host mirror is chain launch number chain_seq (else: some other kernel, synchronise)
     int flush_keep;       // pool key of s_flush: CUs kept free for the chain, -1 = unmasked
@@ -163,6 +164,30 @@ static void pool_give(int device, int keep, hipStream_t s) {
         registered = true;
     }
     g_pool.push_back({device, keep, s});
+}
+
+// Do kernels on two streams of this process really run side by side?  The overlapped pipeline lets a chain kernel wait
+// IN-KERNEL for the dense pass it depends on (cheaper than a cross-stream event by 6 us per window), which is only safe
+// when that pass can run while the chain kernel spins.  Tools that serialise kernel execution (rocprofv3 --pmc) break
+// the assumption; then the pipeline keeps the event.  Probed once per process and device.
+static int concurrent_kernels_ok(int device, hipStream_t a, hipStream_t b) {
+    static std::mutex mu;
+    static std::vector<int> cache(64, -1);
+    std::lock_guard<std::mutex> lk(mu);
+    if (device >= 0 && device < (int)cache.size() && cache[device] >= 0) return cache[device];
+    int *d = nullptr, h[2] = {0, 0};
+    int ok = 0;
+    if (hipMalloc((void **)&d, 2 * sizeof(int)) == hipSuccess && hipMemset(d, 0, 2 * sizeof(int)) == hipSuccess) {
+        hipLaunchKernelGGL(k_probe_wait, dim3(1), dim3(64), 0, a, d, d + 1);
+        hipLaunchKernelGGL(k_probe_set, dim3(1), dim3(64), 0, b, d);
+        if (hipStreamSynchronize(a) == hipSuccess && hipStreamSynchronize(b) == hipSuccess &&
+            hipMemcpy(h, d, 2 * sizeof(int), hipMemcpyDeviceToHost) == hipSuccess)
+            ok = h[1] == 1;
+    }
+    if (d) hipFree(d);
+    (void)hipGetLastError();
+    if (device >= 0 && device < (int)cache.size()) cache[device] = ok;
+    return ok;
 }
 
 template <typename T>
@@ -331,6 +356,7 @@ extern "C" int ekf_batch_create(ekf_handle *out, int batch, int capacity_landmar
     h->chain_seq = 0;
     h->pass_seq = 0;
     h->need_pass = 0;
+    h->inkernel_wait = false;
     h->mirror_by_chain = false;
     h->s_flush = h->s_chain;
     if (h->overlap) {
@@ -362,6 +388,7 @@ extern "C" int ekf_batch_create(ekf_handle *out, int batch, int capacity_landmar
                 HIP_TRY(hipStreamCreateWithFlags(&h->s_flush, hipStreamNonBlocking));
             }
         }
+        h->inkernel_wait = (getenv("EKF_INKERNEL_WAIT") ? atoi(getenv("EKF_INKERNEL_WAIT")) != 0 : true) && concurrent_kernels_ok(device_id, h->s_chain, h->s_flush) != 0;
         HIP_TRY(hipEventCreate(&h->ev_chain));  // (stop events of dispatch packets)
         for (int i = 0; i < 2; i++) HIP_TRY(hipEventCreate(&h->ev_flush[i]));
         h->chain_signalled = false;
@@ -477,7 +504,13 @@ static int close_set(ekf_batch *h) {
     if (h->overlap) {
         // the chain kernels of the next window depend on pass k-1 (they read its output and overwrite the slot rows it
         // read): they wait for its number in dv.pass_flag themselves
-        h->need_pass = h->prev_pending > 0 ? h->pass_seq : 0;  // pass_seq still names pass k-1 here
+        // ... or, where kernels of two streams do not run side by side, the stream waits for the pass's event
+        if (h->inkernel_wait) {
+            h->need_pass = h->prev_pending > 0 ? h->pass_seq : 0;  // pass_seq still names pass k-1 here
+        } else {
+            h->need_pass = 0;
+            if (h->prev_pending > 0) HIP_TRY(hipStreamWaitEvent(h->s_chain, h->ev_flush[h->ev_idx], 0));  // pass k-1
+        }
         hipLaunchKernelGGL(k_mark, dim3(1), dim3(64), 0, sf, h->dv.pass_flag, ++h->pass_seq);  // pass k
         h->ev_idx ^= 1;  // ev_flush[ev_idx] is pass k's completion: its stop event, or, when profiling took that, a marker
         if (h->prof_flush) HIP_TRY(hipEventRecord(h->ev_flush[h->ev_idx], sf));

@@ -1554,6 +1554,23 @@ __global__ void k_set_meta(EkfDev dv, int b, int n_lm) {
     for (int m = 0; m < 2 * dv.maxp; m++) dv.slot_active[(size_t)b * 2 * dv.maxp + m] = 0;
 }
 
+// Probe pair for ekf_api's concurrency check: the waiter spins (bounded, about 2 ms) until the setter, launched on ANOTHER
+// stream after it, has run; out[0] = 1 when it saw the flag.  Under tools that serialise kernel execution it times out.
+__global__ void k_probe_wait(int *flag, int *out) {
+    if (threadIdx.x == 0) {
+        int seen = 0;
+        for (int spin = 0; spin < 20000 && !seen; spin++) {
+            seen = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+            __builtin_amdgcn_s_sleep(8);
+        }
+        out[0] = seen;
+    }
+}
+
+__global__ void k_probe_set(int *flag) {
+    if (threadIdx.x == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // stored behind a dense pass on its stream: the pass's writes are in memory (kernel boundary) before the flag is
 __global__ void k_mark(int *flag, int value) {
     if (threadIdx.x == 0) __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
