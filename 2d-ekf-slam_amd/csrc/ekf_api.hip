@@ -61,6 +61,8 @@ struct ekf_batch {
     int chain_wgs;        // k_chain workgroups per filter
     size_t chain_lds;     // dynamic LDS of a k_chain launch: the own-row cache
     double *bm1_base;     // allocation behind dv.Bm[1] (overlap mode)
+    std::vector<int *> tile_maps;  // [nT]: XCD-aware wave -> tile tables of the row-block dense pass, built on demand
+    bool xcd_map;         // EKF_XCD_MAP (default on)
     size_t device_bytes;
     int chain_threads;
     // host-side tracking
@@ -396,6 +398,7 @@ extern "C" int ekf_batch_create(ekf_handle *out, int batch, int capacity_landmar
     h->stagger_ns = getenv("EKF_FLUSH_STAGGER_NS") ? atoi(getenv("EKF_FLUSH_STAGGER_NS")) : -1;
     h->flush_variant = getenv("EKF_FLUSH_VARIANT") ? atoi(getenv("EKF_FLUSH_VARIANT")) : 2;
     h->dbg_skip_flush = getenv("EKF_DEBUG_SKIP_FLUSH") && atoi(getenv("EKF_DEBUG_SKIP_FLUSH")) != 0;
+    h->xcd_map = getenv("EKF_XCD_MAP") ? atoi(getenv("EKF_XCD_MAP")) != 0 : true;
     h->script_d = nullptr;
     h->script_steps = h->script_M = h->script_has_truth = 0;
     h->h_int.resize(B);
@@ -428,6 +431,8 @@ extern "C" int ekf_destroy(ekf_handle h) {
     hipFree(dv.bar), hipFree(dv.part), hipFree(dv.dbg);
     hipFree(dv.log), hipFree(dv.log_count), hipFree(dv.stats);
     hipFree(h->cursor_d);
+    for (int *m : h->tile_maps)
+        if (m) hipFree(m);
     if (h->script_d) hipFree(h->script_d);
     hipHostFree(h->ring_h);
     hipHostFree(h->mirror_h);
@@ -459,6 +464,47 @@ static int check_launch() {
         return set_error(EKF_ERR_HIP, buf);
     }
     return EKF_OK;
+}
+
+// Wave -> tile table of the row-block dense pass for nT live tile rows: workgroup w (4 waves) gets tiles of class
+// (I mod 2, J mod 4) = w mod 8, consecutive tiles of a class sharing their tile row; a class that runs dry takes from the
+// fullest one.  Built once per nT (the map only grows), uploaded synchronously.
+static const int *tile_map_for(ekf_batch *h, int nT) {
+    if (!h->xcd_map || nT < 8) return nullptr;  // small maps: nothing to share
+    if ((int)h->tile_maps.size() <= nT) h->tile_maps.resize(nT + 1, nullptr);
+    if (h->tile_maps[nT]) return h->tile_maps[nT];
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(h->s_chain, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError();
+        return nullptr;  // no allocation or copy while a graph is being captured: this pass uses the arithmetic order
+    }
+    std::vector<std::vector<int>> cls(8);
+    for (int I = 0; I < nT; I++)
+        for (int J = I; J < nT; J++) cls[(I & 1) * 4 + (J & 3)].push_back((I << 16) | J);
+    std::vector<size_t> pos(8, 0);
+    const int total = nT * (nT + 1) / 2, nwg = (total + 3) / 4;
+    std::vector<int> map((size_t)nwg * 4, -1);
+    for (int w = 0; w < nwg; w++)
+        for (int k = 0; k < 4; k++) {
+            int c = w & 7;
+            if (pos[c] >= cls[c].size()) {  // this class is used up: take from the class with most tiles left
+                size_t best = 0;
+                c = -1;
+                for (int q = 0; q < 8; q++)
+                    if (cls[q].size() - pos[q] > best) best = cls[q].size() - pos[q], c = q;
+                if (c < 0) break;
+            }
+            map[(size_t)w * 4 + k] = cls[c][pos[c]++];
+        }
+    int *d = nullptr;
+    if (hipMalloc((void **)&d, map.size() * sizeof(int)) != hipSuccess) return nullptr;
+    if (hipMemcpy(d, map.data(), map.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+        hipFree(d);
+        return nullptr;
+    }
+    h->device_bytes += map.size() * sizeof(int);
+    h->tile_maps[nT] = d;
+    return d;
 }
 
 // ---- chain / dense-pass alternation ------------------------------------------------------------------
@@ -498,7 +544,7 @@ static int close_set(ekf_batch *h) {
         }
         // (start/stop events ride on the dispatch packet itself: no extra barrier packets)
         if (variant == 1) hipExtLaunchKernelGGL(k_flush_q, grid, dim3(256), 0, sf, e0, e1, 0, h->dv, nT_hi, h->cur_set, h->pending, fin);
-        else if (variant == 2) hipExtLaunchKernelGGL(k_flush_rb, grid, dim3(256), 0, sf, e0, e1, 0, h->dv, nT_hi, h->cur_set, h->pending, fin, fout);
+        else if (variant == 2) hipExtLaunchKernelGGL(k_flush_rb, grid, dim3(256), 0, sf, e0, e1, 0, h->dv, nT_hi, h->cur_set, h->pending, fin, fout, tile_map_for(h, nT_hi));
         else hipExtLaunchKernelGGL(k_flush, grid, dim3(256), 0, sf, e0, e1, 0, h->dv, nT_hi, h->cur_set, h->pending, fin, stagger_ticks);
     }
     if (h->overlap) {
@@ -1062,6 +1108,7 @@ extern "C" int ekf_script_run(ekf_handle h, int first_step, int n_steps, int use
                 int hi_saved = h->n_lm_hi;
                 h->prof_flush = false;    // event pairs are not captured into graphs
                 h->n_lm_hi = h->dv.Ncap;  // graphs bake grid sizes: size the dense pass for the capacity
+                (void)tile_map_for(h, (2 * h->n_lm_hi + 63) / 64);  // built before the capture: the captured passes find it ready
                 HIP_TRY(hipStreamBeginCapture(h->s_chain, hipStreamCaptureModeThreadLocal));
                 int rc2 = enqueue_script_steps(h, h->cursor_d, 0, S);
                 if (rc2 == EKF_OK && h->pending != 0) rc2 = set_error(EKF_ERR_STATE, "graph block does not end on an empty slot set");

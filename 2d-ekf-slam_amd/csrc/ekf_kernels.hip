@@ -1336,18 +1336,28 @@ __device__ __forceinline__ void flush_tile_rb(const double *tp, double *tq, cons
 // (128).  Every load that a later wait names is issued before the stores that precede that wait in program
 // order, except the A operands two row-blocks ahead (their wait is two MFMA blocks later).
 // More than 8 live pairs (windows above 16) fall back to the slot-major walk of k_flush.
-__global__ __launch_bounds__(256, 2) void k_flush_rb(EkfDev dv, int nT_hi, int set, int nslots, int buf, int buf_out) {
+// tile_map (may be null): wave u's tile as (I << 16) | J, -1 = none.  The host orders it so that workgroup w gets tiles
+// of class ((I mod 2), (J mod 4)) = w mod 8: workgroups are dealt round-robin over the 8 XCDs (observed, speed only), so
+// each XCD's L2 fetches half of the A operands and a quarter of the B operands instead of all of both.
+__global__ __launch_bounds__(256, 2) void k_flush_rb(EkfDev dv, int nT_hi, int set, int nslots, int buf, int buf_out, const int *tile_map) {
     int b = blockIdx.y;
     int lane = threadIdx.x & 63;
     int u = blockIdx.x * 4 + (threadIdx.x >> 6);
-    int total = nT_hi * (nT_hi + 1) / 2;
-    if (u >= total) return;
-    int I = (int)(((2.0f * nT_hi + 1.0f) - sqrtf((2.0f * nT_hi + 1.0f) * (2.0f * nT_hi + 1.0f) - 8.0f * (float)u)) * 0.5f);
-    if (I < 0) I = 0;
-    if (I > nT_hi - 1) I = nT_hi - 1;
-    while (I > 0 && I * nT_hi - (I * (I - 1)) / 2 > u) I--;
-    while ((I + 1) * nT_hi - ((I + 1) * I) / 2 <= u) I++;
-    int J = I + (u - (I * nT_hi - (I * (I - 1)) / 2));
+    int I, J;
+    if (tile_map) {
+        const int packed = uni(tile_map[u]);
+        if (packed < 0) return;
+        I = packed >> 16, J = packed & 0xffff;
+    } else {
+        int total = nT_hi * (nT_hi + 1) / 2;
+        if (u >= total) return;
+        I = (int)(((2.0f * nT_hi + 1.0f) - sqrtf((2.0f * nT_hi + 1.0f) * (2.0f * nT_hi + 1.0f) - 8.0f * (float)u)) * 0.5f);
+        if (I < 0) I = 0;
+        if (I > nT_hi - 1) I = nT_hi - 1;
+        while (I > 0 && I * nT_hi - (I * (I - 1)) / 2 > u) I--;
+        while ((I + 1) * nT_hi - ((I + 1) * I) / 2 <= u) I++;
+        J = I + (u - (I * nT_hi - (I * (I - 1)) / 2));
+    }
     int nT = (2 * dv.n_lm_flush[(size_t)b * 2 + set] + 63) >> 6;
     if (J >= nT) return;
 
