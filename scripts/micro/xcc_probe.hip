@@ -23,7 +23,7 @@ int main() {
     for (int conv = 0; conv < 3; conv++) {
         std::vector<uint32_t> mask(ncu / 32, 0u);
         for (int i = 0; i < ncu; i++) {
-            bool on = conv == 0 ? (i % 8 == 0) : conv == 1 ? (i < 32) : (i / 4 % 8 == 0);
+            bool on = conv == 0 ? (i % 8 == 0) : conv == 1 ? (i < 32) : (i >= 32);  // conv 2 = the library's dense-pass mask (32 CUs kept free)
             if (on) mask[i / 32] |= 1u << (i % 32);
         }
         hipStream_t s;
@@ -36,8 +36,10 @@ int main() {
         hipMemcpy(h.data(), d, nwg * 2 * sizeof(int), hipMemcpyDeviceToHost);
         int cnt[16] = {0};
         for (int i = 0; i < nwg; i++) cnt[h[i * 2] & 15]++;
-        printf("convention %d (%s): WGs per XCC:", conv, conv == 0 ? "i%8==0" : conv == 1 ? "i<32" : "i/4%8==0");
+        printf("convention %d (%s): WGs per XCC:", conv, conv == 0 ? "i%8==0" : conv == 1 ? "i<32" : "i>=32");
         for (int x = 0; x < 8; x++) printf(" %d", cnt[x]);
+        printf("\n   block -> XCC:");
+        for (int i = 0; i < 32; i++) printf(" %d", h[i * 2] & 15);
         printf("\n");
         hipStreamDestroy(s);
     }
