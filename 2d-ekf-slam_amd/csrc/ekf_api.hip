@@ -63,6 +63,7 @@ struct ekf_batch {
     double *bm1_base;     // allocation behind dv.Bm[1] (overlap mode)
     std::vector<int *> tile_maps;  // [nT]: XCD-aware wave -> tile tables of the row-block dense pass, built on demand
     bool xcd_map;         // EKF_XCD_MAP (default on)
+    bool batch_interleave; // EKF_BATCH_INTERLEAVE (default on): batches run a filter's dense-pass workgroups on one XCD
     size_t device_bytes;
     int chain_threads;
     // host-side tracking
@@ -399,6 +400,7 @@ extern "C" int ekf_batch_create(ekf_handle *out, int batch, int capacity_landmar
     h->flush_variant = getenv("EKF_FLUSH_VARIANT") ? atoi(getenv("EKF_FLUSH_VARIANT")) : 2;
     h->dbg_skip_flush = getenv("EKF_DEBUG_SKIP_FLUSH") && atoi(getenv("EKF_DEBUG_SKIP_FLUSH")) != 0;
     h->xcd_map = getenv("EKF_XCD_MAP") ? atoi(getenv("EKF_XCD_MAP")) != 0 : true;
+    h->batch_interleave = getenv("EKF_BATCH_INTERLEAVE") ? atoi(getenv("EKF_BATCH_INTERLEAVE")) != 0 : true;
     h->script_d = nullptr;
     h->script_steps = h->script_M = h->script_has_truth = 0;
     h->h_int.resize(B);
@@ -544,7 +546,16 @@ static int close_set(ekf_batch *h) {
         }
         // (start/stop events ride on the dispatch packet itself: no extra barrier packets)
         if (variant == 1) hipExtLaunchKernelGGL(k_flush_q, grid, dim3(256), 0, sf, e0, e1, 0, h->dv, nT_hi, h->cur_set, h->pending, fin);
-        else if (variant == 2) hipExtLaunchKernelGGL(k_flush_rb, grid, dim3(256), 0, sf, e0, e1, 0, h->dv, nT_hi, h->cur_set, h->pending, fin, fout, tile_map_for(h, nT_hi));
+        else if (variant == 2) {
+            const int nwg = cdiv(total, 4);
+            if (h->dv.B > 1 && h->batch_interleave) {  // a filter's workgroups on one XCD
+                dim3 g1((unsigned)(cdiv(h->dv.B, 8) * 8 * nwg), 1);
+                hipExtLaunchKernelGGL(k_flush_rb, g1, dim3(256), 0, sf, e0, e1, 0, h->dv, nT_hi, h->cur_set, h->pending, fin, fout, (const int *)nullptr, nwg);
+            } else {
+                hipExtLaunchKernelGGL(k_flush_rb, grid, dim3(256), 0, sf, e0, e1, 0, h->dv, nT_hi, h->cur_set, h->pending, fin, fout,
+                                      h->dv.B == 1 ? tile_map_for(h, nT_hi) : (const int *)nullptr, 0);
+            }
+        }
         else hipExtLaunchKernelGGL(k_flush, grid, dim3(256), 0, sf, e0, e1, 0, h->dv, nT_hi, h->cur_set, h->pending, fin, stagger_ticks);
     }
     if (h->overlap) {

@@ -1339,10 +1339,20 @@ __device__ __forceinline__ void flush_tile_rb(const double *tp, double *tq, cons
 // tile_map (may be null): wave u's tile as (I << 16) | J, -1 = none.  The host orders it so that workgroup w gets tiles
 // of class ((I mod 2), (J mod 4)) = w mod 8: workgroups are dealt round-robin over the 8 XCDs (observed, speed only), so
 // each XCD's L2 fetches half of the A operands and a quarter of the B operands instead of all of both.
-__global__ __launch_bounds__(256, 2) void k_flush_rb(EkfDev dv, int nT_hi, int set, int nslots, int buf, int buf_out, const int *tile_map) {
-    int b = blockIdx.y;
+// Batches (wgs_per_filter > 0, 1-D grid): workgroup id -> (filter, workgroup of the filter) such that all workgroups of
+// filter b have id mod 8 = b mod 8, i.e. run on one XCD: a filter's slot operands are then fetched into ONE L2 instead
+// of eight (for 256 x N=256 the eightfold operand fetch was as large as the tile traffic itself).
+__global__ __launch_bounds__(256, 2) void k_flush_rb(EkfDev dv, int nT_hi, int set, int nslots, int buf, int buf_out, const int *tile_map,
+                                                     int wgs_per_filter) {
+    int b = blockIdx.y, wg = blockIdx.x;
+    if (wgs_per_filter > 0) {
+        const int per_group = 8 * wgs_per_filter, grp = blockIdx.x / per_group, r = blockIdx.x % per_group;
+        b = grp * 8 + (r & 7);
+        wg = r >> 3;
+        if (b >= dv.B) return;
+    }
     int lane = threadIdx.x & 63;
-    int u = blockIdx.x * 4 + (threadIdx.x >> 6);
+    int u = wg * 4 + (threadIdx.x >> 6);
     int I, J;
     if (tile_map) {
         const int packed = uni(tile_map[u]);
