@@ -71,8 +71,8 @@ struct ekf_batch {
     int cur_set;    // slot set being filled
     int pending;    // slots used in cur_set
     int buf_in;     // Bm buffer the chain kernels read (complete up to the sets still open or in flight)
-    int stagger_ns;       // EKF_FLUSH_STAGGER_NS: first-generation de-phasing delay of the dense pass, -1 = automatic
-    int flush_variant;    // EKF_FLUSH_VARIANT: 2 (default) = row-block pipelined tile, 0 = slot-major tile, 1 = one wave per 32x32 quadrant
+    bool flush_alternate; // EKF_FLUSH_ALTERNATE (default on): dense passes walk the tiles alternately first-to-last and last-to-first
+    int flush_dir;        // direction of the next dense pass (0 = first to last)
     bool dbg_skip_flush;  // EKF_DEBUG_SKIP_FLUSH=1: timing experiments only, results are wrong
     // immediate-mode input ring (host-mapped pinned)
     double *ring_h;
@@ -396,8 +396,8 @@ extern "C" int ekf_batch_create(ekf_handle *out, int batch, int capacity_landmar
         for (int i = 0; i < 2; i++) HIP_TRY(hipEventCreate(&h->ev_flush[i]));
         h->chain_signalled = false;
     }
-    h->stagger_ns = getenv("EKF_FLUSH_STAGGER_NS") ? atoi(getenv("EKF_FLUSH_STAGGER_NS")) : -1;
-    h->flush_variant = getenv("EKF_FLUSH_VARIANT") ? atoi(getenv("EKF_FLUSH_VARIANT")) : 2;
+    h->flush_alternate = getenv("EKF_FLUSH_ALTERNATE") ? atoi(getenv("EKF_FLUSH_ALTERNATE")) != 0 : true;
+    h->flush_dir = 0;
     h->dbg_skip_flush = getenv("EKF_DEBUG_SKIP_FLUSH") && atoi(getenv("EKF_DEBUG_SKIP_FLUSH")) != 0;
     h->xcd_map = getenv("EKF_XCD_MAP") ? atoi(getenv("EKF_XCD_MAP")) != 0 : true;
     h->batch_interleave = getenv("EKF_BATCH_INTERLEAVE") ? atoi(getenv("EKF_BATCH_INTERLEAVE")) != 0 : true;
@@ -530,10 +530,6 @@ static int close_set(ekf_batch *h) {
     if (!h->dbg_skip_flush && (nT_hi > 0 || h->overlap)) {
         if (nT_hi < 1) nT_hi = 1;
         int total = nT_hi * (nT_hi + 1) / 2;
-        const int variant = h->overlap ? 2 : h->flush_variant;  // only the row-block form goes buffer to buffer
-        dim3 grid(variant == 1 ? total : cdiv(total, 4), h->dv.B);
-        // half a tile period: about 4 us of HBM share plus 0.24 us of MFMA per slot (EKF_FLUSH_STAGGER_NS overrides)
-        int stagger_ticks = h->stagger_ns >= 0 ? h->stagger_ns / 10 : (400 + 12 * h->pending);
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (h->overlap) e1 = h->ev_flush[h->ev_idx ^ 1];  // pass k's completion, signalled by its own dispatch packet
         if (h->prof_flush) {
@@ -544,19 +540,20 @@ static int close_set(ekf_batch *h) {
             }
             e0 = h->prof_pool[h->prof_used++], e1 = h->prof_pool[h->prof_used++];  // (recycled after a read: never used for dependencies)
         }
+        // Passes alternate direction: a pass starts on the tiles the previous pass touched last, which are the ones the
+        // 256 MB Infinity Cache still holds (P_LL of N=4096 is 270 MB per buffer: walked the same way every time, the
+        // cache has evicted a tile long before the next pass comes back to it).
+        const int rev = h->flush_alternate ? h->flush_dir : 0;
+        h->flush_dir ^= 1;
+        const int nwg = cdiv(total, 4);
         // (start/stop events ride on the dispatch packet itself: no extra barrier packets)
-        if (variant == 1) hipExtLaunchKernelGGL(k_flush_q, grid, dim3(256), 0, sf, e0, e1, 0, h->dv, nT_hi, h->cur_set, h->pending, fin);
-        else if (variant == 2) {
-            const int nwg = cdiv(total, 4);
-            if (h->dv.B > 1 && h->batch_interleave) {  // a filter's workgroups on one XCD
-                dim3 g1((unsigned)(cdiv(h->dv.B, 8) * 8 * nwg), 1);
-                hipExtLaunchKernelGGL(k_flush_rb, g1, dim3(256), 0, sf, e0, e1, 0, h->dv, nT_hi, h->cur_set, h->pending, fin, fout, (const int *)nullptr, nwg);
-            } else {
-                hipExtLaunchKernelGGL(k_flush_rb, grid, dim3(256), 0, sf, e0, e1, 0, h->dv, nT_hi, h->cur_set, h->pending, fin, fout,
-                                      h->dv.B == 1 ? tile_map_for(h, nT_hi) : (const int *)nullptr, 0);
-            }
+        if (h->dv.B > 1 && h->batch_interleave) {  // a filter's workgroups on one XCD
+            dim3 g1((unsigned)(cdiv(h->dv.B, 8) * 8 * nwg), 1);
+            hipExtLaunchKernelGGL(k_flush_rb, g1, dim3(256), 0, sf, e0, e1, 0, h->dv, nT_hi, h->cur_set, h->pending, fin, fout, (const int *)nullptr, nwg, rev);
+        } else {
+            hipExtLaunchKernelGGL(k_flush_rb, dim3(nwg, h->dv.B), dim3(256), 0, sf, e0, e1, 0, h->dv, nT_hi, h->cur_set, h->pending, fin, fout,
+                                  h->dv.B == 1 ? tile_map_for(h, nT_hi) : (const int *)nullptr, 0, rev);
         }
-        else hipExtLaunchKernelGGL(k_flush, grid, dim3(256), 0, sf, e0, e1, 0, h->dv, nT_hi, h->cur_set, h->pending, fin, stagger_ticks);
     }
     if (h->overlap) {
         // the chain kernels of the next window depend on pass k-1 (they read its output and overwrite the slot rows it

@@ -1144,112 +1144,12 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
 }
 
 // ---------------------------------------------------------------------------------------------
-// The dense pass: Bm[buf] += sum over the active slots of `set` of A B^T, in place, over the
-// upper-triangle tiles.  One wave per 64x64 tile (32 KiB read + 32 KiB written, each as 32
-// wave-contiguous 1 KiB accesses); the rank-(4 * slots) contraction runs on
-// v_mfma_f64_16x16x4_f64 with the tile as the C/D operand.
-// Only the first nslots slots of the set were filled; two rank-2 slots share one k=4 operand.
-// grid (ceil(nT_hi (nT_hi+1)/2 / 4), B), 256 threads.
+// The dense pass: Bm[out] = Bm[in] + sum over the active slots of `set` of A B^T over the upper-triangle
+// tiles (in = out without overlap).  One wave per 64x64 tile (32 KiB read + 32 KiB written, each as 32
+// wave-contiguous 1 KiB accesses); the rank-(4 * pairs) contraction runs on v_mfma_f64_16x16x4_f64 with
+// the tile as the C/D operand.  Only the first nslots slots of the set were filled; two rank-2 slots
+// share one k=4 operand.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void k_flush(EkfDev dv, int nT_hi, int set, int nslots, int buf, int stagger_ticks) {
-    int b = blockIdx.y;
-    int lane = threadIdx.x & 63;
-    // De-phasing: the two waves that share a SIMD would otherwise run load -> MFMA -> store in lock-step
-    // (equal work, simultaneous start), leaving HBM idle while both are in their MFMA phase and the MFMA
-    // pipe idle while both wait for HBM.  In the first generation of workgroups the wave in the odd wave
-    // slot of its SIMD starts half a period late; later generations inherit the offset of the wave they
-    // replace.  stagger_ticks is in 10 ns units of s_memrealtime.
-    if (stagger_ticks > 0 && blockIdx.y == 0 && blockIdx.x >= 256 && blockIdx.x < 512) {
-        // the second workgroup dealt to each CU in the first generation
-        unsigned long long t0, t1;
-        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
-        for (int spin = 0; spin < 4096; spin++) {  // bounded: 4096 x 16 x 64 clocks is far beyond any stagger
-            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
-            if ((long long)(t1 - t0) >= stagger_ticks) break;
-            __builtin_amdgcn_s_sleep(16);
-        }
-    }
-    int u = blockIdx.x * 4 + (threadIdx.x >> 6);
-    int total = nT_hi * (nT_hi + 1) / 2;
-    if (u >= total) return;
-    // u -> (I, J), J >= I, row-major over the nT_hi x nT_hi upper triangle
-    int I = (int)(((2.0f * nT_hi + 1.0f) - sqrtf((2.0f * nT_hi + 1.0f) * (2.0f * nT_hi + 1.0f) - 8.0f * (float)u)) * 0.5f);
-    if (I < 0) I = 0;
-    if (I > nT_hi - 1) I = nT_hi - 1;
-    while (I > 0 && I * nT_hi - (I * (I - 1)) / 2 > u) I--;
-    while ((I + 1) * nT_hi - ((I + 1) * I) / 2 <= u) I++;
-    int J = I + (u - (I * nT_hi - (I * (I - 1)) / 2));
-    int nT = (2 * dv.n_lm_flush[(size_t)b * 2 + set] + 63) >> 6;
-    if (J >= nT) return;
-
-    const int *active = dv.slot_active + ((size_t)b * 2 + set) * dv.maxp;
-    size_t t = (size_t)I * dv.T - ((size_t)I * (I - 1)) / 2 + (size_t)(J - I);
-    double *tp = dv.Bm[buf] + (size_t)b * dv.bm_stride + t * 4096 + (size_t)lane * 2;
-    // operand fragments: lane l supplies row (l & 15), k = l >> 4 of a 16-row x 4 block = 512 contiguous bytes
-    const double *FA = dv.FA + ((size_t)b * 2 + set) * dv.f_stride + ((size_t)64 * I + (lane & 15)) * 4 + (lane >> 4);
-    const double *FB = dv.FB + ((size_t)b * 2 + set) * dv.f_stride + ((size_t)64 * J + (lane & 15)) * 4 + (lane >> 4);
-    const size_t slot_stride = (size_t)dv.rows * 4;
-
-    double4_t acc[16];
-#pragma unroll
-    for (int ch = 0; ch < 16; ch++) {
-        double2_t lo = *(const double2_t *)(tp + ch * 256);
-        double2_t hi = *(const double2_t *)(tp + ch * 256 + 128);
-        acc[ch] = (double4_t){lo.x, lo.y, hi.x, hi.y};
-    }
-    // live slots as a bit mask, walked two per iteration with two named operand sets: the operands of
-    // the next slot are requested before the 16 MFMAs of the current one issue, and the wait in front of
-    // an MFMA block covers only its own, older loads.  Past the last live slot the walk reads slot
-    // `maxp`, which is all zeros by construction (adds exact zeros).
-    unsigned live = 0;  // slot PAIRS with at least one live slot (a dead half holds zeros)
-    for (int m = 0; m < nslots; m++) live |= (active[m] ? 1u : 0u) << (m >> 1);
-    const int zero_slot = dv.maxpairs;
-    double a0[4], b0[4], a1[4], b1[4];
-    int npairs = (__builtin_popcount(live) + 1) >> 1;
-    int m0 = live ? __builtin_ctz(live) : zero_slot;
-    live &= live - 1;
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        a0[q] = FA[(size_t)m0 * slot_stride + q * 64];
-        b0[q] = FB[(size_t)m0 * slot_stride + q * 64];
-    }
-    for (int it = 0; it < npairs; it++) {
-        int m1 = live ? __builtin_ctz(live) : zero_slot;
-        live &= live - 1;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            a1[q] = FA[(size_t)m1 * slot_stride + q * 64];
-            b1[q] = FB[(size_t)m1 * slot_stride + q * 64];
-        }
-        __builtin_amdgcn_sched_barrier(0);  // keep the requests ahead of the MFMA block they overlap
-#pragma unroll
-        for (int rc = 0; rc < 4; rc++)
-#pragma unroll
-            for (int cc = 0; cc < 4; cc++)
-                acc[rc * 4 + cc] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[rc], b0[cc], acc[rc * 4 + cc], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        m0 = live ? __builtin_ctz(live) : zero_slot;
-        live &= live - 1;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            a0[q] = FA[(size_t)m0 * slot_stride + q * 64];
-            b0[q] = FB[(size_t)m0 * slot_stride + q * 64];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int rc = 0; rc < 4; rc++)
-#pragma unroll
-            for (int cc = 0; cc < 4; cc++)
-                acc[rc * 4 + cc] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[rc], b1[cc], acc[rc * 4 + cc], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int ch = 0; ch < 16; ch++) {
-        *(double2_t *)(tp + ch * 256) = (double2_t){acc[ch].x, acc[ch].y};
-        *(double2_t *)(tp + ch * 256 + 128) = (double2_t){acc[ch].z, acc[ch].w};
-    }
-}
-
 // One tile of the row-block dense pass with NP slot pairs resident (the caller pads the live list with the
 // all-zero pair): three row-blocks of the tile in flight, the fourth is requested into the registers of the
 // first once that has been stored.
@@ -1259,8 +1159,13 @@ __global__ __launch_bounds__(256, 2) void k_flush(EkfDev dv, int nT_hi, int set,
 #if !defined(EKF_FLUSH_NT)
 #define EKF_FLUSH_NT 1
 #endif
+// bit 0: nontemporal stores, bit 1: nontemporal loads (experiments; the default is 1)
+#if EKF_FLUSH_NT & 2
+#define TILE_LD(p) __builtin_nontemporal_load((const double2_t *)(p))
+#else
 #define TILE_LD(p) (*(const double2_t *)(p))
-#if EKF_FLUSH_NT >= 1
+#endif
+#if EKF_FLUSH_NT & 1
 #define TILE_ST(p, v) __builtin_nontemporal_store((v), (double2_t *)(p))
 #else
 #define TILE_ST(p, v) (*(double2_t *)(p) = (v))
@@ -1328,14 +1233,13 @@ __device__ __forceinline__ void flush_tile_rb(const double *tp, double *tq, cons
         }
 }
 
-// Row-block form of the dense pass (the default; EKF_FLUSH_VARIANT=0 selects k_flush): the same wave-per-tile mapping and the same
-// arithmetic, but the contraction runs row-block by row-block (16 rows x 64 columns = 4 chains) over ALL live
+// Row-block form: the contraction runs row-block by row-block (16 rows x 64 columns = 4 chains) over ALL live
 // slot pairs, so that a row-block is stored as soon as it is finished: the stores of row-block r overlap the
 // MFMAs of r+1 instead of waiting behind the whole tile's contraction.  The B operands of up to 8 pairs stay in
 // registers (64), the A operands are double-buffered one row-block ahead (32), the tile is the accumulator
 // (128).  Every load that a later wait names is issued before the stores that precede that wait in program
 // order, except the A operands two row-blocks ahead (their wait is two MFMA blocks later).
-// More than 8 live pairs (windows above 16) fall back to the slot-major walk of k_flush.
+// More than 8 live pairs (windows above 16) take the slot-major walk at the end of the kernel.
 // tile_map (may be null): wave u's tile as (I << 16) | J, -1 = none.  The host orders it so that workgroup w gets tiles
 // of class ((I mod 2), (J mod 4)) = w mod 8: workgroups are dealt round-robin over the 8 XCDs (observed, speed only), so
 // each XCD's L2 fetches half of the A operands and a quarter of the B operands instead of all of both.
@@ -1343,10 +1247,13 @@ __device__ __forceinline__ void flush_tile_rb(const double *tp, double *tq, cons
 // filter b have id mod 8 = b mod 8, i.e. run on one XCD: a filter's slot operands are then fetched into ONE L2 instead
 // of eight (for 256 x N=256 the eightfold operand fetch was as large as the tile traffic itself).
 __global__ __launch_bounds__(256, 2) void k_flush_rb(EkfDev dv, int nT_hi, int set, int nslots, int buf, int buf_out, const int *tile_map,
-                                                     int wgs_per_filter) {
-    int b = blockIdx.y, wg = blockIdx.x;
+                                                     int wgs_per_filter, int reverse) {
+    // reverse: the grid walks the tiles (and filters) last to first.  Passes alternate direction, so a pass starts on the
+    // tiles the previous one touched last -- the part of P_LL that is still in the 256 MB Infinity Cache.
+    const int bx = reverse ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;
+    int b = reverse ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y, wg = bx;
     if (wgs_per_filter > 0) {
-        const int per_group = 8 * wgs_per_filter, grp = blockIdx.x / per_group, r = blockIdx.x % per_group;
+        const int per_group = 8 * wgs_per_filter, grp = bx / per_group, r = bx % per_group;
         b = grp * 8 + (r & 7);
         wg = r >> 3;
         if (b >= dv.B) return;
@@ -1393,7 +1300,7 @@ __global__ __launch_bounds__(256, 2) void k_flush_rb(EkfDev dv, int nT_hi, int s
         else flush_tile_rb<8>(tp, tq, FA, FB, lo, live, zero_slot, slot_stride);
         return;
     }
-    // windows above 16: the slot-major walk of k_flush, two pairs per iteration
+    // windows above 16: slot-major walk (whole tile loaded, all pairs, then stored), two pairs per iteration
     double4_t acc[16];
 #pragma unroll
     for (int ch = 0; ch < 16; ch++) {
@@ -1425,92 +1332,6 @@ __global__ __launch_bounds__(256, 2) void k_flush_rb(EkfDev dv, int nT_hi, int s
         *(double2_t *)(tq + ch * 256) = (double2_t){acc[ch].x, acc[ch].y};
         *(double2_t *)(tq + ch * 256 + 128) = (double2_t){acc[ch].z, acc[ch].w};
     }
-}
-
-// Variant of the dense pass: one wave per 32x32 QUADRANT of a tile (4 chains, 8 KiB read + 8 KiB
-// written, 4 MFMAs per slot).  A quarter of the registers per wave, so up to 8 waves per SIMD cover
-// each other's HBM latency and MFMA time; costs twice the operand traffic from L2 per element.
-// grid (total tiles, B), 256 threads: the four waves of a workgroup take the four quadrants of one tile.
-__global__ __launch_bounds__(256, 6) void k_flush_q(EkfDev dv, int nT_hi, int set, int nslots, int buf) {
-    int b = blockIdx.y;
-    int lane = threadIdx.x & 63;
-    int quad = threadIdx.x >> 6;  // (qr, qc) = row half, column half of the tile
-    int qr = quad >> 1, qc = quad & 1;
-    int u = blockIdx.x;
-    int I = (int)(((2.0f * nT_hi + 1.0f) - sqrtf((2.0f * nT_hi + 1.0f) * (2.0f * nT_hi + 1.0f) - 8.0f * (float)u)) * 0.5f);
-    if (I < 0) I = 0;
-    if (I > nT_hi - 1) I = nT_hi - 1;
-    while (I > 0 && I * nT_hi - (I * (I - 1)) / 2 > u) I--;
-    while ((I + 1) * nT_hi - ((I + 1) * I) / 2 <= u) I++;
-    int J = I + (u - (I * nT_hi - (I * (I - 1)) / 2));
-    int nT = (2 * dv.n_lm_flush[(size_t)b * 2 + set] + 63) >> 6;
-    if (J >= nT) return;
-
-    const int *active = dv.slot_active + ((size_t)b * 2 + set) * dv.maxp;
-    size_t t = (size_t)I * dv.T - ((size_t)I * (I - 1)) / 2 + (size_t)(J - I);
-    // chains (2qr + i, 2qc + j), i, j in {0, 1}: chain id = (2qr + i) * 4 + 2qc + j
-    double *tp = dv.Bm[buf] + (size_t)b * dv.bm_stride + t * 4096 + (size_t)((2 * qr) * 4 + 2 * qc) * 256 + (size_t)lane * 2;
-    const double *FA = dv.FA + ((size_t)b * 2 + set) * dv.f_stride + ((size_t)64 * I + 32 * qr + (lane & 15)) * 4 + (lane >> 4);
-    const double *FB = dv.FB + ((size_t)b * 2 + set) * dv.f_stride + ((size_t)64 * J + 32 * qc + (lane & 15)) * 4 + (lane >> 4);
-    const size_t slot_stride = (size_t)dv.rows * 4;
-
-    double4_t acc[4];
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const double *p = tp + (i * 4 + j) * 256;
-            double2_t lo = *(const double2_t *)p, hi = *(const double2_t *)(p + 128);
-            acc[i * 2 + j] = (double4_t){lo.x, lo.y, hi.x, hi.y};
-        }
-    unsigned live = 0;  // slot PAIRS with at least one live slot (a dead half holds zeros)
-    for (int m = 0; m < nslots; m++) live |= (active[m] ? 1u : 0u) << (m >> 1);
-    const int zero_slot = dv.maxpairs;
-    double a0[2], b0[2], a1[2], b1[2];
-    int npairs = (__builtin_popcount(live) + 1) >> 1;
-    int m0 = live ? __builtin_ctz(live) : zero_slot;
-    live &= live - 1;
-#pragma unroll
-    for (int q = 0; q < 2; q++) {
-        a0[q] = FA[(size_t)m0 * slot_stride + q * 64];
-        b0[q] = FB[(size_t)m0 * slot_stride + q * 64];
-    }
-    for (int it = 0; it < npairs; it++) {
-        int m1 = live ? __builtin_ctz(live) : zero_slot;
-        live &= live - 1;
-#pragma unroll
-        for (int q = 0; q < 2; q++) {
-            a1[q] = FA[(size_t)m1 * slot_stride + q * 64];
-            b1[q] = FB[(size_t)m1 * slot_stride + q * 64];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 2; i++)
-#pragma unroll
-            for (int j = 0; j < 2; j++) acc[i * 2 + j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[i], b0[j], acc[i * 2 + j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        m0 = live ? __builtin_ctz(live) : zero_slot;
-        live &= live - 1;
-#pragma unroll
-        for (int q = 0; q < 2; q++) {
-            a0[q] = FA[(size_t)m0 * slot_stride + q * 64];
-            b0[q] = FB[(size_t)m0 * slot_stride + q * 64];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 2; i++)
-#pragma unroll
-            for (int j = 0; j < 2; j++) acc[i * 2 + j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[i], b1[j], acc[i * 2 + j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            double *p = tp + (i * 4 + j) * 256;
-            *(double2_t *)p = (double2_t){acc[i * 2 + j].x, acc[i * 2 + j].y};
-            *(double2_t *)(p + 128) = (double2_t){acc[i * 2 + j].z, acc[i * 2 + j].w};
-        }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -31,6 +31,9 @@ WORKLOADS = {
     # name: (N landmarks, batch per GPU, default steps, default warmup, seed, map half-extent in m)   -- BASELINE.json configs
     "n4096": (4096, 1, 512, 32, 20260003, 50.0),   # config 3 (more steps than its 50: a run is only ~30 ms)
     "n1024": (1024, 1, 200, 10, 20260002, 50.0),   # config 2
+    # not a BASELINE.json config: one size past the 256 MB Infinity Cache in the build's own storage scheme (P_LL triangle
+    # 1.08 GB per buffer), at config 3's landmark density -- tells HBM streaming from cache hits in the roofline fraction
+    "n8192": (8192, 1, 128, 16, 20260008, 70.7),
     # config 4 (config 5 = the same at --gpus 8): 256 landmarks at config 3's landmark density, so that four
     # well-conditioned (range < 9 m, cond(S) < 80) targets exist around the robot at every step
     "batch256": (256, 256, 200, 10, 20260004, 12.5),

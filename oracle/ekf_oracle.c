@@ -20,6 +20,31 @@
 
 #define ORACLE_INF 999999999999.0 /* kalmanfilter.h:17 */
 
+/* Threads of the STRUCTURED mode's two element-wise O(n^2) loops (subtract, symmetrise).  Every element
+ * is computed by exactly the expression of the single-thread loop, so results do not depend on the
+ * setting.  The faithful mode -- the timed "reference CPU path" -- is always single-threaded, like the
+ * reference (Makefile:2 has no -fopenmp). */
+static int g_threads = 1;
+void ekf_oracle_set_threads(int t) { g_threads = t < 1 ? 1 : t; }
+
+/* 0.5*(P + P^T) written to both triangles, 64x64 blocks so that the transposed reads stay in cache;
+ * element for element the same arithmetic as Update.cpp:193-194. */
+static void symmetrise_blocked(int n, double *P) {
+    const int BS = 64;
+    const int nb = (n + BS - 1) / BS;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(g_threads) if (g_threads > 1)
+    for (int bi = 0; bi < nb; bi++)
+        for (int bj = bi; bj < nb; bj++) {
+            int i1 = (bi + 1) * BS < n ? (bi + 1) * BS : n, j1 = (bj + 1) * BS < n ? (bj + 1) * BS : n;
+            for (int a = bi * BS; a < i1; a++)
+                for (int b = (bj == bi ? a + 1 : bj * BS); b < j1; b++) {
+                    double v = 0.5 * (P[(size_t)a * n + b] + P[(size_t)b * n + a]);
+                    P[(size_t)a * n + b] = v;
+                    P[(size_t)b * n + a] = v;
+                }
+        }
+}
+
 /* C(m x n) = A(m x k) * B(k x n), all row-major, tight. */
 static void mm(int m, int k, int n, const double *A, const double *B, double *C) {
     for (int i = 0; i < m; i++)
@@ -203,18 +228,14 @@ static void inv2x2_lu(const double S[4], double Si[4]) {
     }
 }
 
-void ekf_oracle_update(int n, const double *x_in, const double *P_in, int n_z, const double *z_chunk,
+/* The measurement loop of Update.cpp:80-195 on working buffers: x holds cap entries, *Pp points at a
+ * malloc'd (or, with own_P == 0, caller-owned) buffer of cap*cap doubles holding P tight (ld = current
+ * size).  Returns the new state size.  A New landmark builds the grown matrix in a fresh buffer; with
+ * own_P == 0 it is copied back into the caller's buffer. */
+static int update_core(int n, double *x, double **Pp, int cap, int own_P, int n_z, const double *z_chunk,
                        const double *R_chunk, int gamma_max, int gamma_min, double cond_limit,
-                       double *x_out, double *P_out, int *n_out, int *decisions, int *matched,
-                       double *mahal, int faithful) {
-    /* by-value arguments (kalmanfilter.h:42); working copies are needed either way because the
-     * state grows */
-    int cap = n + 2 * n_z;
-    double *x = (double *)malloc((size_t)cap * sizeof(double));
-    double *P = (double *)malloc((size_t)cap * cap * sizeof(double));
-    memcpy(x, x_in, (size_t)n * sizeof(double));
-    memcpy(P, P_in, (size_t)n * n * sizeof(double)); /* tight, ld = current size */
-
+                       int *decisions, int *matched, double *mahal, int faithful) {
+    double *P = *Pp;
     const int n_lm = (n - 3) / 2; /* Update.cpp:26 -- computed once, never refreshed */
     const double J[4] = {0, -1, 1, 0}; /* :73 */
     int size = n;
@@ -320,8 +341,13 @@ void ekf_oracle_update(int n, const double *x_in, const double *P_in, int n_z, c
             }
             for (int a = 0; a < 2; a++)
                 for (int b = 0; b < 2; b++) Pn[(size_t)(stateSize + a) * ns + stateSize + b] = P_LiLi[a * 2 + b]; /* :177 */
-            free(P);
-            P = Pn;
+            if (own_P) {
+                free(P);
+                P = Pn;
+            } else {
+                memcpy(P, Pn, (size_t)ns * ns * sizeof(double));
+                free(Pn);
+            }
             size = ns;
         } else if (Mahal_dist < gamma_min) { /* :181 Old */
             decision = EKF_ORACLE_OLD;
@@ -351,6 +377,7 @@ void ekf_oracle_update(int n, const double *x_in, const double *P_in, int n_z, c
                     for (int b = 0; b < stateSize; b++) P[(size_t)a * ld + b] = P[(size_t)a * ld + b] - M[(size_t)a * stateSize + b];
                 free(M);
             } else {
+#pragma omp parallel for schedule(static) num_threads(g_threads) if (g_threads > 1)
                 for (int a = 0; a < stateSize; a++)
                     for (int b = 0; b < stateSize; b++)
                         P[(size_t)a * ld + b] = P[(size_t)a * ld + b] - (KS[a * 2] * K[b * 2] + KS[a * 2 + 1] * K[b * 2 + 1]);
@@ -365,18 +392,27 @@ void ekf_oracle_update(int n, const double *x_in, const double *P_in, int n_z, c
         if (mahal) mahal[j - 1] = Mahal_dist;
 
         /* :193-194 symmetrise every measurement, every branch */
-        if (faithful) {
-            symmetrise_dense(size, P);
-        } else {
-            for (int a = 0; a < size; a++)
-                for (int b = a + 1; b < size; b++) {
-                    double s = 0.5 * (P[(size_t)a * size + b] + P[(size_t)b * size + a]);
-                    P[(size_t)a * size + b] = s;
-                    P[(size_t)b * size + a] = s;
-                }
-        }
+        if (faithful) symmetrise_dense(size, P);
+        else symmetrise_blocked(size, P);
     }
 
+    *Pp = P;
+    return size;
+}
+
+void ekf_oracle_update(int n, const double *x_in, const double *P_in, int n_z, const double *z_chunk,
+                       const double *R_chunk, int gamma_max, int gamma_min, double cond_limit,
+                       double *x_out, double *P_out, int *n_out, int *decisions, int *matched,
+                       double *mahal, int faithful) {
+    /* by-value arguments (kalmanfilter.h:42); working copies are needed either way because the
+     * state grows */
+    int cap = n + 2 * n_z;
+    double *x = (double *)malloc((size_t)cap * sizeof(double));
+    double *P = (double *)malloc((size_t)cap * cap * sizeof(double));
+    memcpy(x, x_in, (size_t)n * sizeof(double));
+    memcpy(P, P_in, (size_t)n * n * sizeof(double)); /* tight, ld = current size */
+    int size = update_core(n, x, &P, cap, 1, n_z, z_chunk, R_chunk, gamma_max, gamma_min, cond_limit, decisions, matched,
+                           mahal, faithful);
     *n_out = size;
     if (faithful) {
         /* pack Set (:199-201) and the caller's new+unpack (kalmanfilter.cpp:78-84) */
@@ -398,6 +434,14 @@ void ekf_oracle_update(int n, const double *x_in, const double *P_in, int n_z, c
     free(P);
 }
 
+int ekf_oracle_update_inplace(int n, double *x, double *P, int cap, int n_z, const double *z_chunk,
+                              const double *R_chunk, int gamma_max, int gamma_min, double cond_limit,
+                              int *decisions, int *matched, double *mahal) {
+    if (n + 2 * n_z > cap) return -1;
+    double *Pw = P;
+    return update_core(n, x, &Pw, cap, 0, n_z, z_chunk, R_chunk, gamma_max, gamma_min, cond_limit, decisions, matched, mahal, 0);
+}
+
 void ekf_oracle_compass(int n, double *x, double *P, double z, double R, int faithful) {
     /* kalmanfilter.cpp:96-130 */
     double z_hat = x[2];
@@ -416,12 +460,6 @@ void ekf_oracle_compass(int n, double *x, double *P, double z, double R, int fai
     for (int i = 0; i < n; i++)                                         /* :122  (S*K)*K^T */
         for (int j = 0; j < n; j++) P[(size_t)i * n + j] = P[(size_t)i * n + j] - (S * K[i]) * K[j];
     if (faithful) symmetrise_dense(n, P); /* :123-124 */
-    else
-        for (int a = 0; a < n; a++)
-            for (int b = a + 1; b < n; b++) {
-                double s = 0.5 * (P[(size_t)a * n + b] + P[(size_t)b * n + a]);
-                P[(size_t)a * n + b] = s;
-                P[(size_t)b * n + a] = s;
-            }
+    else symmetrise_blocked(n, P);
     free(K);
 }

@@ -49,6 +49,14 @@ void ekf_oracle_update(int n, const double *x_in, const double *P_in, int n_z, c
                        double *x_out, double *P_out, int *n_out, int *decisions, int *matched,
                        double *mahal, int faithful);
 
+/* The same function (structured mode) working in place on caller-owned buffers, for long test runs at
+ * large n where the by-value copies above dominate: x holds cap entries, P holds cap*cap doubles with
+ * the current matrix stored tight (leading dimension = current size n).  Returns the new state size
+ * (P is then tight with that leading dimension), or -1 when n + 2*n_z exceeds cap. */
+int ekf_oracle_update_inplace(int n, double *x, double *P, int cap, int n_z, const double *z_chunk,
+                              const double *R_chunk, int gamma_max, int gamma_min, double cond_limit,
+                              int *decisions, int *matched, double *mahal);
+
 /* KalmanFilter::doUpdateCompass, odometry/kalmanfilter.cpp:96-130.  In place on x[n], P[n*n]. */
 void ekf_oracle_compass(int n, double *x, double *P, double z, double R, int faithful);
 
@@ -58,6 +66,10 @@ void ekf_oracle_make_Q(double v, double sigma_v, double sigma_w, double Q[4]);
 /* Measurement construction of slam.cpp:152-167: feature (fx_mm, fy_mm) in robot-frame mm ->
  * z (metres) and R = G diag(0.0025, 0.0001) G^T, R written column-major. */
 void ekf_oracle_make_measurement(double fx_mm, double fy_mm, double z[2], double R[4]);
+
+/* Threads used by the structured (faithful == 0) mode's element-wise O(n^2) loops; results do not
+ * depend on it.  The faithful mode is always single-threaded. */
+void ekf_oracle_set_threads(int threads);
 
 #ifdef __cplusplus
 }

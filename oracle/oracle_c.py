@@ -42,12 +42,23 @@ def lib():
         L.ekf_oracle_make_Q.restype = None
         L.ekf_oracle_make_measurement.argtypes = [ctypes.c_double, ctypes.c_double, _dp, _dp]
         L.ekf_oracle_make_measurement.restype = None
+        L.ekf_oracle_update_inplace.argtypes = [ctypes.c_int, _dp, _dp, ctypes.c_int, ctypes.c_int, _dp, _dp, ctypes.c_int,
+                                                ctypes.c_int, ctypes.c_double, _ip, _ip, _dp]
+        L.ekf_oracle_update_inplace.restype = ctypes.c_int
+        L.ekf_oracle_set_threads.argtypes = [ctypes.c_int]
+        L.ekf_oracle_set_threads.restype = None
         _lib = L
     return _lib
 
 
 def _p(a):
     return a.ctypes.data_as(_dp)
+
+
+def set_threads(n):
+    """Threads of the structured mode's element-wise O(n^2) loops (results are independent of it); the
+    faithful mode, which bench.py times as the CPU baseline, is always single-threaded."""
+    lib().ekf_oracle_set_threads(int(n))
 
 
 def make_Q(v, sigma_v=0.01, sigma_w=0.04):
@@ -102,3 +113,55 @@ def compass(x, P, z, R, faithful=False):
     P = np.array(P, dtype=np.float64, order="C")
     lib().ekf_oracle_compass(x.size, _p(x), _p(P), float(z), float(R), int(faithful))
     return x, P
+
+
+class Session:
+    """A filter kept in oracle-owned buffers and advanced in place (structured mode): the same functions as
+    propagate / update / compass above without the by-value copies of x and P on every call, for long test
+    runs at large n.  `capacity_landmarks` bounds the growth by New landmarks."""
+
+    def __init__(self, x, P, capacity_landmarks=None):
+        x = np.asarray(x, dtype=np.float64)
+        n = x.size
+        N = (n - 3) // 2
+        cap_lm = N + 4 if capacity_landmarks is None else max(N, int(capacity_landmarks))  # (an update of n_z needs room for n_z New)
+        self.cap = 3 + 2 * cap_lm
+        self.n = n
+        self._x = np.zeros(self.cap)
+        self._P = np.zeros(self.cap * self.cap)
+        self._x[:n] = x
+        self._P[:n * n] = np.asarray(P, dtype=np.float64).reshape(n * n)
+
+    def propagate(self, v, w, Q, dt):
+        Q = np.ascontiguousarray(Q, dtype=np.float64).reshape(4)
+        lib().ekf_oracle_propagate(self.n, _p(self._x), _p(self._P), v, w, _p(Q), dt, _p(self._x), _p(self._P), 0)
+
+    def update(self, z_chunk, R_chunk, gamma_max=50, gamma_min=10, cond_limit=80.0):
+        z = np.asfortranarray(np.asarray(z_chunk, dtype=np.float64).reshape(2, -1))
+        R = np.asfortranarray(np.asarray(R_chunk, dtype=np.float64).reshape(2, -1))
+        n_z = z.shape[1]
+        dec = np.zeros(n_z, dtype=np.int32)
+        mat = np.zeros(n_z, dtype=np.int32)
+        mah = np.zeros(n_z)
+        zf = z.ravel(order="F").copy()
+        Rf = R.ravel(order="F").copy()
+        m = lib().ekf_oracle_update_inplace(self.n, _p(self._x), _p(self._P), self.cap, n_z, _p(zf), _p(Rf), int(gamma_max),
+                                            int(gamma_min), float(cond_limit), dec.ctypes.data_as(_ip), mat.ctypes.data_as(_ip), _p(mah))
+        if m < 0:
+            raise ValueError("oracle session capacity exceeded")
+        self.n = m
+        return dec.tolist(), mat.tolist(), mah.tolist()
+
+    def compass(self, z, R):
+        lib().ekf_oracle_compass(self.n, _p(self._x), _p(self._P), float(z), float(R), 0)
+
+    def state(self):
+        n = self.n
+        return self._x[:n].copy(), self._P[:n * n].reshape(n, n).copy()
+
+    def pose(self):
+        return self._x[:3].copy()
+
+    def robot_cov(self):
+        n = self.n
+        return self._P[:n * n].reshape(n, n)[:3, :3].copy()
