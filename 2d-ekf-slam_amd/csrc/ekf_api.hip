@@ -59,6 +59,8 @@ struct ekf_batch {
     bool mirror_by_chain; // the newest writer of the host mirror is chain launch number chain_seq (else: some other kernel, synchronise)
     int flush_keep;       // pool key of s_flush: CUs kept free for the chain, -1 = unmasked
     int chain_wgs;        // k_chain workgroups per filter
+    int claimed_cus;      // CUs this handle's chain workgroups occupy when they run (residency registry, below)
+    bool flush_masked;    // s_flush is a dedicated CU-masked queue
     size_t chain_lds;     // dynamic LDS of a k_chain launch: the own-row cache
     double *bm1_base;     // allocation behind dv.Bm[1] (overlap mode)
     std::vector<int *> tile_maps;  // [nT]: XCD-aware wave -> tile tables of the row-block dense pass, built on demand
@@ -97,6 +99,8 @@ struct ekf_batch {
     // scratch
     std::vector<int> h_int;
 };
+
+static int sticky_status(ekf_batch *h, bool include_capacity);
 
 extern "C" const char *ekf_last_error(void) { return g_last_error.c_str(); }
 
@@ -203,13 +207,25 @@ static hipError_t dev_alloc_zero(T **p, size_t count, size_t *total, hipStream_t
     return hipMemsetAsync(*p, 0, bytes, s);
 }
 
+// Residency registry.  The workgroups of a filter's chain kernel exchange their arg-min candidates while they run, so all
+// of them must be resident at once; a workgroup that cannot be placed until another one exits would leave the others
+// polling until their bound runs out (EKF_ERR_TIMEOUT).  Every live handle therefore claims the CUs its chain launch needs
+// (workgroups / workgroups-per-CU from the occupancy query), and a handle that does not fit beside the live ones is
+// refused at creation.  Per process and device; other processes on the GPU are out of sight.
+static std::mutex g_res_mu;
+static int g_cus_claimed[64];
+
+static int create_impl(ekf_batch *h, int batch, int capacity_landmarks, int device_id, const ekf_params *params, const hipDeviceProp_t &prop);
+
+extern "C" int ekf_destroy(ekf_handle h);
+
 extern "C" int ekf_batch_create(ekf_handle *out, int batch, int capacity_landmarks, int device_id, const ekf_params *params) {
     if (!out || batch < 1 || capacity_landmarks < 1 || capacity_landmarks > 16000) return set_error(EKF_ERR_BAD_ARG, "bad batch/capacity");
     *out = nullptr;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return set_error(EKF_ERR_NO_DEVICE, "no HIP device: libekfslam_hip has no CPU fallback");
-    if (device_id < 0 || device_id >= ndev) return set_error(EKF_ERR_BAD_ARG, "bad device_id");
+    if (device_id < 0 || device_id >= ndev || device_id >= 64) return set_error(EKF_ERR_BAD_ARG, "bad device_id");
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device_id));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
@@ -218,14 +234,26 @@ extern "C" int ekf_batch_create(ekf_handle *out, int batch, int capacity_landmar
         return set_error(EKF_ERR_NO_DEVICE, buf);
     }
     HIP_TRY(hipSetDevice(device_id));
+    ekf_batch *h = new ekf_batch();  // value-initialised: every pointer null, every count zero
+    h->device = device_id;
+    int rc = create_impl(h, batch, capacity_landmarks, device_id, params, prop);
+    if (rc != EKF_OK) {
+        std::string keep = g_last_error;
+        ekf_destroy(h);  // frees whatever was allocated before the failure (tolerates the null members)
+        (void)hipGetLastError();
+        g_last_error = keep;
+        return rc;
+    }
+    *out = h;
+    return EKF_OK;
+}
 
-    ekf_batch *h = new ekf_batch();
+static int create_impl(ekf_batch *h, int batch, int capacity_landmarks, int device_id, const ekf_params *params, const hipDeviceProp_t &prop) {
     ekf_default_params(&h->params);
     if (params) h->params = *params;
     if (h->params.max_pending < 1) h->params.max_pending = 1;
     if (h->params.max_pending > EKF_MAX_PENDING) h->params.max_pending = EKF_MAX_PENDING;
     if (h->params.log_capacity < 16) h->params.log_capacity = 16;
-    h->device = device_id;
     h->device_bytes = 0;
     if (!pool_take(device_id, -1, &h->s_chain)) {
         TRACE("create: stream");
@@ -296,6 +324,21 @@ extern "C" int ekf_batch_create(ekf_handle *out, int batch, int capacity_landmar
     int workers = (dv.lpw + 63) / 64 * 64;
     if (workers > max_workers) workers = max_workers;
     h->chain_threads = 64 + workers;  // wave 0 is the control wave
+    {
+        int per_cu = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_chain, h->chain_threads, h->chain_lds));
+        if (per_cu < 1) return set_error(EKF_ERR_STATE, "the chain kernel does not fit a CU with this capacity / window");
+        const int need = (G * batch + per_cu - 1) / per_cu;
+        std::lock_guard<std::mutex> lk(g_res_mu);
+        if (g_cus_claimed[device_id] + need > prop.multiProcessorCount) {
+            char buf[256];
+            snprintf(buf, sizeof buf, "this handle's %d chain workgroups need %d CUs, %d of %d are claimed by live handles: they could not all be resident at once",
+                     G * batch, need, g_cus_claimed[device_id], prop.multiProcessorCount);
+            return set_error(EKF_ERR_STATE, buf);
+        }
+        g_cus_claimed[device_id] += need;
+        h->claimed_cus = need;
+    }
     size_t B = batch;
     hipStream_t s = h->s_chain;
     HIP_TRY(dev_alloc_zero(&dv.x, B * dv.xs, &h->device_bytes, s));
@@ -388,10 +431,16 @@ extern "C" int ekf_batch_create(ekf_handle *out, int batch, int capacity_landmar
             }
             if (em != hipSuccess) {
                 (void)hipGetLastError();
-                HIP_TRY(hipStreamCreateWithFlags(&h->s_flush, hipStreamNonBlocking));
+                h->flush_keep = -1;  // an ordinary stream (and that is the pool it goes back to)
+                if (!pool_take(device_id, -1, &h->s_flush)) HIP_TRY(hipStreamCreateWithFlags(&h->s_flush, hipStreamNonBlocking));
             }
         }
-        h->inkernel_wait = (getenv("EKF_INKERNEL_WAIT") ? atoi(getenv("EKF_INKERNEL_WAIT")) != 0 : true) && concurrent_kernels_ok(device_id, h->s_chain, h->s_flush) != 0;
+        h->flush_masked = h->flush_keep > 0;
+        // In-kernel waiting only where the pass has a queue of its own CUs and kernels of the two streams were seen to run
+        // side by side; everywhere else (unmasked fallback stream, serialising tools) the chain stream waits for the
+        // pass's event.
+        h->inkernel_wait = (getenv("EKF_INKERNEL_WAIT") ? atoi(getenv("EKF_INKERNEL_WAIT")) != 0 : true) && h->flush_masked &&
+                           concurrent_kernels_ok(device_id, h->s_chain, h->s_flush) != 0;
         HIP_TRY(hipEventCreate(&h->ev_chain));  // (stop events of dispatch packets)
         for (int i = 0; i < 2; i++) HIP_TRY(hipEventCreate(&h->ev_flush[i]));
         h->chain_signalled = false;
@@ -407,7 +456,6 @@ extern "C" int ekf_batch_create(ekf_handle *out, int batch, int capacity_landmar
     TRACE("create: final sync");
     HIP_TRY(hipStreamSynchronize(h->s_chain));
     TRACE("create: done");
-    *out = h;
     return EKF_OK;
 }
 
@@ -419,13 +467,15 @@ extern "C" int ekf_destroy(ekf_handle h) {
     if (!h) return EKF_OK;
     hipSetDevice(h->device);
     TRACE("destroy: sync");
-    hipStreamSynchronize(h->s_chain);
-    if (h->overlap) {
+    if (h->s_chain) hipStreamSynchronize(h->s_chain);
+    if (h->s_flush && h->s_flush != h->s_chain) {
         hipStreamSynchronize(h->s_flush);
-        hipEventDestroy(h->ev_chain), hipEventDestroy(h->ev_flush[0]), hipEventDestroy(h->ev_flush[1]);
         pool_give(h->device, h->flush_keep, h->s_flush);
-        hipFree(h->bm1_base);
     }
+    if (h->ev_chain) hipEventDestroy(h->ev_chain);
+    for (int i = 0; i < 2; i++)
+        if (h->ev_flush[i]) hipEventDestroy(h->ev_flush[i]);
+    if (h->bm1_base) hipFree(h->bm1_base);
     for (auto &g : h->graphs) hipGraphExecDestroy(g.exec);
     EkfDev &dv = h->dv;
     hipFree(dv.x), hipFree(dv.R), hipFree(dv.D), hipFree(dv.Bm[0]), hipFree(dv.FA), hipFree(dv.FB);
@@ -436,14 +486,21 @@ extern "C" int ekf_destroy(ekf_handle h) {
     for (int *m : h->tile_maps)
         if (m) hipFree(m);
     if (h->script_d) hipFree(h->script_d);
-    hipHostFree(h->ring_h);
-    hipHostFree(h->mirror_h);
-    for (int i = 0; i < 2; i++) hipEventDestroy(h->ring_ev[i]);
-    hipEventDestroy(h->t0), hipEventDestroy(h->t1);
+    if (h->ring_h) hipHostFree(h->ring_h);
+    if (h->mirror_h) hipHostFree(h->mirror_h);
+    for (int i = 0; i < 2; i++)
+        if (h->ring_ev[i]) hipEventDestroy(h->ring_ev[i]);
+    if (h->t0) hipEventDestroy(h->t0);
+    if (h->t1) hipEventDestroy(h->t1);
     for (auto e : h->prof_pool) hipEventDestroy(e);
     TRACE("destroy: streams");
-    pool_give(h->device, -1, h->s_chain);
+    if (h->s_chain) pool_give(h->device, -1, h->s_chain);
+    if (h->claimed_cus > 0) {
+        std::lock_guard<std::mutex> lk(g_res_mu);
+        g_cus_claimed[h->device] -= h->claimed_cus;
+    }
     delete h;
+    (void)hipGetLastError();
     TRACE("destroy: done");
     return EKF_OK;
 }
@@ -686,7 +743,7 @@ static int refresh_bounds(ekf_batch *h, bool full = true) {
         mx = h->h_int[b] > mx ? h->h_int[b] : mx;
     }
     h->n_lm_hi = mx;
-    return EKF_OK;
+    return sticky_status(h, false);  // a timed-out launch left an invalid state: say so wherever state is handed out
 }
 
 // ---- propagate --------------------------------------------------------------------------------------
@@ -814,14 +871,34 @@ extern "C" int ekf_record_truth(ekf_handle h, const double *truth) {
 }
 
 // ---- synchronising accessors ------------------------------------------------------------------------
+// The sticky per-filter status the kernels leave in the host mirror (valid after a synchronising read).  A timeout means
+// the filter's state is invalid, and every accessor that hands out state reports it; a capacity overflow leaves a valid
+// state (the landmark was simply not added) and is reported by ekf_sync only.
+static int sticky_status(ekf_batch *h, bool include_capacity) {
+    for (int b = 0; b < h->dv.B; b++) {
+        const int st = h->mirror_h[b].status;
+        if (st == EKF_ERR_TIMEOUT) {
+            char buf[320];
+            snprintf(buf, sizeof buf, "filter %d: a device-side wait ran out (the %d chain workgroups of a filter were not all resident -- another tenant on the GPU? -- "
+                                      "or the dense pass a launch depends on did not complete); the filter's state is invalid until ekf_set_state", b, h->chain_wgs);
+            return set_error(EKF_ERR_TIMEOUT, buf);
+        }
+        if (st == EKF_ERR_CAPACITY && include_capacity) {
+            char buf[160];
+            snprintf(buf, sizeof buf, "filter %d: a New landmark did not fit capacity_landmarks = %d (Update.cpp:152-178 would have grown the state)", b, h->dv.Ncap);
+            return set_error(EKF_ERR_CAPACITY, buf);
+        }
+        if (st != 0 && st != EKF_ERR_CAPACITY) return set_error(st, "a kernel reported an error status");
+    }
+    return EKF_OK;
+}
+
 extern "C" int ekf_sync(ekf_handle h) {
     if (!h) return set_error(EKF_ERR_BAD_ARG, "null handle");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->s_chain));
     if (h->overlap) HIP_TRY(hipStreamSynchronize(h->s_flush));
-    for (int b = 0; b < h->dv.B; b++)
-        if (h->mirror_h[b].status != 0) return set_error(h->mirror_h[b].status, "a New landmark did not fit capacity_landmarks");
-    return EKF_OK;
+    return sticky_status(h, true);
 }
 
 extern "C" int ekf_flush(ekf_handle h) {
@@ -1111,7 +1188,6 @@ extern "C" int ekf_script_run(ekf_handle h, int first_step, int n_steps, int use
                 if (g.steps == S && g.M == h->script_M && g.has_truth == h->script_has_truth) ge = &g;
             int save_set = h->cur_set, save_buf = h->buf_in;
             if (!ge) {
-                hipGraph_t graph;
                 bool prof_saved = h->prof_flush;
                 int hi_saved = h->n_lm_hi;
                 h->prof_flush = false;    // event pairs are not captured into graphs
@@ -1121,16 +1197,21 @@ extern "C" int ekf_script_run(ekf_handle h, int first_step, int n_steps, int use
                 int rc2 = enqueue_script_steps(h, h->cursor_d, 0, S);
                 if (rc2 == EKF_OK && h->pending != 0) rc2 = set_error(EKF_ERR_STATE, "graph block does not end on an empty slot set");
                 hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, h->s_chain, h->cursor_d, S * ops);
+                hipGraph_t graph = nullptr;
                 hipError_t e = hipStreamEndCapture(h->s_chain, &graph);
                 h->prof_flush = prof_saved;
                 h->n_lm_hi = hi_saved;
-                if (rc2) return rc2;
-                if (e != hipSuccess) return set_error(EKF_ERR_HIP, "graph capture failed");
-                if (h->cur_set != save_set || h->buf_in != save_buf) return set_error(EKF_ERR_STATE, "graph block does not restore the ping-pong state");
+                if (rc2 == EKF_OK && e != hipSuccess) rc2 = set_error(EKF_ERR_HIP, "graph capture failed");
+                if (rc2 == EKF_OK && (h->cur_set != save_set || h->buf_in != save_buf)) rc2 = set_error(EKF_ERR_STATE, "graph block does not restore the ping-pong state");
                 GraphEntry g;
                 g.steps = S, g.M = h->script_M, g.has_truth = h->script_has_truth;
-                HIP_TRY(hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0));
-                HIP_TRY(hipGraphDestroy(graph));
+                g.exec = nullptr;
+                if (rc2 == EKF_OK && hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0) != hipSuccess) rc2 = set_error(EKF_ERR_HIP, "hipGraphInstantiate failed");
+                if (graph) hipGraphDestroy(graph);
+                if (rc2) {
+                    (void)hipGetLastError();
+                    return rc2;
+                }
                 h->graphs.push_back(g);
                 ge = &h->graphs.back();
             }
@@ -1141,6 +1222,9 @@ extern "C" int ekf_script_run(ekf_handle h, int first_step, int n_steps, int use
                 HIP_TRY(hipGraphLaunch(ge->exec, h->s_chain));
                 s += S;
             }
+            // The captured chain launches carry the sequence numbers of the capture: a replay stores those into the host
+            // mirror, so mirror.seq says nothing about which replay has finished.  Readers fall back to a stream synchronise.
+            h->mirror_by_chain = false;
             h->pending = 0;
             h->n_lm_hi = h->dv.Ncap;  // landmarks may have been appended inside the graphs; unknown until a sync
         }

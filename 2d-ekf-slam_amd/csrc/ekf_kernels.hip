@@ -101,6 +101,7 @@ struct ChainLds {
     double pa, pb;                       // Phi_R(0,2), Phi_R(1,2) of the Propagate the control lane has just done
     double xd;                           // the filter-wide pick of the exchange: distance, landmark, owning workgroup
     int xi, xsrc;
+    int abort;  // a bounded wait ran out: every thread leaves the operation loop at the next barrier
     // rows of the matched landmark in every slot of the set being filled, [slot][side A/B][row e][k] (dead slots: zeros)
     // per virtual slot (the set a dense pass is folding first, then the open set): what kind of slot it is, the matched
     // landmark's cached rows loC (K rows of an Old slot, P_xL rows of a New one) and the 2x2 matrix M with
@@ -474,13 +475,15 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
 
     // Overlap mode: wait for the dense pass this launch depends on (MI355X_MICROARCH.md consumer form: one relaxed poll,
     // one agent acquire, vmcnt(0), workgroup barrier, then plain loads).  Normally the pass finished long ago.
+    if (tid == 0) L.abort = 0;
     if (need_pass > 0) {
         if (tid == 0) {
             long spins = 0;
             while ((int)(__hip_atomic_load(dv.pass_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - need_pass) < 0) {
                 __builtin_amdgcn_s_sleep(8);
-                if (++spins > (1L << 24)) {  // bounded
-                    dv.status[b] = EKF_ERR_HIP;
+                if (++spins > (1L << 24)) {  // bounded: the launch then applies nothing (the pass's output is not there)
+                    dv.status[b] = EKF_ERR_TIMEOUT;
+                    L.abort = 1;
                     break;
                 }
             }
@@ -488,6 +491,15 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads();
+        if (L.abort) {  // (uniform over the workgroup; the other workgroups of the filter time out the same way)
+            if (lead && tid == 0) {
+                EkfMirror *mr = dv.mirror + b;
+                mr->status = EKF_ERR_TIMEOUT;
+                __atomic_thread_fence(__ATOMIC_RELEASE);
+                __hip_atomic_store(&mr->seq, launch_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            return;
+        }
     }
 
     // the control lane records what kind of slot the operation leaves (every workgroup in LDS, workgroup 0 also in HBM
@@ -743,11 +755,9 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                 }
                 // The control wave polls the heads (lane l reads workgroup l's), picks, and hands the result to the workers
                 // through LDS and one workgroup barrier: a third of the polling loads of "every wave for itself", and the
-                // control wave has nothing else to do here.  (EKF_POLL_ALL builds keep the every-wave form.)
+                // control wave has nothing else to do here.
                 const int lane = tid & 63;
-#ifndef EKF_POLL_ALL
                 if (!worker) {
-#endif
                     const unsigned long long *hd = (const unsigned long long *)(part + ((size_t)(epoch & 1) * dv.gmax + (lane < G ? lane : 0)) * EKF_REC_DOUBLES) + 2 * EKF_REC_HEAD;
                     unsigned long long h0 = 0, h1 = 0, h2 = 0;
                     long spins = 0;
@@ -757,8 +767,8 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                         h2 = __hip_atomic_load(hd + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         const bool ok = lane >= G || (((h0 ^ tag) >> 32) == 0 && ((h1 ^ tag) >> 32) == 0 && ((h2 ^ tag) >> 32) == 0);
                         if (__all(ok)) break;
-                        if (++spins > (1L << 22)) {  // bounded: a lost workgroup must not hang the GPU
-                            if (lane == 0) dv.status[b] = EKF_ERR_HIP;
+                        if (++spins > (1L << 22)) {  // bounded: a workgroup that is not running must not hang the GPU
+                            if (lane == 0) dv.status[b] = EKF_ERR_TIMEOUT, L.abort = 1;
                             break;
                         }
                         __builtin_amdgcn_s_sleep(1);
@@ -771,13 +781,11 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                         i = (int)(unsigned)(h2 & 0xffffffffull);
                     }
                     wave_argmin(d, i, src);
-                    gd = d, gi = i;
-#ifndef EKF_POLL_ALL
                     if (lane == 0) L.xd = d, L.xi = i, L.xsrc = src;
                 }
                 __syncthreads();  // (X) the pick is known to every wave
+                if (L.abort) goto finish;  // (uniform: read behind the barrier)
                 gd = L.xd, gi = uni(L.xi), src = uni(L.xsrc);
-#endif
                 epoch++;
                 STAMP(2);  // publish + poll + pick
             }
@@ -864,7 +872,8 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                             }
                             if ((bad >> 32) == 0) break;
                             if (++spins > (1L << 22)) {  // bounded
-                                dv.status[b] = EKF_ERR_HIP;
+                                dv.status[b] = EKF_ERR_TIMEOUT;
+                                L.abort = 1;
                                 break;
                             }
                         }
@@ -890,6 +899,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                     }
                 }
                 __syncthreads();  // (3) staged rows visible
+                if (L.abort) goto finish;
                 STAMP(4);
                 if (worker) {
                     const OldHdr h = old_header(RS.c, RS.s, L.w);
@@ -1111,6 +1121,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
         }
         // OP_NOP
     }
+finish:  // (also the way out when a bounded wait ran out: the sticky status says so, later operations are not applied)
 
 #ifdef EKF_CHAIN_STAMPS
     if ((tid == 0 || tid == 64) && g == 0 && b == 0)

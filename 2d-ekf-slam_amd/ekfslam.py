@@ -11,7 +11,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EKFSLAM_LIB", os.path.join(_HERE, "lib", "libekfslam_hip.so"))  # override: diagnostic builds
 
-OK, ERR_BAD_ARG, ERR_CAPACITY, ERR_HIP, ERR_NO_DEVICE, ERR_STATE = 0, -1, -2, -3, -4, -5
+OK, ERR_BAD_ARG, ERR_CAPACITY, ERR_HIP, ERR_NO_DEVICE, ERR_STATE, ERR_TIMEOUT = 0, -1, -2, -3, -4, -5, -6
 NEW, OLD, IGNORE = 1, 2, 3
 
 # every symbol include/ekfslam_c.h declares

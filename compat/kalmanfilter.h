@@ -61,7 +61,9 @@ public:
         if (Num_Landmarks > 0) {  // :53-60, including its stride-1 indexing
             xbuf.resize(3 + 2 * (size_t)Num_Landmarks);
             check(ekf_get_x(h, 0, xbuf.data(), (int)xbuf.size()));
-            for (int i = 1; i < Num_Landmarks; i++) knownfeaturesFile << xbuf[3 + i] << " " << xbuf[4 + i] << std::endl;
+            // (same lines as the reference; one flush per call instead of its std::endl per line)
+            for (int i = 1; i < Num_Landmarks; i++) knownfeaturesFile << xbuf[3 + i] << " " << xbuf[4 + i] << "\n";
+            knownfeaturesFile.flush();
         }
     }
 

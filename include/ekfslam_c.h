@@ -36,7 +36,11 @@ extern "C" {
 #define EKF_ERR_CAPACITY (-2)  /* a New landmark did not fit capacity_landmarks (sticky until ekf_set_state) */
 #define EKF_ERR_HIP (-3)       /* HIP runtime error, see ekf_last_error() */
 #define EKF_ERR_NO_DEVICE (-4) /* no usable gfx950 device: the product path has no CPU fallback */
-#define EKF_ERR_STATE (-5)     /* call not valid in the handle's current state */
+#define EKF_ERR_STATE (-5)     /* call not valid in the handle's current state (also: the GPU cannot keep this handle's
+                                  chain workgroups resident beside those of the handles already live, see ekf_batch_create) */
+#define EKF_ERR_TIMEOUT (-6)   /* a bounded device-side wait ran out (a filter's workgroups were not all running at once, or the
+                                  dense pass a launch depends on did not complete): the launch stopped applying operations and
+                                  the filter's state is invalid; sticky until ekf_set_state */
 
 /* Gate decisions, as printed by Update.cpp:154,183,191 ("New " / "Old " / "Ignore "). */
 #define EKF_DECISION_NEW 1
@@ -83,7 +87,10 @@ void ekf_default_params(ekf_params *p);
 
 /* KalmanFilter::KalmanFilter, kalmanfilter.cpp:4-12: x = 0_3, P = 0_3x3, no landmarks.
  * capacity_landmarks bounds N; all device memory is allocated here, none later (except a transient
- * staging buffer inside ekf_get_state / ekf_set_state). */
+ * staging buffer inside ekf_get_state / ekf_set_state).
+ * The sequential part of a filter runs on a few workgroups that exchange their arg-min candidates while they
+ * run, so all of them must be resident on the GPU at once: creation fails with EKF_ERR_STATE when this
+ * handle's workgroups do not fit beside those of the handles already live on the device (in this process). */
 int ekf_create(ekf_handle *out, int capacity_landmarks, int device_id, const ekf_params *params);
 int ekf_batch_create(ekf_handle *out, int batch, int capacity_landmarks, int device_id, const ekf_params *params);
 int ekf_destroy(ekf_handle h);
@@ -154,7 +161,7 @@ int ekf_script_run(ekf_handle h, int first_step, int n_steps, int use_graph);
 
 /* ---- synchronisation, timing, diagnostics ---------------------------------------------------- */
 
-int ekf_sync(ekf_handle h);  /* waits for the stream, returns a sticky error (EKF_ERR_CAPACITY) if any filter raised one */
+int ekf_sync(ekf_handle h);  /* waits for the stream, returns a sticky error (EKF_ERR_CAPACITY, EKF_ERR_TIMEOUT) if any filter raised one */
 /* Fold the deferred slots into P_LL now (one dense pass, asynchronous). */
 int ekf_flush(ekf_handle h);
 /* hipEvent pair on the handle's stream. stop synchronises and returns elapsed milliseconds. */

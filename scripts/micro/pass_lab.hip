@@ -147,7 +147,7 @@ static double time_us(F launch, int iters) {
 
 int main() {
     const int sizes[2] = {8256, 32896};
-    for (int si = 0; si < 2; si++) {
+    for (int si = 0; si < (getenv("LAB_SMALL") ? 1 : 2); si++) {
         const int ntiles = sizes[si];
         const size_t n = (size_t)ntiles * 4096, bytes = n * 8;
         double *a, *b0;
@@ -156,6 +156,16 @@ int main() {
         double *b = b0 + 512;  // 4 KB skew as the library's second buffer
         CK(hipMemset(a, 0, bytes));
         CK(hipMemset(b0, 0, bytes + 4096));
+        if (getenv("LAB_RANDOM")) {  // zeros vs data: does the content of the stream matter?
+            std::vector<double> hbuf(n);
+            unsigned long long st = 88172645463325252ull;
+            for (size_t i = 0; i < n; i++) {
+                st ^= st << 13, st ^= st >> 7, st ^= st << 17;
+                hbuf[i] = (double)(st >> 11) * (1.0 / 9007199254740992.0) - 0.5;
+            }
+            CK(hipMemcpy(a, hbuf.data(), bytes, hipMemcpyHostToDevice));
+            CK(hipMemcpy(b, hbuf.data(), bytes, hipMemcpyHostToDevice));
+        }
         const int iters = si == 0 ? 40 : 12;
         const double gb = 2.0 * bytes / 1e9;
         auto report = [&](const char *name, double us) { printf("tiles %5d  %-44s %8.1f us  %6.0f GB/s  (%.3f of 8 TB/s)\n", ntiles, name, us, gb / (us * 1e-6), gb / (us * 1e-6) / 8000.0); fflush(stdout); };

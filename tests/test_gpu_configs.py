@@ -1,0 +1,211 @@
+"""BASELINE.json configs 2, 3 and 4 at FULL size on the GPU against the CPU oracle, on the very inputs bench.py
+times (same seeds, same scenario functions, default window, both pipeline modes), plus a strongly correlated
+covariance at N = 1120 and the sweep's NaN behaviour.  SURVEY.md 8(d): N = 4096 checked after steps 1 and 5,
+N = 1024 after steps 1, 10 and 200, 256 filters x N = 256 over 200 steps with sampled filters compared state for
+state.  Tolerance: helpers.py (north_star's 1e-6 relative on x and P); decisions and matched indices identical.
+
+The oracle runs once per configuration (in-place session, structured mode) and is reused by the second pipeline
+mode."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+from helpers import assert_bitwise_symmetric, assert_state_close, correlated_state
+
+pytestmark = pytest.mark.gpu
+
+_cache = {}
+
+
+def cached(key, fn):
+    """One entry at a time: the reference states are hundreds of MB at N = 4096."""
+    if key not in _cache:
+        _cache.clear()
+        _cache[key] = fn()
+    return _cache[key]
+
+
+def oracle_checkpoints(oc, x0, P0, sc, M, checkpoints, truth=False):
+    """Run the scripted steps on the oracle; state, decisions and (optionally) NIS / NEES sums at each checkpoint."""
+    oc.set_threads(min(16, os.cpu_count() or 1))
+    S = oc.Session(x0, P0)
+    out, decs = {}, []
+    nis = nees = 0.0
+    for s in range(max(checkpoints)):
+        v, w, dt = sc["ctrl"][s]
+        S.propagate(v, w, oc.make_Q(v), dt)
+        for m in range(M):
+            d, mt, mh = S.update(sc["z"][s, m].reshape(2, 1), sc["R"][s, m].reshape(2, 2, order="F"))
+            decs.append((d[0], mt[0]))
+            if d[0] == oc.OLD:
+                nis += mh[0]  # the accepted match's Mahalanobis distance, Update.cpp:136,142
+        if truth:
+            e = S.pose() - sc["truth"][s]
+            e[2] -= 2 * math.pi * math.floor((e[2] + math.pi) / (2 * math.pi))
+            nees += float(e @ np.linalg.solve(S.robot_cov(), e))
+        if s + 1 in checkpoints:
+            x, P = S.state()
+            out[s + 1] = dict(x=x, P=P, decs=list(decs), nis=nis, nees=nees)
+    return out
+
+
+def load_script(f, scs):
+    f.script_load(np.stack([s["ctrl"] for s in scs], axis=1), np.stack([s["z"] for s in scs], axis=2),
+                  np.stack([s["R"] for s in scs], axis=2), truth=np.stack([s["truth"] for s in scs], axis=1))
+
+
+def bench_inputs(pkg, workload, steps, g=0):
+    """Exactly what bench.py builds for global filter g of `workload`."""
+    import bench
+    N, B, _, _, seed, extent = bench.WORKLOADS[workload]
+    mc = pkg.montecarlo
+    x0, P0 = pkg.scenarios.injected_state(N, seed=mc.filter_seed(seed, g), extent=extent)
+    sc = pkg.scenarios.steady_script(x0, steps=steps, M=4, seed=mc.filter_seed(seed + 7919, g))
+    return N, x0, P0, sc
+
+
+def test_config3_benchmarked_configuration_vs_oracle(pkg, oc, pipeline_mode):
+    """N = 4096 (dense P 8195 x 8195), window 16, the pipeline mode under test: the configuration BENCH_rNN times.
+    Oracle check after step 1 and after step 5 (20 measurements: one full window folded by a dense pass that, in
+    overlap mode, runs beside the chain kernels of the second window, plus a partly filled window)."""
+    M = 4
+    N, x0, P0, sc = bench_inputs(pkg, "n4096", 5)
+    ref = cached("config3", lambda: oracle_checkpoints(oc, x0, P0, sc, M, (1, 5)))
+    for steps in (1, 5):
+        f = pkg.FilterBatch(1, N, max_pending=16)
+        assert f.window == 16 and f.overlap == (pipeline_mode == "overlap")
+        f.set_state(x0, P0)
+        load_script(f, [sc])
+        f.script_run(0, steps)
+        f.sync()
+        r = ref[steps]
+        assert [(d[0], d[1]) for d in f.decisions(0, steps * M)] == r["decs"]
+        assert all(d[0] == oc.OLD for d in r["decs"])
+        xg, Pg = f.get_state()
+        assert_state_close(xg, Pg, r["x"], r["P"], "N=4096 after step %d" % steps)
+        assert_bitwise_symmetric(Pg)
+        f.close()
+        del xg, Pg
+
+
+def test_config2_n1024_after_steps_1_10_200(pkg, oc):
+    """N = 1024, default window, bench.py's inputs: oracle check after steps 1, 10 and 200."""
+    M = 4
+    N, x0, P0, sc = bench_inputs(pkg, "n1024", 200)
+    ref = cached("config2", lambda: oracle_checkpoints(oc, x0, P0, sc, M, (1, 10, 200), truth=True))
+    f = pkg.FilterBatch(1, N, max_pending=16, log_capacity=1024)
+    f.set_state(x0, P0)
+    load_script(f, [sc])
+    done = 0
+    for cp in (1, 10, 200):
+        f.script_run(done, cp - done)
+        done = cp
+        f.sync()
+        r = ref[cp]
+        assert [(d[0], d[1]) for d in f.decisions(0, cp * M)] == r["decs"]
+        xg, Pg = f.get_state()
+        assert_state_close(xg, Pg, r["x"], r["P"], "N=1024 after step %d" % cp)
+        assert_bitwise_symmetric(Pg)
+        st = f.stats()[0]
+        assert st["nis_count"] == cp * M and st["nees_count"] == cp
+        assert abs(st["nis_sum"] - r["nis"]) <= 1e-6 * abs(r["nis"]) + 1e-9
+        assert abs(st["nees_sum"] - r["nees"]) <= 1e-6 * abs(r["nees"]) + 1e-9
+    f.close()
+
+
+def test_config4_full_size_batch_256_filters(pkg, oc):
+    """256 independent filters x N = 256 behind one handle, 200 steps of 1 Propagate + 4 Updates (bench.py's batch256
+    inputs): every filter's decisions are the intended Old matches; 9 sampled filters are compared with the oracle
+    state for state, and their device-side NIS / NEES sums with values computed from the oracle's Mahalanobis
+    distances and P_RR."""
+    B, M, steps = 256, 4, 200
+    sampled = [0, 1, 37, 74, 111, 148, 185, 222, 255]
+
+    def build():
+        ins = [bench_inputs(pkg, "batch256", steps, g) for g in range(B)]
+        refs = {g: oracle_checkpoints(oc, ins[g][1], ins[g][2], ins[g][3], M, (steps,), truth=True)[steps] for g in sampled}
+        return ins, refs
+
+    ins, refs = cached("config4", build)
+    N = ins[0][0]
+    f = pkg.FilterBatch(B, N, max_pending=16, log_capacity=steps * M)
+    for b in range(B):
+        f.set_state(ins[b][1], ins[b][2], index=b)
+    load_script(f, [i[3] for i in ins])
+    f.script_run(0, steps)
+    f.sync()
+    st = f.stats()
+    assert all(s["n_old"] == steps * M and s["n_new"] == 0 and s["n_ignore"] == 0 for s in st)
+    for b in range(B):
+        if b in sampled or b % 16 == 0:
+            dec = f.decisions(b, steps * M)
+            assert [d[1] for d in dec] == [3 + 2 * int(t) for t in ins[b][3]["target"].ravel()], "filter %d" % b
+    for g in sampled:
+        r = refs[g]
+        assert [(d[0], d[1]) for d in f.decisions(g, steps * M)] == r["decs"]
+        xg, Pg = f.get_state(g)
+        assert_state_close(xg, Pg, r["x"], r["P"], "filter %d of 256" % g)
+        assert_bitwise_symmetric(Pg)
+        assert abs(st[g]["nis_sum"] - r["nis"]) <= 1e-6 * abs(r["nis"]) + 1e-9, (g, st[g]["nis_sum"], r["nis"])
+        assert abs(st[g]["nees_sum"] - r["nees"]) <= 1e-6 * abs(r["nees"]) + 1e-9, (g, st[g]["nees_sum"], r["nees"])
+        assert st[g]["nis_count"] == steps * M and st[g]["nees_count"] == steps
+    f.close()
+
+
+@pytest.mark.parametrize("copies,max_pending", [(20, 16), (20, 3), (4, 8)])
+def test_strongly_correlated_covariance(pkg, oc, copies, max_pending):
+    """A covariance as SLAM really produces it -- every landmark correlated with every other through the robot --
+    at N = 1120 (35 x 35 tiles): a config-1 lifecycle run on the oracle (56 landmarks), tiled 20 times with
+    correlation 0.8 between the copies (helpers.correlated_state).  Off-diagonal P_LL entries are of the size of the diagonal, so every tile of
+    the multi-tile MFMA pass moves by much more than the tolerance per measurement."""
+    x0, P0 = cached(("corr", copies), lambda: correlated_state(pkg, oc, copies=copies, rho=0.8))
+    N = (x0.size - 3) // 2
+    off = np.abs(P0[3:, 3:][np.triu_indices(2 * N, k=2)])
+    assert np.median(off) > 0.05 * np.median(np.diag(P0)[3:])  # strongly correlated indeed
+    M, steps = 4, 8
+    sc = pkg.scenarios.steady_script(x0, steps=steps, M=M, seed=5, min_separation=1.0)
+    f = pkg.FilterBatch(1, N, max_pending=max_pending)
+    f.set_state(x0, P0)
+    load_script(f, [sc])
+    f.script_run(0, steps)
+    f.sync()
+    r = oracle_checkpoints(oc, x0, P0, sc, M, (steps,))[steps]
+    assert [(d[0], d[1]) for d in f.decisions(0, steps * M)] == r["decs"]
+    assert sum(d[0] == oc.OLD for d in r["decs"]) >= steps * M // 2
+    xg, Pg = f.get_state()
+    assert xg.size == r["x"].size
+    assert_state_close(xg, Pg, r["x"], r["P"], "correlated N=%d" % N)
+    assert_bitwise_symmetric(Pg)
+    # the update moved the far copies' blocks too (they are correlated with the observed landmarks)
+    far = slice(3 + 2 * (N - N // copies), None)
+    assert np.abs(r["P"][far, far] - P0[far, far]).max() > 1e-3 * np.abs(P0[far, far]).max()
+    f.close()
+
+
+def test_sweep_nan_behaviour(pkg, oc):
+    """Update.cpp:131,140 with NaN: `cond >= 80` is false (the landmark is not skipped) and `Mahal_dist > NaN` is
+    false (it is never selected).  A landmark whose 2x2 block is NaN can therefore never be matched: a measurement
+    aimed at it opens a New landmark, a measurement aimed elsewhere updates as if it were not there."""
+    N = 12
+    x0, P0 = pkg.scenarios.injected_state(N, seed=3, extent=40.0)  # sparse: every other landmark is far beyond the gate
+    sc = pkg.scenarios.steady_script(x0, steps=1, M=2, seed=4, min_separation=0.5)
+    bad = int(sc["target"][0, 0])   # the first measurement's landmark is poisoned, the second's is healthy
+    Li = 3 + 2 * bad
+    P0[Li:Li + 2, Li:Li + 2] = np.nan
+    f = pkg.FilterBatch(1, N + 4, max_pending=4)
+    f.set_state(x0, P0)
+    x, P = x0, P0
+    for m in range(2):
+        z, R = sc["z"][0, m], sc["R"][0, m].reshape(2, 2, order="F")
+        dec = f.update(z.reshape(1, 1, 2), R.reshape(1, 1, 2, 2))[0]
+        x, P, do, mo, _ = oc.update(x, P, z.reshape(2, 1), R)
+        assert (dec[0][0], dec[0][1]) == (do[0], mo[0])
+        assert mo[0] != Li and do[0] == (oc.NEW if m == 0 else oc.OLD), (m, do, mo)
+    xg, Pg = f.get_state()
+    assert xg.shape == x.shape
+    assert np.array_equal(np.isnan(Pg), np.isnan(P)) and np.isnan(P).sum() >= 4
+    ok = ~np.isnan(P)
+    assert_state_close(xg, np.where(ok, Pg, 0.0), x, np.where(ok, P, 0.0), "NaN landmark")
+    f.close()

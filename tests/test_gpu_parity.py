@@ -536,3 +536,91 @@ def test_overlap_equals_inplace_when_the_pass_is_the_longer_leg(pkg, monkeypatch
     assert np.abs(xi - xo).max() <= 1e-11 * np.abs(xi).max()
     assert np.abs(Pi - Po).max() <= 1e-11 * np.abs(Pi).max()
     assert_bitwise_symmetric(Po)
+
+
+def test_graph_replays_do_not_fool_the_host_mirror(pkg, oc):
+    """A captured block replayed several times stores the capture's launch numbers into the host mirror; reads of
+    pose / landmark count / decisions right behind the replays (no explicit sync) must still wait for the LAST replay,
+    and the dense passes that follow must still cover landmarks appended inside the replays."""
+    steps, M = 96, 3
+    script, ctrl, z, R, valid = lifecycle_as_script(pkg, steps, M)
+    outs = []
+    for graph in (False, True):
+        f = pkg.FilterBatch(1, 64, max_pending=4, log_capacity=1024, overlap=0)
+        f.script_load(ctrl, z, R, valid=valid)
+        f.script_run(0, steps, use_graph=graph)  # graph: blocks of 8 steps -> 12 replays of one captured block
+        poses, nlm = f.poses().copy(), f.num_landmarks().copy()  # no f.sync() in between
+        f.script_run(0, 8, use_graph=False)  # more measurements: the next dense pass must be sized for the real map
+        f.sync()
+        outs.append((poses, nlm, f.get_state(), f.decisions(0, 1024)))
+        f.close()
+    (p0, n0, (x0, P0), d0), (p1, n1, (x1, P1), d1) = outs
+    assert n0[0] >= 4 and np.array_equal(n0, n1)
+    assert np.array_equal(p0, p1)
+    assert d0 == d1 and np.array_equal(x0, x1) and np.array_equal(P0, P1)
+    # and against the oracle, so that "equal" is not "equally wrong"
+    x, P = np.zeros(3), np.zeros((3, 3))
+    for st in script + script[:8]:
+        x, P = oc.propagate(x, P, st["v"], st["w"], oc.make_Q(st["v"]), st["dt"])
+        for fx, fy in st["feats_mm"]:
+            zz, RR = oc.make_measurement(fx, fy)
+            x, P, _, _, _ = oc.update(x, P, zz.reshape(2, 1), RR)
+    assert_state_close(x1, P1, x, P, "graph replays")
+
+
+def test_residency_registry_refuses_what_cannot_be_co_resident(pkg, monkeypatch):
+    """The chain workgroups of a filter must all be resident at once.  Handles claim the CUs their chain launch needs;
+    creation fails with EKF_ERR_STATE once the live handles of the process would not fit the GPU together, and a
+    destroyed handle gives its share back."""
+    monkeypatch.setenv("EKF_OVERLAP", "0")
+    live = []
+    refused = None
+    for k in range(40):  # N = 2048: 11 or more workgroups of > 80 KB LDS each, one per CU
+        try:
+            live.append(pkg.FilterBatch(1, 2048, max_pending=16))
+        except pkg.EkfError as e:
+            refused = e
+            break
+    assert refused is not None and refused.code == pkg.ekfslam.ERR_STATE and "resident" in str(refused)
+    assert 8 <= len(live) < 40
+    live.pop().close()
+    live.append(pkg.FilterBatch(1, 2048, max_pending=16))  # fits again
+    for f in live:
+        f.close()
+
+
+def test_concurrent_handles_of_32_workgroups(pkg, oc):
+    """Four handles whose filters spread over 32 chain workgroups each (N = 4096), driven at the same time from one host
+    thread (asynchronous launches on four stream pairs): all 128 workgroups are co-resident, every exchange completes,
+    and each handle reproduces the run it makes alone."""
+    N, M, steps = 4096, 4, 12
+    x0, P0 = pkg.scenarios.injected_state(N, seed=20260003)
+    scs = [pkg.scenarios.steady_script(x0, steps=steps, M=M, seed=60 + k) for k in range(4)]
+
+    def make(k):
+        f = pkg.FilterBatch(1, N, max_pending=16)
+        f.set_state(x0, P0)
+        load_script(f, scs[k])
+        return f
+
+    alone = []
+    for k in range(2):
+        f = make(k)
+        f.script_run(0, steps)
+        f.sync()
+        alone.append((f.get_x(0), f.decisions(0, steps * M)))
+        f.close()
+    for count in (2, 4):
+        fs = [make(k) for k in range(count)]
+        for s in range(0, steps, 4):  # interleave the handles' launches
+            for f in fs:
+                f.script_run(s, 4)
+        for f in fs:
+            f.sync()  # raises on EKF_ERR_TIMEOUT
+        for k, f in enumerate(fs):
+            dec = f.decisions(0, steps * M)
+            assert [d[1] for d in dec] == [3 + 2 * int(t) for t in scs[k]["target"].ravel()]
+            if k < 2:
+                assert np.array_equal(f.get_x(0), alone[k][0]) and dec == alone[k][1]
+        for f in fs:
+            f.close()
