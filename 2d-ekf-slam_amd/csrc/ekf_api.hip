@@ -59,6 +59,7 @@ struct ekf_batch {
     bool mirror_by_chain; // the newest writer of the host mirror is chain launch number chain_seq (else: some other kernel, synchronise)
     int flush_keep;       // pool key of s_flush: CUs kept free for the chain, -1 = unmasked
     int chain_wgs;        // k_chain workgroups per filter
+    int chain_filters;    // filters per k_chain launch (all of the batch when its workgroups are resident together)
     int claimed_cus;      // CUs this handle's chain workgroups occupy when they run (residency registry, below)
     bool flush_masked;    // s_flush is a dedicated CU-masked queue
     size_t chain_lds;     // dynamic LDS of a k_chain launch: the own-row cache
@@ -287,7 +288,7 @@ static int create_impl(ekf_batch *h, int batch, int capacity_landmarks, int devi
     // the LDS of at most 64 resident workgroups per filter, i.e. when it does not cost window length
     int want_overlap = getenv("EKF_OVERLAP") ? atoi(getenv("EKF_OVERLAP")) : h->params.overlap;
     if (want_overlap < 0) {
-        int g_max = EKF_CHAIN_MAX_WGS < 256 / batch ? EKF_CHAIN_MAX_WGS : 256 / batch;
+        int g_max = batch >= 256 ? 1 : (EKF_CHAIN_MAX_WGS < 256 / batch ? EKF_CHAIN_MAX_WGS : 256 / batch);
         if (g_max < 1) g_max = 1;
         long lpw_min = (capacity_landmarks + g_max - 1) / g_max;
         want_overlap = (lpw_min * maxp * 2 * 32 <= lds_budget) ? 1 : 0;
@@ -303,11 +304,12 @@ static int create_impl(ekf_batch *h, int batch, int capacity_landmarks, int devi
     int G_lds = (int)(((long)capacity_landmarks * maxp * sets_in_lds * 32 + lds_budget - 1) / lds_budget);
     if (G_lds > G) G = G_lds;
     if (G > EKF_CHAIN_MAX_WGS) G = EKF_CHAIN_MAX_WGS;
-    if (G * batch > 256) G = 256 / batch;
+    if (G * batch > 256) G = 256 / batch;  // (batches of more than 256 filters: one workgroup per filter, several launches)
     if (G < 1) G = 1;
     if (getenv("EKF_CHAIN_WGS")) G = atoi(getenv("EKF_CHAIN_WGS")) > 0 ? atoi(getenv("EKF_CHAIN_WGS")) : G;
     if (G > EKF_CHAIN_MAX_WGS) G = EKF_CHAIN_MAX_WGS;
     h->chain_wgs = G;
+    h->chain_filters = batch * G <= 256 ? batch : 256 / G;  // every workgroup of a launch resident at once
     dv.gmax = G;
     dv.lpw = (capacity_landmarks + G - 1) / G;
     if ((long)dv.lpw * maxp * sets_in_lds * 32 > lds_budget) {
@@ -328,7 +330,7 @@ static int create_impl(ekf_batch *h, int batch, int capacity_landmarks, int devi
         int per_cu = 0;
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_chain, h->chain_threads, h->chain_lds));
         if (per_cu < 1) return set_error(EKF_ERR_STATE, "the chain kernel does not fit a CU with this capacity / window");
-        const int need = (G * batch + per_cu - 1) / per_cu;
+        const int need = (G * h->chain_filters + per_cu - 1) / per_cu;
         std::lock_guard<std::mutex> lk(g_res_mu);
         if (g_cus_claimed[device_id] + need > prop.multiProcessorCount) {
             char buf[256];
@@ -669,9 +671,14 @@ static int launch_ops(ekf_batch *h, const double *in, const int *cursor, int k0,
         }
         // overlap: the launch that fills the set signals ev_chain from its own dispatch packet (no marker packet)
         const bool closes = h->overlap && used == h->dv.maxp;
-        hipExtLaunchKernelGGL(k_chain, dim3(h->chain_wgs, h->dv.B), dim3(h->chain_threads), h->chain_lds, h->s_chain, nullptr,
-                              closes ? h->ev_chain : nullptr, 0, h->dv, in, cursor, k0 + start, i - start, h->pending, h->cur_set, h->buf_in,
-                              h->prev_pending, ++h->chain_seq, h->need_pass);
+        ++h->chain_seq;  // (one number per logical launch: every filter's mirror reaches it)
+        for (int b0 = 0; b0 < h->dv.B; b0 += h->chain_filters) {
+            const int nb = h->dv.B - b0 < h->chain_filters ? h->dv.B - b0 : h->chain_filters;
+            const bool last = b0 + nb >= h->dv.B;
+            hipExtLaunchKernelGGL(k_chain, dim3(h->chain_wgs, nb), dim3(h->chain_threads), h->chain_lds, h->s_chain, nullptr,
+                                  closes && last ? h->ev_chain : nullptr, 0, h->dv, in, cursor, k0 + start, i - start, h->pending, h->cur_set, h->buf_in,
+                                  h->prev_pending, h->chain_seq, h->need_pass, b0);
+        }
         h->mirror_by_chain = true;
         h->chain_signalled = closes;
         h->pending = used;

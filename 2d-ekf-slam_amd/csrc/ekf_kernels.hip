@@ -209,6 +209,7 @@ __device__ __forceinline__ size_t chk_idx(long long *dbg, int line, long long id
 //                       The LDS copy of the own rows and the exchanged rows cover n_prev + slot "virtual" slots,
 //                       the other set's first.
 //   buf_read          : Bm buffer to read P_LL columns from
+//   b_off             : first filter of this launch (a batch larger than the GPU keeps resident at once is cut into launches)
 //   need_pass         : > 0: dense pass number need_pass wrote Bm[buf_read] and read the slot rows this launch is about to
 //                       overwrite; the launch waits for dv.pass_flag to reach it before touching either (an in-kernel
 //                       wait instead of a cross-stream event: the event's barrier packet cost 6 us per window)
@@ -303,12 +304,12 @@ __device__ __forceinline__ void sweep_one(int lm, const LmState &st, double z0, 
 }
 
 __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, const double *in, const int *cursor, int k0,
-                                                                int nops, int slot0, int set, int buf_read, int n_prev, long long launch_seq, int need_pass) {
+                                                                int nops, int slot0, int set, int buf_read, int n_prev, long long launch_seq, int need_pass, int b_off) {
     __shared__ ChainLds L;
     __shared__ double recs[EKF_CHAIN_MAX_OPS * 8];
     extern __shared__ double own_rows[];  // [virtual slot][component 00 01 10 11][local landmark]: K rows (Old, compass), P_xL rows (New), zeros (dead)
     const int g = blockIdx.x, G = gridDim.x;
-    const int b = blockIdx.y;
+    const int b = blockIdx.y + b_off;  // batches beyond 256 resident workgroups go out as several launches (b_off)
     const int tid = threadIdx.x;
     const int bd = blockDim.x;
     const bool lead = (g == 0);

@@ -132,3 +132,42 @@ def lifecycle_script(seed=20260001, n_landmarks=50, steps=1000, v=0.3, radius=8.
             comp = (pose[2] + math.sqrt(COMPASS_VAR) * rng.standard_normal()) % (2 * math.pi)
         out.append(dict(v=v_meas, w=w_meas, dt=dt, feats_mm=feats, compass=comp, truth=pose.copy()))
     return out
+
+
+def simulated_scan(seed, n_rays=181, noise_mm=8.0, max_range_mm=12000.0):
+    """One sweep of a SICK LMS-200 as the reference reads it (slam.cpp:90: 180 degrees; featuredetector.cpp:18-22:
+    range, local x, local y per reading, mm): the robot stands in a random rectilinear room with a few partition
+    walls, one ray per degree from -90 to +90 degrees, Gaussian range noise.  Rays that hit nothing within
+    max_range_mm report max_range_mm (beyond the detector's 8 m limit).  Returns (range, lx, ly) float64 arrays."""
+    rng = np.random.default_rng(seed)
+    w, h = rng.uniform(3000.0, 9000.0, 2)          # room half-extents, mm
+    rot = rng.uniform(-math.pi, math.pi)            # room orientation relative to the robot
+    walls = [((-w, -h), (w, -h)), ((w, -h), (w, h)), ((w, h), (-w, h)), ((-w, h), (-w, -h))]
+    for _ in range(int(rng.integers(0, 4))):       # partitions jutting out of a wall: more corners
+        if rng.random() < 0.5:
+            x0 = rng.uniform(-0.8 * w, 0.8 * w)
+            walls.append(((x0, -h), (x0, -h + rng.uniform(0.2, 0.7) * 2 * h)))
+        else:
+            y0 = rng.uniform(-0.8 * h, 0.8 * h)
+            walls.append(((-w, y0), (-w + rng.uniform(0.2, 0.7) * 2 * w, y0)))
+    off = np.array([rng.uniform(-0.6 * w, 0.6 * w), rng.uniform(-0.6 * h, 0.6 * h)])
+    c, s = math.cos(rot), math.sin(rot)
+    Rm = np.array([[c, -s], [s, c]])
+    segs = [(Rm @ (np.array(a) - off), Rm @ (np.array(b) - off)) for a, b in walls]
+    ang = np.deg2rad(np.linspace(-90.0, 90.0, n_rays))
+    rngs = np.full(n_rays, max_range_mm)
+    for a, b in segs:
+        d = b - a
+        for k, th in enumerate(ang):
+            u = np.array([math.cos(th), math.sin(th)])
+            den = u[0] * d[1] - u[1] * d[0]
+            if abs(den) < 1e-12:
+                continue
+            t = (a[0] * d[1] - a[1] * d[0]) / den      # distance along the ray
+            q = (a[0] * u[1] - a[1] * u[0]) / den      # position along the wall
+            if t > 50.0 and 0.0 <= q <= 1.0 and t < rngs[k]:
+                rngs[k] = t
+    hit = rngs < max_range_mm
+    rngs = np.where(hit, np.maximum(rngs + noise_mm * rng.standard_normal(n_rays), 20.0), max_range_mm)
+    rngs = np.floor(rngs)                              # ArSensorReading::getRange is an unsigned int of millimetres
+    return rngs.astype(np.float64), rngs * np.cos(ang), rngs * np.sin(ang)

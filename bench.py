@@ -28,16 +28,80 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s mea
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X datasheet fp64 matrix; v_mfma_f64_16x16x4_f64 measured 68 TFLOP/s (scripts/micro)
 
 WORKLOADS = {
-    # name: (N landmarks, batch per GPU, default steps, default warmup, seed, map half-extent in m)   -- BASELINE.json configs
-    "n4096": (4096, 1, 512, 32, 20260003, 50.0),   # config 3 (more steps than its 50: a run is only ~30 ms)
-    "n1024": (1024, 1, 200, 10, 20260002, 50.0),   # config 2
+    # name: (N landmarks, batch per GPU, default steps, default warmup, seed, map half-extent in m, min. target separation)   -- BASELINE.json configs
+    "n4096": (4096, 1, 512, 32, 20260003, 50.0, 1.5),   # config 3 (more steps than its 50: a run is only ~30 ms)
+    "n1024": (1024, 1, 200, 10, 20260002, 50.0, 1.5),   # config 2
     # not a BASELINE.json config: one size past the 256 MB Infinity Cache in the build's own storage scheme (P_LL triangle
     # 1.08 GB per buffer), at config 3's landmark density -- tells HBM streaming from cache hits in the roofline fraction
-    "n8192": (8192, 1, 128, 16, 20260008, 70.7),
-    # config 4 (config 5 = the same at --gpus 8): 256 landmarks at config 3's landmark density, so that four
-    # well-conditioned (range < 9 m, cond(S) < 80) targets exist around the robot at every step
-    "batch256": (256, 256, 200, 10, 20260004, 12.5),
+    "n8192": (8192, 1, 128, 16, 20260008, 70.7, 1.5),
+    # config 4 (config 5 = the same, sharded over --gpus N): 256 landmarks at config 3's landmark density, so that four
+    # well-conditioned (range < 9 m, cond(S) < 80) targets exist around the robot at every step; targets at least 1 m from
+    # their nearest neighbour: checked on the oracle, all 2048 filters of config 5 take only the intended Old matches
+    "batch256": (256, 256, 200, 10, 20260004, 12.5, 1.0),
 }
+
+def make_filters(pkg, mc, workload, lo, hi, steps, M, dev_id, max_pending, log_entries, tail_windows=0):
+    """A handle holding global filters [lo, hi) of `workload`, states injected and the step script loaded (all untimed):
+    `steps` steps plus `tail_windows` windows' worth for measurements outside the timed region."""
+    import numpy as np
+    N, _, _, _, seed, extent, min_sep = WORKLOADS[workload]
+    f = pkg.FilterBatch(hi - lo, N, device=dev_id, max_pending=max_pending, log_capacity=max(4096, log_entries))
+    total_steps = steps + tail_windows * -(-f.window // M)  # (the library may have shortened the window to fit its on-chip buffer)
+    scripts = []
+    for b, g in enumerate(range(lo, hi)):
+        x0, P0 = pkg.scenarios.injected_state(N, seed=mc.filter_seed(seed, g), extent=extent)
+        f.set_state(x0, P0, index=b)
+        scripts.append(pkg.scenarios.steady_script(x0, steps=total_steps, M=M, seed=mc.filter_seed(seed + 7919, g), min_separation=min_sep))
+        del P0
+    f.script_load(np.stack([s["ctrl"] for s in scripts], axis=1), np.stack([s["z"] for s in scripts], axis=2),
+                  np.stack([s["R"] for s in scripts], axis=2), truth=np.stack([s["truth"] for s in scripts], axis=1))
+    return f, scripts
+
+
+def timed_steps(f, mc, torch, dist, coll_device, W, K, graph):
+    """W untimed warm-up steps, then exactly K steps bracketed by barrier + synchronize on both sides; the timed region
+    ends with P_LL fully folded (ekf_flush) and with the one collective, the all-gather of per-filter NIS / NEES."""
+    f.script_run(0, W, use_graph=graph)
+    f.sync()
+    f.reset_stats()
+    f.flush_profile_read()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    f.timer_start()
+    f.script_run(W, K, use_graph=graph)
+    f.flush()                # P_LL fully folded inside the timed region, whatever K*M modulo the window is
+    dev_ms = f.timer_stop()  # hipEvents on the handle's own stream
+    summary = mc.summarise(f.stats())
+    gathered = mc.gather_stats(summary, device=coll_device)  # the one collective (RCCL all-gather)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        te = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+    return elapsed, dev_ms, gathered
+
+
+def config5_legs(pkg, mc, torch, dist, coll_device, rank, world, dev_id, M, max_pending):
+    """BASELINE.json config 5: independent filters at N = 256 sharded over the ranks, RCCL all-gather of NIS / NEES inside
+    the timed region.  Weak: 256 filters per GPU.  Strong: 2048 filters in all (more than 256 per GPU go out as several
+    chain launches per window)."""
+    _, per_gpu, K, W, _, _, _ = WORKLOADS["batch256"]
+    out = {"world_size": world, "N": 256, "M": M, "steps": K, "warmup": W}
+    for leg, total in (("weak", per_gpu * world), ("strong", 2048)):
+        lo, hi = mc.shard_range(total, rank, world)
+        f, _ = make_filters(pkg, mc, "batch256", lo, hi, W + K, M, dev_id, max_pending, (K + W) * M)
+        elapsed, _, gathered = timed_steps(f, mc, torch, dist, coll_device, W, K, False)
+        st = f.stats()
+        assert all(s["n_old"] == K * M for s in st), "a filter left the Old branch"
+        f.close()
+        out[leg] = {"filters_total": total, "filters_per_gpu": hi - lo, "value": total * K / elapsed, "unit": "filter-steps/s",
+                    "ms_per_step": elapsed / K * 1e3, "gathered_rows": int(gathered.shape[0])}
+    return out
 
 
 def main():
@@ -53,6 +117,7 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the real thing) or gloo (rehearsal of the multi-rank path on a one-GPU box)")
     ap.add_argument("--device", type=int, default=None, help="force a device id (rehearsal only; default LOCAL_RANK)")
     ap.add_argument("--no-flush-profile", action="store_true", help="do not bracket the dense pass with hipEvents")
+    ap.add_argument("--no-config5", action="store_true", help="with --gpus N > 1: skip the config-5 legs (256 filters/GPU weak, 2048 filters strong)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -70,7 +135,7 @@ def main():
     pkg = ge.load_package()
     mc = pkg.montecarlo
 
-    N, B, d_steps, d_warm, seed, extent = WORKLOADS[args.workload]
+    N, B, d_steps, d_warm, seed, extent, min_sep = WORKLOADS[args.workload]
     K = args.steps if args.steps is not None else d_steps
     W = args.warmup if args.warmup is not None else d_warm
     M = args.M
@@ -88,49 +153,14 @@ def main():
 
     # ---- inputs: built on the host, then moved to HBM (untimed) ------------------------------------
     lo, hi = mc.shard_range(B * world, rank, world)
-    f = pkg.FilterBatch(B, N, device=dev_id, max_pending=args.max_pending, log_capacity=max(4096, (K + W) * M))
+    # (4 windows of untimed tail: dense passes measured one at a time, nothing beside them)
+    f, scripts = make_filters(pkg, mc, args.workload, lo, hi, W + K, M, dev_id, args.max_pending, (K + W) * M, tail_windows=4)
     args.max_pending = f.window  # the library may shorten the window to fit its on-chip buffer
     win_steps = -(-f.window // M)   # steps that fill one window
-    tail_steps = 4 * win_steps      # untimed tail: dense passes measured one at a time, nothing beside them
-    scripts = []
-    for b, g in enumerate(range(lo, hi)):
-        x0, P0 = pkg.scenarios.injected_state(N, seed=mc.filter_seed(seed, g), extent=extent)
-        f.set_state(x0, P0, index=b)
-        scripts.append(pkg.scenarios.steady_script(x0, steps=W + K + tail_steps, M=M, seed=mc.filter_seed(seed + 7919, g)))
-        del P0
-    ctrl = np.stack([s["ctrl"] for s in scripts], axis=1)
-    z = np.stack([s["z"] for s in scripts], axis=2)
-    Rz = np.stack([s["R"] for s in scripts], axis=2)
-    truth = np.stack([s["truth"] for s in scripts], axis=1)
-    f.script_load(ctrl, z, Rz, truth=truth)
-
-    # ---- warm-up (untimed) ---------------------------------------------------------------------------
-    f.script_run(0, W, use_graph=bool(args.graph))
-    f.sync()
-    f.reset_stats()
     f.flush_profile(not args.no_flush_profile)
-    f.flush_profile_read()
 
-    # ---- timed region: exactly K steps ------------------------------------------------------------------
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    f.timer_start()
-    f.script_run(W, K, use_graph=bool(args.graph))
-    f.flush()                # P_LL fully folded inside the timed region, whatever K*M modulo the window is
-    dev_ms = f.timer_stop()  # hipEvents on the handle's own stream
-    summary = mc.summarise(f.stats())
-    gathered = mc.gather_stats(summary, device=coll_device)  # the one collective (RCCL all-gather)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    if dist is not None:
-        te = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
+    # ---- warm-up (untimed), then the timed region: exactly K steps -----------------------------------------
+    elapsed, dev_ms, gathered = timed_steps(f, mc, torch, dist, coll_device, W, K, bool(args.graph))
 
     # ---- checks outside the timed region --------------------------------------------------------------
     f.sync()
@@ -151,6 +181,11 @@ def main():
             f.flush()
             f.sync()
         alone_launches, alone_ms = f.flush_profile_read()
+
+    config5 = None
+    if world > 1 and not args.no_config5:
+        f.close()
+        config5 = config5_legs(pkg, mc, torch, dist, coll_device, rank, world, dev_id, M, args.max_pending)
 
     if rank != 0:
         if dist is not None:
@@ -183,15 +218,18 @@ def main():
         a_s = alone_ms / 1e3 / alone_launches
         roofline["alone"] = {"avg_launch_us": a_s * 1e6, "achieved": bytes_per_launch / a_s / 1e9, "frac": bytes_per_launch / a_s / 1e9 / HBM_PEAK_GBS,
                              "launches": int(alone_launches), "note": "same pass, nothing else on the GPU, outside the timed region"}
-    tfile = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
-    if os.path.exists(tfile):  # PMC-derived HBM bytes per launch (rocprofv3 passes of the same command, see profiles/)
-        tj = json.load(open(tfile))
-        if tj.get("max_pending") == args.max_pending and B == 1:
-            roofline["traffic"] = tj.get("hbm_bytes_per_launch")
+    # PMC-derived HBM bytes per launch (separate rocprofv3 --pmc passes of this very command: scripts/profile_r02.sh, profiles/)
+    for tname in ("traffic_%s.json" % args.workload, "traffic_%s_inplace.json" % args.workload):
+        tfile = os.path.join(ROOT, "profiles", tname)
+        if os.path.exists(tfile):
+            tj = json.load(open(tfile))
+            if tj.get("max_pending") == args.max_pending and tj.get("overlap", int(f.overlap)) == int(f.overlap) and tj.get("filters_per_gpu", B) == B:
+                roofline["traffic"] = tj.get("hbm_bytes_per_launch")
+                break
 
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(pkg, N, M, seed, extent)
+        cpu = cpu_baseline(pkg, N, M, seed, extent, min_sep)
 
     rep = mc.consistency_report(gathered, K * M, K)
     # the steady workload feeds 0.5-sigma measurement noise and a noise-free truth (margins
@@ -217,13 +255,14 @@ def main():
         "roofline": roofline,
         "cpu_baseline": cpu,
         "mc_stats": mc_stats,
+        "config5": config5,
     }
     print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()
 
 
-def cpu_baseline(pkg, N, M, seed, extent):
+def cpu_baseline(pkg, N, M, seed, extent, min_sep):
     """The oracle's faithful-dense path (same dense O(n^2) passes as the reference, 1 thread: the
     reference's Makefile:2 has no OpenMP) timed on this host on a bounded sample of the same workload."""
     import numpy as np
@@ -232,7 +271,7 @@ def cpu_baseline(pkg, N, M, seed, extent):
 
     sample_steps = {4096: 4, 1024: 40, 256: 400}.get(N, 2)  # about 10-20 s of single-thread CPU work
     x, P = pkg.scenarios.injected_state(N, seed=seed, extent=extent)
-    sc = pkg.scenarios.steady_script(x, steps=sample_steps, M=M, seed=seed + 7919)
+    sc = pkg.scenarios.steady_script(x, steps=sample_steps, M=M, seed=seed + 7919, min_separation=min_sep)
     oc.build()
     t0 = time.perf_counter()
     for s in range(sample_steps):

@@ -1,0 +1,43 @@
+/*
+ * features_oracle.h -- CPU restatement of the reference's perception path (features/houghtransform.cpp,
+ * features/featuredetector.cpp:74-289).  TEST INFRASTRUCTURE ONLY; PARITY UNPINNED (see features_oracle.c).
+ * Only tests/ may use this code; the product path (2d-ekf-slam_amd/csrc) never links, loads or calls it.
+ */
+#ifndef FEATURES_ORACLE_H
+#define FEATURES_ORACLE_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* houghtransform.h:20-30, featuredetector.h:27-34 */
+#define FEAT_MAX_DIST 8000
+#define FEAT_DISTANCE 10
+#define FEAT_THETA_SIZE 180
+#define FEAT_RADIUS_SIZE (2 * FEAT_MAX_DIST / FEAT_DISTANCE + 1)
+#define FEAT_ADDITION (FEAT_RADIUS_SIZE / 2)
+#define FEAT_NUM_PEAKS 200
+#define FEAT_MERGE_THETA 30
+#define FEAT_MERGE_RADIUS 5
+#define FEAT_MIN_DIST (1000 * 1000)
+#define FEAT_MIN_POINTS 3
+#define FEAT_POINT_DIST 600
+#define FEAT_CORNER_DIST 90000
+#define FEAT_MAX_SEGS 128 /* (not in the reference: output capacity; a segment needs more than 3 points) */
+
+void feat_oracle_tables(float *cos_t, float *sin_t);
+void feat_oracle_hough(int n, const double *range, const double *lx, const double *ly, unsigned char *grid);
+void feat_oracle_peaks(const unsigned char *grid, int *peaks);
+/* lines: [radius, theta, weight] each; returns the number of lines (may exceed max_lines: only max_lines are written) */
+int feat_oracle_lines(const unsigned char *grid, const int *peaks, double *lines, int max_lines);
+/* segs: [radius, theta, startX, startY, endX, endY, numPoints] each */
+int feat_oracle_segments(int n, const double *range, const double *lx, const double *ly, int nlines, const double *lines,
+                         double *segs, int max_segs);
+int feat_oracle_corners(int nseg, const double *segs, double *corners, int max_corners);
+/* the whole of getFeatures minus the ARIA reads and the structural compass; every *_out may be NULL */
+int feat_oracle_extract(int n, const double *range, const double *lx, const double *ly, double *corners, int max_corners,
+                        unsigned char *grid_out, int *peaks_out, int *n_lines_out, double *lines_out, int *n_segs_out, double *segs_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -18,7 +18,8 @@ _ip = ctypes.POINTER(ctypes.c_int)
 
 
 def build(force=False):
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(os.path.join(_HERE, "ekf_oracle.c")):
+    srcs = [os.path.join(_HERE, f) for f in ("ekf_oracle.c", "ekf_oracle.h", "features_oracle.c", "features_oracle.h")]
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _SO
 

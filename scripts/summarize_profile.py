@@ -1,18 +1,22 @@
-"""Condense a scripts/profile_r01.sh output directory into the small files committed under profiles/."""
+"""Condense a scripts/profile_r02.sh output directory into the small files committed under profiles/:
+<tag>_kernel_stats.csv (rocprofv3 --kernel-trace --stats), <tag>_summary.json (per-kernel averages, PMC means per
+dispatch, the bench lines of the profiled runs, HBM traffic per dense-pass launch) and traffic_<workload>[_inplace].json,
+which bench.py reads back into roofline.traffic."""
 import collections, csv, glob, json, os, shutil, sys
 
-src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof_r01"
-tag = sys.argv[2] if len(sys.argv) > 2 else "r01_n4096_w16"
+src = sys.argv[1]
+tag = sys.argv[2]
+args = sys.argv[3] if len(sys.argv) > 3 else ""
 dst = "profiles"
 os.makedirs(dst, exist_ok=True)
-ks = glob.glob(os.path.join(src, "trace/runc/*_kernel_stats.csv"))[0]
+ks = glob.glob(os.path.join(src, "trace/*/*_kernel_stats.csv"))[0]
 shutil.copy(ks, os.path.join(dst, tag + "_kernel_stats.csv"))
-summary = {"command": "rocprofv3 --kernel-trace --stats | --pmc FETCH_SIZE | --pmc WRITE_SIZE | --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE  -- python3 bench.py --no-cpu-baseline --steps 64 --warmup 8 [+ args] (scripts/profile_r01.sh, scripts/collect_r01.sh for the tag-specific arguments and EKF_OVERLAP)",
+summary = {"command": "rocprofv3 --kernel-trace --stats | --pmc FETCH_SIZE | --pmc WRITE_SIZE | --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE  -- python3 bench.py %s   (scripts/profile_r02.sh; EKF_OVERLAP=%s)" % (args, os.environ.get("EKF_OVERLAP", "unset")),
            "kernels": {}, "bench_lines": {}}
 for row in csv.DictReader(open(ks)):
     summary["kernels"][row["Name"].split("(")[0]] = {"calls": int(row["Calls"]), "avg_us": float(row["AverageNs"]) / 1e3, "pct": float(row["Percentage"])}
 for name in ("pmc_fetch", "pmc_write", "pmc_mfma"):
-    fs = glob.glob(os.path.join(src, name, "runc/*_counter_collection.csv"))
+    fs = glob.glob(os.path.join(src, name, "*/*_counter_collection.csv"))
     if not fs:
         continue
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -22,20 +26,28 @@ for name in ("pmc_fetch", "pmc_write", "pmc_mfma"):
         if k in summary["kernels"]:
             for c, vals in v.items():
                 summary["kernels"][k][c + "_mean_per_dispatch"] = sum(vals) / len(vals)
+line = None
 for n in ("trace", "fetch", "write", "mfma"):
     p = os.path.join(src, "bench_%s.json" % n)
     if os.path.exists(p) and os.path.getsize(p):
-        d = json.load(open(p))
+        d = json.loads(open(p).read().strip().splitlines()[-1])
+        line = line or d
         summary["bench_lines"][n] = {"value": d["value"], "flush_avg_launch_us_events": d["roofline"]["avg_launch_us"], "frac": d["roofline"]["frac"]}
-fl = summary["kernels"].get("k_flush_rb") or summary["kernels"].get("k_flush", {})
-if "FETCH_SIZE_mean_per_dispatch" in fl and "WRITE_SIZE_mean_per_dispatch" in fl:
+fl = summary["kernels"].get("k_flush_rb", {})
+if "FETCH_SIZE_mean_per_dispatch" in fl and "WRITE_SIZE_mean_per_dispatch" in fl and line:
     # rocprofv3 reports KB.  gfx950: FETCH_SIZE tallies the 128-byte requests of a 16 B/lane stream at 64 B
-    # (MI355X_MICROARCH.md, HBM): the tile stream (= WRITE_SIZE bytes, read once, written once) is doubled,
-    # what is left of FETCH_SIZE is the 8 B/lane operand traffic and is taken as reported.
+    # (MI355X_MICROARCH.md, HBM): the tile stream (= WRITE_SIZE bytes: every tile read once, written once) is doubled,
+    # what is left of FETCH_SIZE is the 8 B/lane slot-operand traffic and is taken as reported.
     f_kb, w_kb = fl["FETCH_SIZE_mean_per_dispatch"], fl["WRITE_SIZE_mean_per_dispatch"]
     tile_read = w_kb * 1024.0
     operand = max(f_kb * 1024.0 - tile_read / 2.0, 0.0)
+    cfg = line["config"]
     summary["traffic"] = {"fetch_size_kb": f_kb, "write_size_kb": w_kb, "tile_read_bytes": tile_read, "operand_read_bytes": operand,
-                          "hbm_bytes_per_launch": tile_read + operand + w_kb * 1024.0}
+                          "hbm_bytes_per_launch": tile_read + operand + w_kb * 1024.0, "algorithmic_bytes_per_launch": line["roofline"]["bytes_per_launch"]}
+    wl = cfg["workload"].split(":")[0]
+    tj = {"workload": wl, "max_pending": cfg["max_pending"], "overlap": cfg["overlap"], "filters_per_gpu": cfg["filters_per_gpu"],
+          "hbm_bytes_per_launch": summary["traffic"]["hbm_bytes_per_launch"], "tile_read_bytes": tile_read, "operand_read_bytes": operand,
+          "write_bytes": w_kb * 1024.0, "algorithmic_bytes_per_launch": line["roofline"]["bytes_per_launch"],
+          "source": "profiles/%s_summary.json: WRITE_SIZE exact; FETCH_SIZE halves the 16 B/lane tile stream (MI355X_MICROARCH.md; calibrated on the 1-measurement window in round 1)" % tag}
+    json.dump(tj, open(os.path.join(dst, "traffic_%s%s.json" % (wl, "" if cfg["overlap"] or wl != "n4096" else "_inplace")), "w"), indent=1)
 json.dump(summary, open(os.path.join(dst, tag + "_summary.json"), "w"), indent=1)
-

@@ -59,10 +59,10 @@ def load_script(f, scs):
 def bench_inputs(pkg, workload, steps, g=0):
     """Exactly what bench.py builds for global filter g of `workload`."""
     import bench
-    N, B, _, _, seed, extent = bench.WORKLOADS[workload]
+    N, B, _, _, seed, extent, min_sep = bench.WORKLOADS[workload]
     mc = pkg.montecarlo
     x0, P0 = pkg.scenarios.injected_state(N, seed=mc.filter_seed(seed, g), extent=extent)
-    sc = pkg.scenarios.steady_script(x0, steps=steps, M=4, seed=mc.filter_seed(seed + 7919, g))
+    sc = pkg.scenarios.steady_script(x0, steps=steps, M=4, seed=mc.filter_seed(seed + 7919, g), min_separation=min_sep)
     return N, x0, P0, sc
 
 

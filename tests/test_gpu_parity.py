@@ -624,3 +624,29 @@ def test_concurrent_handles_of_32_workgroups(pkg, oc):
                 assert np.array_equal(f.get_x(0), alone[k][0]) and dec == alone[k][1]
         for f in fs:
             f.close()
+
+
+def test_batch_larger_than_the_resident_workgroups(pkg, oc):
+    """600 filters behind one handle: more than the 256 chain workgroups the GPU keeps resident at once, so every chain
+    launch goes out in three pieces (filters 0-255, 256-511, 512-599).  Sampled filters of every piece against the oracle."""
+    B, N, M, steps = 600, 24, 3, 6
+    f = pkg.FilterBatch(B, N + 2, max_pending=4)
+    ins = []
+    for b in range(B):
+        x0, P0 = pkg.scenarios.injected_state(N, seed=4000 + b, extent=10.0)
+        f.set_state(x0, P0, index=b)
+        ins.append((x0, P0, pkg.scenarios.steady_script(x0, steps=steps, M=M, seed=5000 + b, min_separation=0.8)))
+    f.script_load(np.stack([i[2]["ctrl"] for i in ins], axis=1), np.stack([i[2]["z"] for i in ins], axis=2),
+                  np.stack([i[2]["R"] for i in ins], axis=2))
+    f.script_run(0, steps)
+    f.sync()
+    poses = f.poses()
+    for b in (0, 255, 256, 300, 511, 512, 599):
+        xo, Po, decs = run_oracle_script(oc, ins[b][0], ins[b][1], ins[b][2], steps, M)
+        assert [(d[0], d[1]) for d in f.decisions(b, steps * M)] == decs
+        xg, Pg = f.get_state(b)
+        assert_state_close(xg, Pg, xo, Po, "filter %d of 600" % b)
+        assert np.allclose(poses[b], xo[:3], rtol=0, atol=1e-12)
+    st = f.stats()
+    assert all(s["n_old"] + s["n_new"] + s["n_ignore"] == steps * M for s in st)
+    f.close()
