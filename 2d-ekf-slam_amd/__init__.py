@@ -3,5 +3,6 @@
 The directory name is not a Python identifier; load it with `__graft_entry__.load_package()`
 (importlib, registered as module `ekfslam_amd`).
 """
-from . import ekfslam, montecarlo, scenarios  # noqa: F401
+from . import ekfslam, features, montecarlo, scenarios  # noqa: F401
 from .ekfslam import FilterBatch, KalmanFilter, EkfError, load  # noqa: F401
+from .features import FeatureExtractor  # noqa: F401

@@ -26,6 +26,8 @@ static int set_error(int code, const char *what) {
     return code;
 }
 
+int ekf_set_last_error(int code, const char *what) { return set_error(code, what); }  // for the library's other translation units (feat_api.hip)
+
 #define HIP_TRY(expr)                                                                        \
     do {                                                                                     \
         hipError_t e_ = (expr);                                                              \

@@ -1,0 +1,236 @@
+"""the perception front end (Hough accumulate, peak selection, line grouping, segment fitting, corner
+extraction: features/houghtransform.cpp, features/featuredetector.cpp:74-289).
+
+CPU tests pin the C oracle (oracle/features_oracle.c, parity unpinned) with known-answer cases read off the source and
+with an independent NumPy / pure-Python restatement written from the same text.  GPU tests (-m gpu) run many simulated
+scans through the C ABI (include/ekffeat_c.h) and demand BIT-EXACT votes, peak arrays (position for position), line and
+segment counts and segment point counts; lines, segment end points and corners are doubles computed by the same
+expressions in the same order and must agree to 1e-9 relative."""
+import math
+
+import numpy as np
+import pytest
+
+T, RSZ, NPK, ADD = 180, 1601, 200, 800
+
+
+@pytest.fixture(scope="module")
+def fc(oc):
+    from oracle import features_c
+    return features_c
+
+
+def wall_scan(points_mm):
+    pts = np.asarray(points_mm, dtype=np.float64)
+    rng = np.floor(np.hypot(pts[:, 0], pts[:, 1]))
+    return rng, pts[:, 0].copy(), pts[:, 1].copy()
+
+
+# ---- independent restatement (NumPy for the votes, plain Python for the sequential parts) --------------------------------
+def py_tables():
+    d = np.float32(3.141592654 / T)
+    th = np.float32(0.0)
+    c, s = np.zeros(T, dtype=np.float32), np.zeros(T, dtype=np.float32)
+    for i in range(T):
+        c[i], s[i] = np.float32(math.cos(float(th))), np.float32(math.sin(float(th)))
+        th = np.float32(th + d)
+    return c, s
+
+
+def py_hough(rng, lx, ly):
+    c, s = py_tables()
+    grid = np.zeros(T * RSZ, dtype=np.int64)
+    ok = rng <= 8000
+    v = np.outer(lx[ok], c.astype(np.float64)) + np.outer(ly[ok], s.astype(np.float64))
+    r = np.sign(v) * np.floor(np.abs(v) + 0.5)                      # round half away from zero
+    idx = np.trunc(r / 10.0).astype(np.int64) + ADD                 # C integer division truncates
+    cells = (np.arange(T)[None, :] * RSZ + idx).ravel()
+    np.add.at(grid, cells, 1)
+    return (grid % 256).astype(np.uint8).reshape(T, RSZ)
+
+
+def py_peaks(grid):
+    g = grid.ravel()
+    peaks = [0] * NPK
+    mindex = 0
+    for cell in np.flatnonzero(g):          # zero cells can never beat a count that is >= 0
+        if g[cell] > g[peaks[mindex]]:
+            peaks[mindex] = int(cell)
+            for i in range(NPK):
+                if g[peaks[i]] < g[peaks[mindex]]:
+                    mindex = i
+    return np.array(peaks, dtype=np.int32)
+
+
+def py_lines(grid, peaks):
+    g = grid.ravel()
+    groups = []
+    for p in peaks:
+        r, t, w = int(p) % RSZ, int(p) // RSZ, int(g[p])
+        if r <= 0:
+            continue
+        for G in groups:
+            in_t = abs(G["maxT"] - t) < 30 or abs(G["minT"] - t) < 30 or (G["minT"] < t < G["maxT"])
+            in_r = abs(G["maxR"] - r) < 5 or abs(G["minR"] - r) < 5 or (G["minR"] < r < G["maxR"])
+            if in_t and in_r:
+                G["maxR"], G["minR"], G["maxT"], G["minT"] = max(r, G["maxR"]), min(r, G["minR"]), max(t, G["maxT"]), min(t, G["minT"])
+                G["r"] += r * w
+                G["t"] += t * w
+                G["w"] += w
+                G["n"] += 1
+                break
+        else:
+            groups.append(dict(maxR=r, minR=r, maxT=t, minT=t, r=r * w, t=t * w, w=w, n=1))
+    for G in groups:
+        if G["r"] < ADD * G["w"]:
+            G["r"] = 2 * ADD * G["w"] - G["r"]
+            G["maxR"], G["minR"] = 2 * ADD - G["maxR"], 2 * ADD - G["minR"]
+            G["t"] -= T * G["w"]
+            G["maxT"] -= T
+            G["minT"] -= T
+    n = len(groups)
+    merge = [-1] * n
+    for i in range(n):
+        m = groups[i]
+        for j in range(i + 1, n):
+            G = groups[j]
+            in_t = abs(G["maxT"] - m["minT"]) < 30 or abs(G["minT"] - m["maxT"]) < 30 or (m["maxT"] > G["minT"] and m["minT"] < G["maxT"])
+            in_r = abs(G["maxR"] - m["minR"]) < 5 or abs(G["minR"] - m["maxR"]) < 5 or (m["maxR"] > G["minR"] and m["minR"] < G["maxR"])
+            if in_t and in_r:
+                merge[j] = i
+    for i in range(n):
+        if merge[i] == -1:
+            continue
+        j = i
+        while merge[j] != -1:
+            j = merge[j]
+        m, G = groups[i], groups[j]
+        G["maxR"], G["minR"], G["maxT"], G["minT"] = max(m["maxR"], G["maxR"]), min(m["minR"], G["minR"]), max(m["maxT"], G["maxT"]), min(m["minT"], G["minT"])
+        G["r"] += m["r"]
+        G["t"] += m["t"]
+        G["w"] += m["w"]
+        G["n"] += m["n"]
+    out = []
+    for i in range(n):
+        if merge[i] != -1:
+            continue
+        G = groups[i]
+        out.append(((G["r"] / float(G["w"]) - ADD) * 10, (G["t"] / float(G["w"])) * (3.141592654 / T), G["w"] / float(G["n"])))
+    return np.array(out).reshape(-1, 3)
+
+
+# ---- CPU: known answers and the independent restatement -----------------------------------------------------------------
+def test_tables_and_single_point_votes(fc):
+    c, s = fc.tables()
+    pc, ps = py_tables()
+    assert np.array_equal(c, pc) and np.array_equal(s, ps)
+    assert c[0] == 1.0 and s[0] == 0.0 and abs(float(c[90])) < 1e-5 and abs(float(s[90]) - 1.0) < 1e-6  # (theta is accumulated in float: bin 90 is not exactly pi/2)
+    # one reading at (2000, 0): theta bin t votes for radius bin (int)round(2000 cos) / 10 + 800 (houghtransform.cpp:247-251)
+    o = fc.extract(*wall_scan([(2000.0, 0.0)]))
+    assert o["grid"].sum() == T and o["grid"][0, 1000] == 1 and o["grid"][90, 800] == 1 and o["grid"][179].argmax() == 600
+    # negative projections truncate towards zero: -1999.7 -> round -2000 -> / 10 = -200; -5 -> 0, not -1
+    o = fc.extract(*wall_scan([(5.0, 0.0)]))
+    assert o["grid"][179, 800] == 1 and o["grid"][0, 800] == 1
+    # a reading beyond MAX_DIST = 8000 does not vote (:243)
+    assert fc.extract(np.array([8001.0]), np.array([8001.0]), np.array([0.0]))["grid"].sum() == 0
+    assert fc.extract(np.array([8000.0]), np.array([8000.0]), np.array([0.0]))["grid"].sum() == T
+
+
+def test_peaks_known_answers(fc):
+    # empty accumulator: peaks stay {0} (houghtransform.cpp:54)
+    assert not fc.extract(np.zeros(0), np.zeros(0), np.zeros(0))["peaks"].any()
+    # a wall x = 3000 seen by 41 readings: every cell (t, r) on the sinusoids gets votes; the 41-vote cell is theta 0, r 1100
+    ys = np.linspace(-2000, 2000, 41)
+    o = fc.extract(*wall_scan([(3000.0, y) for y in ys]))
+    g = o["grid"]
+    assert g.max() == 41 and g[0, 1100] == 41
+    pk = o["peaks"]
+    assert 0 * RSZ + 1100 in pk and len(set(pk.tolist())) == NPK   # 200 distinct cells once more than 200 cells are non-zero
+    # the kept cells are the 200 largest counts (ties at the threshold resolved by scan order)
+    kept = np.sort(g.ravel()[pk])[::-1]
+    allv = np.sort(g.ravel())[::-1][:NPK]
+    assert np.array_equal(kept, allv)
+    # one line: the wall, radius 3000 mm at theta 0, a single corner-free scan
+    assert o["n_corners"] == 0 and len(o["lines"]) >= 1
+    best = o["lines"][np.argmax(o["lines"][:, 2])]
+    assert abs(best[0] - 3000.0) < 40.0 and abs(best[1]) < 0.06
+
+
+def test_corner_of_two_walls_known_answer(fc):
+    # walls x = 3000 (y from -1500 to 2000) and y = 2000 (x from 500 to 3000) meet at (3000, 2000)
+    pts = [(3000.0, y) for y in np.arange(-1500.0, 2000.0, 50.0)] + [(x, 2000.0) for x in np.arange(3000.0, 500.0, -50.0)]
+    o = fc.extract(*wall_scan(pts))
+    assert o["n_corners"] >= 1
+    d = np.hypot(o["corners"][:, 0] - 3000.0, o["corners"][:, 1] - 2000.0)
+    assert d.min() < 60.0, o["corners"]
+    # segments carry more than MIN_POINTS = 3 readings and lie on their lines (featuredetector.cpp:206)
+    assert len(o["segs"]) >= 2 and np.all(o["segs"][:, 6] > 3)
+    for sg in o["segs"]:
+        assert abs(sg[2] * math.cos(sg[1]) + sg[3] * math.sin(sg[1]) - sg[0]) <= 600.0
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 7, 11])
+def test_oracle_against_independent_restatement(pkg, fc, seed):
+    r, x, y = pkg.scenarios.simulated_scan(seed)
+    o = fc.extract(r, x, y)
+    g = py_hough(r, x, y)
+    assert np.array_equal(o["grid"], g)
+    pk = py_peaks(g)
+    assert np.array_equal(o["peaks"], pk)
+    ln = py_lines(g, pk)
+    assert ln.shape == o["lines"].shape and np.allclose(ln, o["lines"], rtol=1e-14, atol=0)
+
+
+def test_feature_library_exports(pkg):
+    import ctypes, os, re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = re.sub(r"/\*.*?\*/", "", open(os.path.join(root, "include", "ekffeat_c.h")).read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(feat_[a-z_0-9]+)\s*\(", src)))
+    lib = ctypes.CDLL(pkg.ekfslam.LIB_PATH)
+    assert names == sorted(pkg.features.FEAT_ABI_SYMBOLS)
+    for n in names:
+        assert hasattr(lib, n), n
+    for f in ("feat_api.hip", "feat_kernels.hip", "feat_device.h"):
+        assert "oracle" not in open(os.path.join(root, "2d-ekf-slam_amd", "csrc", f)).read().lower()
+
+
+# ---- GPU: the batched kernel against the oracle --------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_batched_extraction_is_bit_exact(pkg, fc):
+    seeds = list(range(300))
+    scans = [pkg.scenarios.simulated_scan(s) for s in seeds]
+    scans[5] = (np.zeros(0), np.zeros(0), np.zeros(0))                                   # an empty scan
+    scans[6] = wall_scan([(3000.0, y) for y in np.linspace(-2000, 2000, 41)])            # ragged: 41 readings
+    scans[7] = tuple(np.concatenate([a, a]) for a in pkg.scenarios.simulated_scan(7))   # 362 readings: votes up to 2 x 181 wrap past 255
+    fx = pkg.FeatureExtractor(len(scans), max_points=384, max_corners=32, keep_intermediates=True)
+    corners, nc = fx.extract(scans)
+    n_with = 0
+    for s, (r, x, y) in enumerate(scans):
+        o = fc.extract(r, x, y, max_corners=32)
+        im = fx.intermediates(s)
+        assert im["dropped"] == 0
+        assert np.array_equal(im["grid"], o["grid"]), "votes of scan %d" % s
+        assert np.array_equal(im["peaks"], o["peaks"]), "peaks of scan %d" % s
+        assert im["lines"].shape == o["lines"].shape and np.array_equal(im["lines"], o["lines"]), "lines of scan %d" % s
+        assert im["segs"].shape == o["segs"].shape, "segment count of scan %d" % s
+        assert np.array_equal(im["segs"][:, 6], o["segs"][:, 6])
+        assert np.allclose(im["segs"], o["segs"], rtol=1e-9, atol=1e-9)
+        assert nc[s] == o["n_corners"], "corner count of scan %d" % s
+        assert np.allclose(corners[s], o["corners"], rtol=1e-9, atol=1e-6)
+        n_with += nc[s] > 0
+    assert n_with >= 40          # the simulated rooms do produce corners
+    assert fx.intermediates(7)["grid"].max() <= 255
+    fx.close()
+
+
+@pytest.mark.gpu
+def test_extraction_throughput_and_determinism(pkg, fc):
+    scans = [pkg.scenarios.simulated_scan(1000 + s) for s in range(64)] * 64   # 4096 scans
+    fx = pkg.FeatureExtractor(len(scans), max_points=181, max_corners=16)
+    c1, n1 = fx.extract(scans)
+    ms = fx.kernel_ms()
+    c2, n2 = fx.extract(scans)
+    assert np.array_equal(n1, n2) and all(np.array_equal(a, b) for a, b in zip(c1, c2))
+    assert all(np.array_equal(c1[i], c1[i + 64]) for i in range(64))           # same scan, same answer, wherever it ran
+    print("feature extraction: %d scans in %.2f ms on the device = %.0f scans/s" % (len(scans), ms, len(scans) / ms * 1e3))
+    fx.close()
