@@ -519,6 +519,39 @@ extern "C" size_t ekf_device_bytes(ekf_handle h) { return h ? h->device_bytes : 
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// Low-latency waits: a blocking hipStreamSynchronize / hipEventSynchronize costs 20-50 us of wake-up latency, which is a
+// sizeable part of a run of a few hundred microseconds.  The host polls the stream / event for up to two milliseconds
+// (about a microsecond per query) and only then blocks.
+static hipError_t stream_wait(hipStream_t s) {
+    timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (long spin = 0;; spin++) {
+        hipError_t e = hipStreamQuery(s);
+        if (e != hipErrorNotReady) return e;
+        if ((spin & 63) == 63) {
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            if ((t1.tv_sec - t0.tv_sec) * 1000000000L + (t1.tv_nsec - t0.tv_nsec) > 2000000L) break;
+        }
+        __builtin_ia32_pause();
+    }
+    return hipStreamSynchronize(s);
+}
+
+static hipError_t event_wait(hipEvent_t ev) {
+    timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (long spin = 0;; spin++) {
+        hipError_t e = hipEventQuery(ev);
+        if (e != hipErrorNotReady) return e;
+        if ((spin & 63) == 63) {
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            if ((t1.tv_sec - t0.tv_sec) * 1000000000L + (t1.tv_nsec - t0.tv_nsec) > 2000000L) break;
+        }
+        __builtin_ia32_pause();
+    }
+    return hipEventSynchronize(ev);
+}
+
 static int check_launch() {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
@@ -905,8 +938,8 @@ static int sticky_status(ekf_batch *h, bool include_capacity) {
 extern "C" int ekf_sync(ekf_handle h) {
     if (!h) return set_error(EKF_ERR_BAD_ARG, "null handle");
     HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(hipStreamSynchronize(h->s_chain));
-    if (h->overlap) HIP_TRY(hipStreamSynchronize(h->s_flush));
+    HIP_TRY(stream_wait(h->s_chain));
+    if (h->overlap) HIP_TRY(stream_wait(h->s_flush));
     return sticky_status(h, true);
 }
 
@@ -1008,7 +1041,7 @@ extern "C" int ekf_get_stats(ekf_handle h, ekf_stats *out) {
     if (!h || !out) return set_error(EKF_ERR_BAD_ARG, "null argument");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipMemcpyAsync(out, h->dv.stats, sizeof(ekf_stats) * h->dv.B, hipMemcpyDeviceToHost, h->s_chain));
-    HIP_TRY(hipStreamSynchronize(h->s_chain));
+    HIP_TRY(stream_wait(h->s_chain));
     return EKF_OK;
 }
 
@@ -1269,7 +1302,7 @@ extern "C" int ekf_timer_stop(ekf_handle h, double *ms_out) {
     HIP_TRY(hipSetDevice(h->device));
     if (h->overlap && h->prev_pending > 0) HIP_TRY(hipStreamWaitEvent(h->s_chain, h->ev_flush[h->ev_idx], 0));  // the pass in flight counts
     HIP_TRY(hipEventRecord(h->t1, h->s_chain));
-    HIP_TRY(hipEventSynchronize(h->t1));
+    HIP_TRY(event_wait(h->t1));
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, h->t0, h->t1));
     *ms_out = ms;

@@ -333,7 +333,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
 #ifdef EKF_CHAIN_STAMPS
     unsigned long long stamp_t;
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_t)::"memory");
-    long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long stamp_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // [8], [9]: the first worker's wait for its P_LL entries, its fold
 #endif
     // slot arrays addressed as base + set offset: a 4-way pointer select would become a scratch table
     const double *FAb = dv.FA + (size_t)b * 2 * dv.f_stride, *FBb = dv.FB + (size_t)b * 2 * dv.f_stride;
@@ -915,6 +915,12 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                             } else {
                                 load_old_inputs(lm, w_lo, p);
                             }
+#ifdef EKF_CHAIN_STAMPS
+                            if (prefetched) {
+                                asm volatile("" ::"v"(p[0][0]), "v"(p[0][1]), "v"(p[1][0]), "v"(p[1][1]));  // (forces the wait for the loads)
+                                STAMP(8);
+                            }
+#endif
                             // the unflushed slots are not in Bm yet: P[lm rows, lo cols] += (own cached rows) * M_slot
                             const double *own = own_rows + (lm - own_lo);
                             double pe[2][2] = {{0, 0}, {0, 0}}, po[2][2] = {{0, 0}, {0, 0}};  // even / odd slots: two dependency chains
@@ -953,6 +959,12 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                             }
                             for (int a = 0; a < 2; a++)
                                 for (int e = 0; e < 2; e++) p[a][e] += pe[a][e] + po[a][e];
+#ifdef EKF_CHAIN_STAMPS
+                            if (prefetched) {
+                                asm volatile("" ::"v"(p[0][0]), "v"(p[0][1]), "v"(p[1][0]), "v"(p[1][1]));
+                                STAMP(9);
+                            }
+#endif
                         }
                         apply_old(lm, st, p, slot, h, RS.Prr, L.w);
                     };
@@ -1126,7 +1138,7 @@ finish:  // (also the way out when a bounded wait ran out: the sticky status say
 
 #ifdef EKF_CHAIN_STAMPS
     if ((tid == 0 || tid == 64) && g == 0 && b == 0)
-        for (int i = 0; i < 8; i++) dv.dbg[(tid == 0 ? 0 : 16) + i] += stamp_acc[i];
+        for (int i = 0; i < (tid == 0 ? 8 : 10); i++) dv.dbg[(tid == 0 ? 0 : 16) + i] += stamp_acc[i];
 #endif
     if (tid == 0) {
         if (lead) {
