@@ -102,6 +102,7 @@ struct ChainLds {
     double xd;                           // the filter-wide pick of the exchange: distance, landmark, owning workgroup
     int xi, xsrc;
     int abort;  // a bounded wait ran out: every thread leaves the operation loop at the next barrier
+    signed char ap_tab[EKF_CHAIN_MAX_OPS];  // per operation: the Propagate that follows it behind truth samples only (look-ahead), -1 = none
     // rows of the matched landmark in every slot of the set being filled, [slot][side A/B][row e][k] (dead slots: zeros)
     // per virtual slot (the set a dense pass is folding first, then the open set): what kind of slot it is, the matched
     // landmark's cached rows loC (K rows of an Old slot, P_xL rows of a New one) and the 2x2 matrix M with
@@ -361,10 +362,14 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
     };
     // P[rows of lm, columns of lo] as stored in Bm[buf_read] (row index = the older landmark)
     auto load_old_inputs = [=](int lm, int lo, double p[2][2]) {
+        // the 2x2 block (rows 2lm, 2lm+1; columns 2lo, 2lo+1) never straddles a 16x16 chain: one offset, then +2 per column and
+        // +32 per row of the stored orientation (bm_offset: lane = 16 (row & 3) + column, two doubles per lane)
         const bool below = lm < lo;
-        const int ip = 2 * lm, jo = 2 * lo;
-        for (int a = 0; a < 2; a++)
-            for (int e = 0; e < 2; e++) p[a][e] = below ? Bmr[CK(bm_offset(T_, ip + a, jo + e), lim_B)] : Bmr[CK(bm_offset(T_, jo + e, ip + a), lim_B)];
+        const int ri = below ? 2 * lm : 2 * lo, ci = below ? 2 * lo : 2 * lm;  // stored as (row of the older landmark, column of the younger)
+        const double *q = Bmr + CK(bm_offset(T_, ri, ci), lim_B - 34);
+        const double v00 = q[0], v01 = q[2], v10 = q[32], v11 = q[34];  // stored (row + a, column + e)
+        p[0][0] = v00, p[1][1] = v11;
+        p[0][1] = below ? v01 : v10, p[1][0] = below ? v10 : v01;  // p[a][e] = P[2lm + a, 2lo + e]
     };
     // One landmark's two rows of a measurement's rank-2 slot: A rows (a00 a01 / a10 a11), B rows likewise.
     // Slots are stored in pairs (one k=4 MFMA operand): an even slot writes whole 32-byte rows and
@@ -518,6 +523,11 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
     for (int q = tid; q < n_prev + slot0; q += bd)
         L.sm[q] = dv.slot_meta[((size_t)b * 2 + (q < n_prev ? (set ^ 1) : set)) * dv.maxp + (q < n_prev ? q : q - n_prev)];
     __syncthreads();
+    if (tid < nops) {
+        int k = tid + 1;
+        while (k < nops && (int)recs[k * 8 + 7] == OP_TRUTH) k++;
+        L.ap_tab[tid] = (signed char)((k < nops && (int)recs[k * 8 + 7] == OP_PROP) ? k : -1);
+    }
     unsigned long long new_mask = 0;  // virtual slots that appended a landmark (wave-uniform, kept by every thread)
     for (int q = 0; q < n_prev + slot0; q++) new_mask |= (uni(L.sm[q].type) == SLOT_NEW ? 1ull : 0ull) << q;
     if (worker) {
@@ -828,12 +838,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
             }
 
             if (hdr == HDR_OLD) {
-                ahead_prop = -1;
-                {
-                    int k = op + 1;
-                    while (k < nops && uni((int)recs[k * 8 + 7]) == OP_TRUTH) k++;
-                    if (k < nops && uni((int)recs[k * 8 + 7]) == OP_PROP) ahead_prop = k;
-                }
+                ahead_prop = uni((int)L.ap_tab[op]);
                 // ---- Old, Update.cpp:181-189.  Workers: request the matched landmark's slot rows (into LDS) and their
                 // own P_LL entries and slot rows (into registers), barrier, fold, gain, store.  Control lane: robot block.
                 const int hi = own_hi < n_lm_before ? own_hi : n_lm_before;
