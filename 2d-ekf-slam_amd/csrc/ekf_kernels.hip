@@ -42,6 +42,11 @@ __device__ __forceinline__ bool cand_better(double da, int ia, double db, int ib
     return (da < db) | ((da == db) & (ia < ib));  // bitwise: no short-circuit branches in the reductions
 }
 
+// One 16-byte sc1 (agent-scope, write-through) store = two adjacent 8-byte granules of the cross-workgroup exchange (hipcc
+// has no builtin for it; an inline-asm store merely makes the compiler's own vmcnt waits conservative).
+typedef unsigned int uint4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st_sc1_b128(void *p, uint4_t v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory"); }
+
 // The robot block and the landmark counts.  Two copies live in LDS: operations read rs[cur], the control lane
 // writes the complete next state into rs[cur ^ 1] (k_chain, "the operation loop").
 struct RobotState {
@@ -749,10 +754,8 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                 // cannot publish exchange e+2 before every workgroup has read e.
                 const unsigned long long tag = (unsigned long long)(unsigned)(ebase + epoch + 1) << 32;
                 unsigned long long *rec = (unsigned long long *)(part + ((size_t)(epoch & 1) * dv.gmax + g) * EKF_REC_DOUBLES);
-                auto put = [=](unsigned long long *at, double v) {
-                    const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
-                    __hip_atomic_store(at, tag | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(at + 1, tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                auto put = [=](unsigned long long *at, double v) {  // a double = two granules, written by one 16-byte store (each half validates itself)
+                    st_sc1_b128(at, (uint4_t){(unsigned)__double2loint(v), (unsigned)(tag >> 32), (unsigned)__double2hiint(v), (unsigned)(tag >> 32)});
                 };
                 if (tid == 0) {
                     put(rec + 2 * EKF_REC_HEAD, gd);
