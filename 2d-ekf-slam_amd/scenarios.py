@@ -171,3 +171,49 @@ def simulated_scan(seed, n_rays=181, noise_mm=8.0, max_range_mm=12000.0):
     rngs = np.where(hit, np.maximum(rngs + noise_mm * rng.standard_normal(n_rays), 20.0), max_range_mm)
     rngs = np.floor(rngs)                              # ArSensorReading::getRange is an unsigned int of millimetres
     return rngs.astype(np.float64), rngs * np.cos(ang), rngs * np.sin(ang)
+
+
+def _cast_rays(segs, ang, max_range_mm):
+    """Distances along the rays (angles `ang`, from the origin) to the nearest of the wall segments (robot frame, mm)."""
+    rngs = np.full(ang.size, max_range_mm)
+    for a, b in segs:
+        d = b - a
+        ux, uy = np.cos(ang), np.sin(ang)
+        den = ux * d[1] - uy * d[0]
+        ok = np.abs(den) > 1e-12
+        den = np.where(ok, den, 1.0)
+        t = (a[0] * d[1] - a[1] * d[0]) / den
+        q = (a[0] * uy - a[1] * ux) / den
+        hit = ok & (t > 50.0) & (q >= 0.0) & (q <= 1.0) & (t < rngs)
+        rngs = np.where(hit, t, rngs)
+    return rngs
+
+
+def simulated_drive(seed=20260012, steps=120, dt=0.25, v=0.3, noise_mm=6.0, max_range_mm=12000.0):
+    """A robot driving a gentle arc through a 12 m x 9 m room with two partitions, one SICK sweep per loop iteration
+    (181 rays, -90..+90 degrees) cast from the TRUE pose, odometry with the reference's noise model
+    (kalmanfilter.cpp:28-37): the input of the whole slam.cpp loop (:130-204), perception included.
+    Returns a list of dict(dt, v_mm_s, rot_deg_s, scan=(range_mm, lx, ly), truth)."""
+    rng = np.random.default_rng(seed)
+    W, H = 6000.0, 4500.0
+    walls = [((-W, -H), (W, -H)), ((W, -H), (W, H)), ((W, H), (-W, H)), ((-W, H), (-W, -H)),
+             ((1500.0, -H), (1500.0, -1200.0)), ((-W, 1000.0), (-2500.0, 1000.0))]
+    walls = [(np.array(a), np.array(b)) for a, b in walls]
+    pose = np.array([-3500.0, -2500.0, 0.35])  # mm, mm, rad in the room frame; the filter's frame starts at this pose
+    w = 0.06
+    ang = np.deg2rad(np.linspace(-90.0, 90.0, 181))
+    out = []
+    for s in range(steps):
+        pose = pose + dt * np.array([1000.0 * v * math.cos(pose[2]), 1000.0 * v * math.sin(pose[2]), w])
+        c, sn = math.cos(pose[2]), math.sin(pose[2])
+        Rt = np.array([[c, sn], [-sn, c]])
+        segs = [(Rt @ (a - pose[:2]), Rt @ (b - pose[:2])) for a, b in walls]
+        r = _cast_rays(segs, ang, max_range_mm)
+        hit = r < max_range_mm
+        r = np.where(hit, np.maximum(r + noise_mm * rng.standard_normal(ang.size), 20.0), max_range_mm)
+        r = np.floor(r)
+        v_meas = v + SIGMA_V * v * rng.standard_normal()
+        w_meas = w + SIGMA_W * v * rng.standard_normal()
+        out.append(dict(dt=dt, v_mm_s=1000.0 * v_meas, rot_deg_s=w_meas * 180.0 / 3.141592654,
+                        scan=(r.astype(np.float64), r * np.cos(ang), r * np.sin(ang)), truth=pose.copy()))
+    return out

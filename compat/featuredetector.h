@@ -1,0 +1,129 @@
+// compat/featuredetector.h -- header-compatible replacement for the reference's features/featuredetector.h:27-66 on top of
+// the batched perception entry points of libekfslam_hip.so (include/ekffeat_c.h).  Same class name, same public members
+// (NO_COMPASS), same getFeatures(featVec, structCompass, curPhi) signature; slam.cpp:110,141 compile against it unchanged.
+//
+// What runs where: the copy of the readings under sick->lockDevice() and the new-scan check (featuredetector.cpp:18-34) stay
+// here; Hough votes, peak selection, line grouping, segment fitting and corner extraction (houghtransform.cpp:40-280,
+// featuredetector.cpp:74-289) run on the GPU for this one scan (feat_extract with n_scans = 1); the structural compass
+// (featuredetector.cpp:294-365) keeps COMPASS_OFFSET between scans and is computed here from the lines the GPU returns.
+#ifndef FEATUREDETECTOR_H
+#define FEATUREDETECTOR_H
+
+#include <cmath>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#if __has_include("Aria.h")
+#include "Aria.h"
+#else
+#include "standin/aria_standin.h"
+#endif
+
+#include "../include/ekffeat_c.h"
+#include "../include/ekfslam_c.h"
+
+typedef struct Feature {  // featuredetector.h:16-19
+    double x, y;
+    double dist, bear;
+} Feature;
+
+class FeatureDetector {
+public:
+    double NO_COMPASS = 100.0;  // featuredetector.h:25
+
+    explicit FeatureDetector(ArSick *sick, int device_id = 0) : sick(sick) {
+        check(feat_create(&fh, 1, EKF_FEAT_MAX_POINTS, kMaxCorners, device_id, /*keep_intermediates (the lines, for the compass)*/ 1));
+    }
+    ~FeatureDetector() { feat_destroy(fh); }
+    FeatureDetector(const FeatureDetector &) = delete;
+    FeatureDetector &operator=(const FeatureDetector &) = delete;
+
+    // featuredetector.cpp:16-70
+    int getFeatures(std::vector<Feature> *featVec, double *structCompass, double curPhi) {
+        sick->lockDevice();  // :18-22
+        std::vector<ArSensorReading> *r = sick->getRawReadingsAsVector();
+        std::vector<ArSensorReading> readings(*r);
+        ArTime curTime = sick->getLastReadingTime();
+        sick->unlockDevice();
+        if (readings.size() == 0) {  // :25-28
+            (*structCompass) = NO_COMPASS;
+            return 0;
+        }
+        if (curTime.isAt(Last_Time)) {  // :31-34: no new scan
+            (*structCompass) = NO_COMPASS;
+            return 0;
+        }
+        Last_Time = curTime;
+        int n = (int)readings.size();
+        if (n > EKF_FEAT_MAX_POINTS) n = EKF_FEAT_MAX_POINTS;
+        rng.resize(EKF_FEAT_MAX_POINTS), lx.resize(EKF_FEAT_MAX_POINTS), ly.resize(EKF_FEAT_MAX_POINTS);
+        for (int i = 0; i < n; i++) rng[i] = readings[i].getRange(), lx[i] = readings[i].getLocalX(), ly[i] = readings[i].getLocalY();
+        int nc = 0;
+        corners.resize(2 * kMaxCorners);
+        check(feat_extract(fh, 1, &n, rng.data(), lx.data(), ly.data(), &nc, corners.data()));  // :37-56
+        const int numf = nc < kMaxCorners ? nc : kMaxCorners;
+        for (int i = 0; i < numf; i++) {  // :275-280
+            Feature f;
+            f.x = corners[2 * i], f.y = corners[2 * i + 1];
+            f.dist = f.bear = 0.0;  // (never set by the reference either)
+            featVec->push_back(f);
+        }
+        int nl = 0;
+        lines.resize(3 * EKF_FEAT_NUM_PEAKS);
+        check(feat_get_intermediates(fh, 0, nullptr, nullptr, &nl, lines.data(), nullptr, nullptr, nullptr));
+        (*structCompass) = getStructCompass(nl, curPhi);  // :68
+        return numf;
+    }
+
+private:
+    static constexpr int kMaxCorners = 64;
+    double COMPASS_THRESH = 10 * 3.141592654 / 180.0;  // featuredetector.h:36
+    double COMPASS_OFFSET = 100.0;                      // featuredetector.h:59
+    ArTime Last_Time;
+    ArSick *sick;
+    feat_handle fh = nullptr;
+    std::vector<double> rng, lx, ly, corners, lines;
+
+    // featuredetector.cpp:294-365; lines[i] = (radius, theta, weight)
+    double getStructCompass(int nlines, double curPhi) {
+        struct Group {
+            double wsum_theta, wsum;  // sum of weight * (theta mod 90 deg), sum of weights
+        };
+        std::vector<Group> groups;
+        const double quarter = 1.570796327;
+        for (int i = 0; i < nlines; i++) {
+            const double th = lines[3 * i + 1], wt = lines[3 * i + 2];
+            const double th90 = th - quarter * floor(th / quarter);
+            bool joined = false;
+            for (Group &g : groups)  // every group within the threshold takes the line (the reference does not stop at the first)
+                if (fabs(th90 - g.wsum_theta / g.wsum) < COMPASS_THRESH) g.wsum_theta += th90 * wt, g.wsum += wt, joined = true;
+            if (!joined) groups.push_back(Group{th90 * wt, wt});
+        }
+        const Group *best = nullptr;
+        for (const Group &g : groups)
+            if (g.wsum > (best ? best->wsum : 0.0)) best = &g;
+        if (!best) return NO_COMPASS;
+        double cardinal = -(best->wsum_theta / best->wsum);
+        if (COMPASS_OFFSET == 100.0) COMPASS_OFFSET = cardinal;  // the first heading seen defines zero
+        cardinal -= COMPASS_OFFSET;
+        cardinal -= quarter * floor(cardinal / quarter);
+        curPhi -= 6.283185307 * floor(curPhi / 6.283185307);
+        // which quadrant is the robot in?  Candidates in the reference's order (0, 90, 180, 270 degrees, +360 and -90 for the
+        // roll-over); the first one with the smallest error wins, the two roll-over candidates standing for 0 and 270.
+        static const double shift[6] = {0.0, 1.570796327, 3.141592654, 4.71238898, 6.283185307, -1.570796327};
+        static const double heading[6] = {0.0, 1.570796327, 3.141592654, 4.71238898, 0.0, 4.71238898};
+        int k_best = 0;
+        double e_best = fabs(curPhi - cardinal - shift[0]);
+        for (int k = 1; k < 6; k++) {
+            const double e = fabs(curPhi - cardinal - shift[k]);
+            if (e < e_best) e_best = e, k_best = k;
+        }
+        return cardinal + heading[k_best];
+    }
+    static void check(int rc) {
+        if (rc < 0) throw std::runtime_error(std::string("libekfslam_hip: ") + ekf_last_error());
+    }
+};
+
+#endif  // FEATUREDETECTOR_H

@@ -17,7 +17,10 @@
 // Options (not in the reference): --state FILE starts from an injected state instead of x = 0_3, P = 0
 // (binary doubles: n, x[n], P[n*n]); --dump-state FILE writes the final state in the same format (through
 // ekf_get_state); --timing prints per-iteration wall-clock statistics of the filter calls (and leaves
-// knownfeaturesRun.txt empty: its O(N) text lines per iteration would otherwise be what is timed).
+// knownfeaturesRun.txt empty: its O(N) text lines per iteration would otherwise be what is timed); --detect takes the
+// corner features and the structural compass from the header-compatible FeatureDetector (compat/featuredetector.h, Hough
+// and corner extraction on the GPU) run on the `scan` lines, exactly as slam.cpp:138-147 does, instead of from the record
+// (every `scan` line is then a NEW sweep: featuredetector.cpp:31-34 skips iterations without one).
 #include <sys/stat.h>
 
 #include <algorithm>
@@ -31,6 +34,7 @@
 #include <string>
 #include <vector>
 
+#include "featuredetector.h"
 #include "kalmanfilter.h"
 
 struct Reading {
@@ -49,11 +53,12 @@ static bool read_state(const char *path, std::vector<double> &x, std::vector<dou
 int main(int argc, char **argv) {
     std::vector<std::string> pos;
     const char *state_in = nullptr, *state_out = nullptr;
-    bool timing = false;
+    bool timing = false, detect = false;
     for (int i = 1; i < argc; i++) {
         if (!std::strcmp(argv[i], "--state") && i + 1 < argc) state_in = argv[++i];
         else if (!std::strcmp(argv[i], "--dump-state") && i + 1 < argc) state_out = argv[++i];
         else if (!std::strcmp(argv[i], "--timing")) timing = true;
+        else if (!std::strcmp(argv[i], "--detect")) detect = true;
         else pos.push_back(argv[i]);
     }
     if (pos.size() < 2) {
@@ -68,15 +73,17 @@ int main(int argc, char **argv) {
     for (const char *d : {"/data", "/data/odom", "/data/features", "/data/scan", "/data/cov", "/maps"}) mkdir((dir + d).c_str(), 0777);
     std::ofstream odomFile(dir + "/data/odom/odomRun.txt"), scanFile(dir + "/data/scan/scanRun.txt"),
         featuresFile(dir + "/data/features/featuresRun.txt"), knownfeaturesFile(dir + "/data/features/knownfeaturesRun.txt"),
-        covFile(dir + "/data/cov/covRun.txt"), decisionFile(dir + "/data/decisionsRun.txt");  // slam.cpp:21-50
+        covFile(dir + "/data/cov/covRun.txt"), decisionFile(dir + "/data/decisionsRun.txt"), compassFile(dir + "/data/compassRun.txt");  // slam.cpp:21-50
     if (!odomFile || !scanFile || !featuresFile || !knownfeaturesFile || !covFile) return std::fprintf(stderr, "cannot create the data files under %s\n", dir.c_str()), 2;
-    for (std::ofstream *f : {&odomFile, &scanFile, &featuresFile, &knownfeaturesFile, &covFile, &decisionFile}) f->precision(17);
+    for (std::ofstream *f : {&odomFile, &scanFile, &featuresFile, &knownfeaturesFile, &covFile, &decisionFile, &compassFile}) f->precision(17);
     // --timing measures the filter calls: the O(N) text lines of knownfeaturesRun.txt (kalmanfilter.cpp:56-59) would be what
     // is timed at large N, so that file stays empty in a timing run (a failed stream ignores its insertions)
     if (timing) knownfeaturesFile.setstate(std::ios::badbit);
 
     ArRobot robot;
+    ArSick sick;
     try {
+        FeatureDetector *f = detect ? new FeatureDetector(&sick) : nullptr;  // slam.cpp:110
         KalmanFilter *ekf = new KalmanFilter(&robot, cap);  // slam.cpp:127
         if (state_in) {
             std::vector<double> x, P;
@@ -96,6 +103,11 @@ int main(int argc, char **argv) {
                 ls >> tag >> k;
                 readings.assign((size_t)std::max(k, 0), Reading{0, 0, 0});
                 for (auto &r : readings) ls >> r.range >> r.lx >> r.ly;
+                if (detect) {
+                    std::vector<ArSensorReading> sr;
+                    for (const Reading &r : readings) sr.push_back(ArSensorReading((unsigned int)r.range, r.lx, r.ly));
+                    sick.setScan(sr);
+                }
                 continue;
             }
             double dt, vel, rot;
@@ -105,10 +117,20 @@ int main(int argc, char **argv) {
             robot.setVelocities(vel, rot);
             auto t0 = std::chrono::steady_clock::now();
             ekf->doPropagation(dt, covFile, knownfeaturesFile);  // slam.cpp:136
-            if (comp != "nan") ekf->doUpdateCompass(std::stod(comp), 0.0005);  // :144-147
+            std::vector<Feature> fvec;  // :139-141
+            if (detect) {
+                double compass;
+                f->getFeatures(&fvec, &compass, ekf->Phi);
+                if (compass != f->NO_COMPASS) {  // :144-147
+                    compassFile << compass << "\n";
+                    ekf->doUpdateCompass(compass, 0.0005);
+                }
+                n = (int)fvec.size();
+            } else if (comp != "nan") ekf->doUpdateCompass(std::stod(comp), 0.0005);
             for (int i = 0; i < n; i++) {
                 double fxmm, fymm;
-                ls >> fxmm >> fymm;
+                if (detect) fxmm = fvec[i].x, fymm = fvec[i].y;
+                else ls >> fxmm >> fymm;
                 Eigen::MatrixXd z_chunk(2, 1), R(2, 2), R_chunk(2, 2), G(2, 2);
                 z_chunk(0, 0) = fxmm / 1000.0, z_chunk(1, 0) = fymm / 1000.0;  // :157
                 double fx = fxmm / 1000.0, fy = fymm / 1000.0;
@@ -164,6 +186,7 @@ int main(int argc, char **argv) {
             f.write((const char *)P.data(), P.size() * sizeof(double));
         }
         delete ekf;
+        delete f;
     } catch (const std::exception &e) {
         std::fprintf(stderr, "%s\n", e.what());
         return 1;

@@ -21,6 +21,8 @@ def lib():
         L.feat_oracle_extract.restype = ctypes.c_int
         L.feat_oracle_tables.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
         L.feat_oracle_tables.restype = None
+        L.feat_oracle_compass.argtypes = [ctypes.c_int, _dp, ctypes.c_double, _dp]
+        L.feat_oracle_compass.restype = ctypes.c_double
         _lib = L
     return _lib
 
@@ -46,3 +48,9 @@ def extract(rng_mm, lx, ly, max_corners=64):
                                    ctypes.byref(nl), p(lines), ctypes.byref(ns), p(segs))
     return dict(grid=grid.reshape(THETA_SIZE, RADIUS_SIZE), peaks=peaks, lines=lines[:min(nl.value, NUM_PEAKS)].copy(), segs=segs[:ns.value].copy(),
                 corners=corners[:min(nc, max_corners)].copy(), n_corners=nc)
+
+
+def compass(lines, cur_phi, offset):
+    """getStructCompass; `offset` is a 1-element float64 array holding COMPASS_OFFSET (100.0 at the start), updated in place."""
+    ln = np.ascontiguousarray(lines, dtype=np.float64).reshape(-1, 3)
+    return lib().feat_oracle_compass(ln.shape[0], ln.ctypes.data_as(_dp), float(cur_phi), offset.ctypes.data_as(_dp))

@@ -317,3 +317,49 @@ int feat_oracle_extract(int n, const double *range, const double *lx, const doub
     if (!segs_out) free(segs);
     return nc;
 }
+
+double feat_oracle_compass(int nlines, const double *lines, double curPhi, double *compass_offset) {
+    /* FeatureDetector::getStructCompass, featuredetector.cpp:294-365.  *compass_offset is the member COMPASS_OFFSET
+     * (featuredetector.h:59: 100.0 until the first compass value fixes it).  Returns NO_COMPASS = 100.0 when there is no line. */
+    const double COMPASS_THRESH = 10 * 3.141592654 / 180.0; /* featuredetector.h:36 */
+    double gtheta[FEAT_NUM_PEAKS], gweight[FEAT_NUM_PEAKS];
+    int ng = 0;
+    if (nlines > FEAT_NUM_PEAKS) nlines = FEAT_NUM_PEAKS;
+    for (int i = 0; i < nlines; i++) { /* :298-325 */
+        double curTheta = lines[i * 3 + 1] - 1.570796327 * floor(lines[i * 3 + 1] / 1.570796327);
+        double curWeight = lines[i * 3 + 2];
+        int merge = 0;
+        for (int j = 0; j < ng; j++) { /* no break: a line may join several groups (:305-315) */
+            double mergeTheta = gtheta[j] / gweight[j];
+            double thetaDiff = fabs(curTheta - mergeTheta);
+            if (thetaDiff < COMPASS_THRESH) {
+                gtheta[j] += curTheta * curWeight;
+                gweight[j] += curWeight;
+                merge = 1;
+            }
+        }
+        if (!merge) gtheta[ng] = curTheta * curWeight, gweight[ng] = curWeight, ng++;
+    }
+    double maxtheta = 0.0, maxweight = 0.0;
+    for (int i = 0; i < ng; i++) /* :328-335 */
+        if (gweight[i] > maxweight) maxtheta = gtheta[i], maxweight = gweight[i];
+    if (maxweight == 0.0) return 100.0; /* :338 */
+    double cardinal = -(maxtheta / maxweight); /* :341-344 */
+    if (*compass_offset == 100.0) *compass_offset = cardinal;
+    cardinal -= *compass_offset;
+    cardinal -= 1.570796327 * floor(cardinal / 1.570796327);
+    curPhi -= 6.283185307 * floor(curPhi / 6.283185307); /* :347 */
+    /* :350-365: six candidate headings (0, 90, 180, 270 degrees, and the roll-overs +360 and -90); the reference's cascade
+     * of <= comparisons takes candidate k when its error is <= the error of every LATER candidate, tried in order; the
+     * roll-over candidates return the headings of the candidates they alias (+360 -> cardinal, -90 -> cardinal + 270). */
+    static const double shift[6] = {0.0, 1.570796327, 3.141592654, 4.71238898, 6.283185307, -1.570796327};
+    static const double ret[6] = {0.0, 1.570796327, 3.141592654, 4.71238898, 0.0, 4.71238898};
+    double err[6];
+    for (int k = 0; k < 6; k++) err[k] = fabs(curPhi - cardinal - shift[k]);
+    for (int k = 0; k < 5; k++) {
+        int wins = 1;
+        for (int l = k + 1; l < 6; l++) wins &= (err[k] <= err[l]);
+        if (wins) return cardinal + ret[k];
+    }
+    return cardinal + ret[5];
+}

@@ -37,6 +37,9 @@ int feat_oracle_corners(int nseg, const double *segs, double *corners, int max_c
 int feat_oracle_extract(int n, const double *range, const double *lx, const double *ly, double *corners, int max_corners,
                         unsigned char *grid_out, int *peaks_out, int *n_lines_out, double *lines_out, int *n_segs_out, double *segs_out);
 
+/* FeatureDetector::getStructCompass, featuredetector.cpp:294-365; *compass_offset = the member COMPASS_OFFSET (start at 100.0) */
+double feat_oracle_compass(int nlines, const double *lines, double curPhi, double *compass_offset);
+
 #ifdef __cplusplus
 }
 #endif

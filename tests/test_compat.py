@@ -190,3 +190,69 @@ def test_immediate_mode_latency_is_bounded(replay_bin, pkg, tmp_path, N):
     median_py = float(np.median(per_step[16:]))
     print("immediate mode N=%d: %.0f us/step C++ (p90 %.0f), %.0f us/step Python" % (N, median_cpp, p90_cpp, median_py))
     assert median_cpp < bound_us and median_py < bound_us, (N, median_cpp, median_py)
+
+
+def test_compat_featuredetector_header_keeps_the_reference_interface():
+    """compat/featuredetector.h against perception/featuredetector.h:60-72: the class, NO_COMPASS, getFeatures' signature
+    and the Feature struct's fields; and it compiles against the stand-ins."""
+    src = open(os.path.join(ROOT, "compat", "featuredetector.h")).read()
+    for decl in ("class FeatureDetector", "struct Feature", "NO_COMPASS", "FeatureDetector(ArSick *",
+                 "int getFeatures(std::vector<Feature> *featVec, double *structCompass, double curPhi)"):
+        assert decl in src, decl
+    out = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "compat", "standin"),
+                          "-x", "c++", os.path.join(ROOT, "compat", "featuredetector.h")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+
+
+@pytest.mark.gpu
+def test_replay_detect_runs_perception_and_filter_end_to_end_like_the_oracle(replay_bin, pkg, oc, tmp_path):
+    """The whole slam.cpp:130-204 loop with perception in it: every iteration a new sweep -> FeatureDetector::getFeatures
+    (compat/featuredetector.h -> feat_extract on the GPU) -> doUpdateCompass when a wall gives a heading
+    (slam.cpp:144-147) -> one doUpdate per corner (:152-170).  The oracle side runs the SAME loop with the CPU restatement
+    of the detector (oracle/features_oracle.c) feeding the CPU restatement of the filter (oracle/ekf_oracle.c): the
+    compass values, every gate decision, the trajectory and the final x, P must agree, and the filter must end close to
+    the simulated truth."""
+    from helpers import assert_state_close
+    from oracle import features_c as fc
+    drive = pkg.scenarios.simulated_drive(steps=120)
+    rec = tmp_path / "rec.txt"
+    with open(rec, "w") as f:
+        for it in drive:
+            r, lx, ly = it["scan"]
+            f.write("scan %d %s\n" % (r.size, " ".join("%r %r %r" % (float(a), float(b), float(c)) for a, b, c in zip(r, lx, ly))))
+            f.write("%r %r %r nan 0\n" % (float(it["dt"]), float(it["v_mm_s"]), float(it["rot_deg_s"])))
+    dump = tmp_path / "final.bin"
+    out = subprocess.run([replay_bin, str(rec), str(tmp_path), "64", "--detect", "--dump-state", str(dump)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+
+    x, P = np.zeros(3), np.zeros((3, 3))
+    offset = np.array([100.0])  # featuredetector.h:71: COMPASS_OFFSET starts at NO_COMPASS
+    comps, decs, odom = [], [], []
+    for it in drive:
+        v, w = it["v_mm_s"] / 1000.0, it["rot_deg_s"] * 3.141592654 / 180.0
+        x, P = oc.propagate(x, P, v, w, oc.make_Q(v), it["dt"])
+        o = fc.extract(*it["scan"], max_corners=64)
+        cp = fc.compass(o["lines"], x[2], offset)       # featuredetector.cpp:61 with curPhi = ekf->Phi after Propagate
+        if cp != 100.0:
+            comps.append(cp)
+            x, P = oc.compass(x, P, cp, 0.0005)
+        for cx, cy in o["corners"]:
+            z, R = oc.make_measurement(cx, cy)
+            x, P, d, m, mh = oc.update(x, P, z.reshape(2, 1), R)
+            decs.append((d[0], m[0], mh[0]))
+        odom.append((x[0], x[1]))
+    tol = dict(rtol=1e-6, atol=1e-9)
+    assert len(comps) > 100 and np.allclose(np.loadtxt(str(tmp_path / "data/compassRun.txt")), comps, **tol)
+    dd = np.loadtxt(str(tmp_path / "data/decisionsRun.txt"), ndmin=2)
+    assert len(decs) > 80 and [(int(a), int(b)) for a, b in dd[:, :2]] == [(a, b) for a, b, _ in decs]
+    assert np.allclose(dd[:, 2], [d[2] for d in decs], **tol)
+    assert {oc.NEW, oc.OLD} <= {d[0] for d in decs}
+    assert np.allclose(np.loadtxt(str(tmp_path / "data/odom/odomRun.txt"), ndmin=2), np.array(odom), **tol)
+    xg, Pg = read_state(str(dump))
+    assert_state_close(xg, Pg, x, P, "replay --detect final state")
+    # and the estimate is right: the truth, expressed in the frame the filter started in
+    p0 = np.array([-3500.0, -2500.0, 0.35])
+    d = (drive[-1]["truth"][:2] - p0[:2]) / 1000.0
+    c, s = np.cos(p0[2]), np.sin(p0[2])
+    truth = np.array([c * d[0] + s * d[1], -s * d[0] + c * d[1], drive[-1]["truth"][2] - p0[2]])
+    assert np.all(np.abs(xg[:3] - truth) < [0.1, 0.1, 0.02]), (xg[:3], truth)

@@ -181,6 +181,53 @@ def test_oracle_against_independent_restatement(pkg, fc, seed):
     assert ln.shape == o["lines"].shape and np.allclose(ln, o["lines"], rtol=1e-14, atol=0)
 
 
+def load_feat_golden():
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "feat_golden.npz"))
+    out = []
+    for i in range(int(g["n_scans"])):
+        d = {k: g["scan%d_%s" % (i, k)] for k in ("in", "peaks", "lines", "segs", "corners", "votes")}
+        if "scan%d_grid_idx" % i in g:
+            grid = np.zeros(T * RSZ, dtype=np.uint8)
+            grid[g["scan%d_grid_idx" % i]] = g["scan%d_grid_val" % i]
+            d["grid"] = grid.reshape(T, RSZ)
+        out.append(d)
+    return out
+
+
+def test_oracle_reproduces_the_committed_golden_vectors(fc):
+    """tests/golden/feat_golden.npz (generator: make_feat_golden.py): nine simulated sweeps, one wall, one corner, one wall of 300
+    readings whose cell wraps past 255."""
+    gold = load_feat_golden()
+    assert len(gold) == 12
+    for i, d in enumerate(gold):
+        o = fc.extract(*d["in"], max_corners=64)
+        assert np.array_equal(o["peaks"], d["peaks"]) and np.array_equal(o["lines"], d["lines"]), i
+        assert np.array_equal(o["segs"], d["segs"]) and np.array_equal(o["corners"], d["corners"]), i
+        assert (int(o["grid"].sum()), int(o["grid"].max())) == tuple(int(v) for v in d["votes"])
+        if "grid" in d:
+            assert np.array_equal(o["grid"], d["grid"])
+    assert sum(len(d["corners"]) for d in gold) >= 3
+    assert gold[-1]["grid"][0, 1100] == 300 - 256  # 300 readings on the wall x = 3000: the unsigned char wrapped (houghtransform.cpp:252)
+
+
+def test_structural_compass_known_answers(fc):
+    """getStructCompass (featuredetector.cpp:294-365) by hand: walls at Hough angles 0.5 and 0.5 + 90 degrees fold onto one
+    group (theta mod 90 degrees); the first call fixes COMPASS_OFFSET so the heading reads 0; after the robot turns +0.1 rad
+    the walls appear at 0.4, the heading mod 90 degrees is 0.1, and the quadrant comes from the filter's own Phi."""
+    q = 1.570796327
+    off = np.array([100.0])
+    assert fc.compass(np.zeros((0, 3)), 0.0, off) == 100.0 and off[0] == 100.0           # no line: NO_COMPASS, offset untouched
+    first = fc.compass([(1000.0, 0.5, 10.0), (2000.0, 0.5 + q, 5.0)], 0.1, off)
+    assert abs(off[0] + 0.5) < 1e-12 and abs(first) < 1e-12
+    assert abs(fc.compass([(1000.0, 0.4, 10.0), (2000.0, 0.4 + q, 5.0)], 0.12, off) - 0.1) < 1e-9
+    assert abs(fc.compass([(1000.0, 0.4, 10.0)], 1.7, off) - (0.1 + q)) < 1e-9            # same walls, Phi in the second quadrant
+    assert abs(fc.compass([(1000.0, 0.4, 10.0)], 3.2, off) - (0.1 + 3.141592654)) < 1e-9
+    assert abs(fc.compass([(1000.0, 0.4, 10.0)], -1.5, off) - (0.1 + 4.71238898)) < 1e-9  # Phi = -1.5 = 4.78 mod 360 degrees
+    # the heavier group wins: a 12-weight wall direction 30 degrees off the 10-weight one
+    assert abs(fc.compass([(1000.0, 0.4, 10.0), (500.0, 0.4 - 0.5236, 12.0)], 0.6, off) - (0.1 + 0.5236)) < 1e-9
+
+
 def test_feature_library_exports(pkg):
     import ctypes, os, re
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -201,7 +248,7 @@ def test_batched_extraction_is_bit_exact(pkg, fc):
     scans = [pkg.scenarios.simulated_scan(s) for s in seeds]
     scans[5] = (np.zeros(0), np.zeros(0), np.zeros(0))                                   # an empty scan
     scans[6] = wall_scan([(3000.0, y) for y in np.linspace(-2000, 2000, 41)])            # ragged: 41 readings
-    scans[7] = tuple(np.concatenate([a, a]) for a in pkg.scenarios.simulated_scan(7))   # 362 readings: votes up to 2 x 181 wrap past 255
+    scans[7] = wall_scan([(3000.0, y) for y in np.linspace(-2500, 2500, 300)])           # 300 readings on one wall: its cell wraps past 255
     fx = pkg.FeatureExtractor(len(scans), max_points=384, max_corners=32, keep_intermediates=True)
     corners, nc = fx.extract(scans)
     n_with = 0
@@ -219,7 +266,7 @@ def test_batched_extraction_is_bit_exact(pkg, fc):
         assert np.allclose(corners[s], o["corners"], rtol=1e-9, atol=1e-6)
         n_with += nc[s] > 0
     assert n_with >= 40          # the simulated rooms do produce corners
-    assert fx.intermediates(7)["grid"].max() <= 255
+    assert fx.intermediates(7)["grid"][0, 1100] == 300 - 256
     fx.close()
 
 
@@ -233,4 +280,22 @@ def test_extraction_throughput_and_determinism(pkg, fc):
     assert np.array_equal(n1, n2) and all(np.array_equal(a, b) for a, b in zip(c1, c2))
     assert all(np.array_equal(c1[i], c1[i + 64]) for i in range(64))           # same scan, same answer, wherever it ran
     print("feature extraction: %d scans in %.2f ms on the device = %.0f scans/s" % (len(scans), ms, len(scans) / ms * 1e3))
+    fx.close()
+
+
+@pytest.mark.gpu
+def test_kernel_reproduces_the_committed_golden_vectors(pkg):
+    gold = load_feat_golden()
+    fx = pkg.FeatureExtractor(len(gold), max_points=384, max_corners=64, keep_intermediates=True)
+    corners, nc = fx.extract([tuple(d["in"]) for d in gold])
+    for i, d in enumerate(gold):
+        im = fx.intermediates(i)
+        assert im["dropped"] == 0
+        assert np.array_equal(im["peaks"], d["peaks"]) and np.array_equal(im["lines"], d["lines"]), i
+        assert (int(im["grid"].astype(np.int64).sum()), int(im["grid"].max())) == tuple(int(v) for v in d["votes"])
+        if "grid" in d:
+            assert np.array_equal(im["grid"], d["grid"])
+        assert im["segs"].shape == d["segs"].shape and np.array_equal(im["segs"][:, 6], d["segs"][:, 6])
+        assert np.allclose(im["segs"], d["segs"], rtol=1e-9, atol=1e-9)
+        assert nc[i] == len(d["corners"]) and np.allclose(corners[i], d["corners"], rtol=1e-9, atol=1e-6)
     fx.close()
