@@ -58,6 +58,7 @@ struct ekf_batch {
     int need_pass;        // the pass the next chain launches have to wait for in-kernel, 0 = none
     bool inkernel_wait;   // chain kernels wait for their pass in-kernel (kernels of two streams run side by side), else by event
     long long chain_seq;  // chain launches so far; the kernel stores it into the host mirror when it is done
+    bool stats_in_mirror = false;  // mirror.stats is current (a chain launch ran since the last ekf_reset_stats)
     bool mirror_by_chain; // the newest writer of the host mirror is chain launch number chain_seq (else: some other kernel, synchronise)
     int flush_keep;       // pool key of s_flush: CUs kept free for the chain, -1 = unmasked
     int chain_wgs;        // k_chain workgroups per filter
@@ -277,6 +278,13 @@ static int create_impl(ekf_batch *h, int batch, int capacity_landmarks, int devi
     dv.gamma_max = h->params.gamma_max;
     dv.gamma_min = h->params.gamma_min;
     dv.cond_limit = h->params.cond_limit;
+    {
+        // cond >= L  <=>  q r >= kappa (q^2 + r^2); kappa = 1/2 - 1/(L^2 + 1) (-> 1/2 for L = inf: only q = r is skipped).
+        // L <= 1: every finite S is skipped (cond >= 1 always): kappa = 0.  NaN stays NaN: nothing is skipped.
+        const long double L = h->params.cond_limit;
+        long double kappa = L <= 1.0L ? 0.0L : 0.5L - 1.0L / (L * L + 1.0L);
+        dv.cond_k2 = (double)(kappa * kappa);
+    }
     // k_chain geometry.  About one landmark per worker thread, at most 32 workgroups per filter, and few
     // enough workgroups in total (<= 256) that all of them are resident at once: the cross-workgroup
     // barrier needs every workgroup of a filter running.  Every workgroup keeps its landmarks' rows of every
@@ -292,7 +300,7 @@ static int create_impl(ekf_batch *h, int batch, int capacity_landmarks, int devi
     if (want_overlap < 0) {
         int g_max = batch >= 256 ? 1 : (EKF_CHAIN_MAX_WGS < 256 / batch ? EKF_CHAIN_MAX_WGS : 256 / batch);
         if (g_max < 1) g_max = 1;
-        long lpw_min = (capacity_landmarks + g_max - 1) / g_max;
+        long lpw_min = ((capacity_landmarks + g_max - 1) / g_max + 63) / 64 * 64;  // (the LDS cache is laid out in chunks of 64 landmarks)
         want_overlap = (lpw_min * maxp * 2 * 32 <= lds_budget) ? 1 : 0;
         // ... and when a dense pass is long enough to be worth hiding (P_LL of the whole batch >= 128 MB, a pass of
         // about 45 us): below that the chain kernels dominate and the second window's bookkeeping only costs
@@ -303,19 +311,27 @@ static int create_impl(ekf_batch *h, int batch, int capacity_landmarks, int devi
     h->params.overlap = h->overlap ? 1 : 0;
     const int sets_in_lds = h->overlap ? 2 : 1;  // overlap: the set being folded by the dense pass in flight is still needed
     int G = (capacity_landmarks + max_workers - 1) / max_workers;
-    int G_lds = (int)(((long)capacity_landmarks * maxp * sets_in_lds * 32 + lds_budget - 1) / lds_budget);
+    int G_lds = (int)((((long)capacity_landmarks + 63) / 64 * 64 * maxp * sets_in_lds * 32 + lds_budget - 1) / lds_budget);
     if (G_lds > G) G = G_lds;
     if (G > EKF_CHAIN_MAX_WGS) G = EKF_CHAIN_MAX_WGS;
     if (G * batch > 256) G = 256 / batch;  // (batches of more than 256 filters: one workgroup per filter, several launches)
     if (G < 1) G = 1;
+    // the cache holds whole chunks of 64 landmarks per workgroup: a few more workgroups can save a whole chunk each
+    // (N = 4096, window 16, two sets: 28 workgroups of 147 landmarks would need 3 chunks, 32 of 128 need 2)
+    {
+        auto lds_need = [&](int g) { return ((long)(capacity_landmarks + g - 1) / g + 63) / 64 * 64 * maxp * sets_in_lds * 32; };
+        const int g_cap = batch >= 256 ? 1 : (EKF_CHAIN_MAX_WGS < 256 / batch ? EKF_CHAIN_MAX_WGS : 256 / batch);
+        while (G < g_cap && lds_need(G) > lds_budget) G++;
+    }
     if (getenv("EKF_CHAIN_WGS")) G = atoi(getenv("EKF_CHAIN_WGS")) > 0 ? atoi(getenv("EKF_CHAIN_WGS")) : G;
     if (G > EKF_CHAIN_MAX_WGS) G = EKF_CHAIN_MAX_WGS;
     h->chain_wgs = G;
     h->chain_filters = batch * G <= 256 ? batch : 256 / G;  // every workgroup of a launch resident at once
     dv.gmax = G;
     dv.lpw = (capacity_landmarks + G - 1) / G;
-    if ((long)dv.lpw * maxp * sets_in_lds * 32 > lds_budget) {
-        maxp = (int)(lds_budget / ((long)dv.lpw * sets_in_lds * 32));
+    const long lpw64 = ((long)dv.lpw + 63) / 64 * 64;  // the own-row cache holds whole chunks of 64 landmarks
+    if (lpw64 * maxp * sets_in_lds * 32 > lds_budget) {
+        maxp = (int)(lds_budget / (lpw64 * sets_in_lds * 32));
         if (maxp > 1) maxp &= ~1;  // whole slot pairs
     }
     if (maxp < 1) return set_error(EKF_ERR_BAD_ARG, "capacity too large for this batch size (one window slot does not fit LDS)");
@@ -323,7 +339,8 @@ static int create_impl(ekf_batch *h, int batch, int capacity_landmarks, int devi
     dv.maxp = maxp;
     dv.maxpairs = (dv.maxp + 1) / 2;
     dv.f_stride = (size_t)(dv.maxpairs + 1) * dv.rows * 4;
-    h->chain_lds = (size_t)dv.lpw * maxp * sets_in_lds * 32;
+    dv.vs_cap = maxp * sets_in_lds;
+    h->chain_lds = (size_t)lpw64 * maxp * sets_in_lds * 32;
     HIP_TRY(hipFuncSetAttribute((const void *)k_chain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_budget));  // one setting for every handle
     int workers = (dv.lpw + 63) / 64 * 64;
     if (workers > max_workers) workers = max_workers;
@@ -610,13 +627,20 @@ static const int *tile_map_for(ekf_batch *h, int nT) {
 //    k+1 read Bm[fin] and fold set k themselves (n_prev).  Pass k starts after the chain kernels of window k
 //    (ev_chain) and, by stream order, after pass k-1 whose output it reads; the chain kernels of window k+1
 //    start after pass k-1 (they read its output and overwrite the slot rows it read).
-static int close_set(ekf_batch *h) {
+static int close_set(ekf_batch *h, bool terminal = false) {
     if (h->pending == 0) return EKF_OK;
     int nT_hi = (2 * h->n_lm_hi + 63) / 64;
     const int fin = (h->overlap && h->prev_pending > 0) ? h->buf_in ^ 1 : h->buf_in;
-    const int fout = h->overlap ? fin ^ 1 : fin;
-    hipStream_t sf = h->s_flush;
-    if (h->overlap) {
+    // terminal: the caller asked for everything to be folded (ekf_flush, settle), so no chain kernel will run beside this
+    // pass.  It then goes out on the chain's own stream (no cross-stream event hop: ~16 us, no k_mark: ~9 us), on all CUs,
+    // and in place (the faster form when nothing else uses the memory system); the pipeline restarts empty afterwards.
+    terminal = terminal && h->overlap;
+    const int fout = (h->overlap && !terminal) ? fin ^ 1 : fin;
+    hipStream_t sf = terminal ? h->s_chain : h->s_flush;
+    if (terminal) {
+        if (h->prev_pending > 0) HIP_TRY(hipStreamWaitEvent(h->s_chain, h->ev_flush[h->ev_idx], 0));  // pass k-1 wrote Bm[fin]
+        h->chain_signalled = false;
+    } else if (h->overlap) {
         if (!h->chain_signalled) HIP_TRY(hipEventRecord(h->ev_chain, h->s_chain));
         h->chain_signalled = false;
         HIP_TRY(hipStreamWaitEvent(sf, h->ev_chain, 0));
@@ -625,7 +649,7 @@ static int close_set(ekf_batch *h) {
         if (nT_hi < 1) nT_hi = 1;
         int total = nT_hi * (nT_hi + 1) / 2;
         hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (h->overlap) e1 = h->ev_flush[h->ev_idx ^ 1];  // pass k's completion, signalled by its own dispatch packet
+        if (h->overlap && !terminal) e1 = h->ev_flush[h->ev_idx ^ 1];  // pass k's completion, signalled by its own dispatch packet
         if (h->prof_flush) {
             while (h->prof_pool.size() < h->prof_used + 2) {
                 hipEvent_t e;
@@ -649,7 +673,11 @@ static int close_set(ekf_batch *h) {
                                   h->dv.B == 1 ? tile_map_for(h, nT_hi) : (const int *)nullptr, 0, rev);
         }
     }
-    if (h->overlap) {
+    if (terminal) {
+        h->need_pass = 0;
+        h->buf_in = fin;
+        h->prev_pending = 0;
+    } else if (h->overlap) {
         // the chain kernels of the next window depend on pass k-1 (they read its output and overwrite the slot rows it
         // read): they wait for its number in dv.pass_flag themselves
         // ... or, where kernels of two streams do not run side by side, the stream waits for the pass's event
@@ -673,7 +701,7 @@ static int close_set(ekf_batch *h) {
 
 // Everything folded into Bm[buf_in], streams idle.
 static int settle(ekf_batch *h) {
-    int rc = close_set(h);
+    int rc = close_set(h, true);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(h->s_chain));
     if (h->overlap) {
@@ -688,8 +716,14 @@ static int settle(ekf_batch *h) {
 
 // Launch k_chain over ops [k0, k0 + nops) of `in`, cutting at slot-set boundaries.
 // consumes[i] != 0 when op i takes a slot (measurement, masked measurement, compass).
-static int launch_ops(ekf_batch *h, const double *in, const int *cursor, int k0, const unsigned char *consumes, int nops) {
+// defer_last_close: when the last launch of this call fills the set, leave the set closed-to-be: the next call closes it
+// (regular pass) or ekf_flush / a state read does (terminal pass, close_set).  Scripted runs use it; never while capturing.
+static int launch_ops(ekf_batch *h, const double *in, const int *cursor, int k0, const unsigned char *consumes, int nops, bool defer_last_close = false) {
     int i = 0;
+    if (h->pending == h->dv.maxp && nops > 0) {  // a set whose close the previous call deferred: more work follows, regular pass
+        int rc = close_set(h);
+        if (rc) return rc;
+    }
     while (i < nops) {
         int start = i, used = h->pending;
         while (i < nops && i - start < EKF_CHAIN_MAX_OPS) {
@@ -699,7 +733,7 @@ static int launch_ops(ekf_batch *h, const double *in, const int *cursor, int k0,
             }
             i++;
         }
-        if (i == start) {  // set already full (cannot happen: sets are closed as soon as they fill)
+        if (i == start) {  // set already full (cannot happen: full sets are closed above and below)
             int rc = close_set(h);
             if (rc) return rc;
             continue;
@@ -715,9 +749,10 @@ static int launch_ops(ekf_batch *h, const double *in, const int *cursor, int k0,
                                   h->prev_pending, h->chain_seq, h->need_pass, b0);
         }
         h->mirror_by_chain = true;
+        h->stats_in_mirror = true;
         h->chain_signalled = closes;
         h->pending = used;
-        if (used == h->dv.maxp) {
+        if (used == h->dv.maxp && !(defer_last_close && i == nops)) {
             int rc = close_set(h);
             if (rc) return rc;
         }
@@ -946,7 +981,13 @@ extern "C" int ekf_sync(ekf_handle h) {
 extern "C" int ekf_flush(ekf_handle h) {
     if (!h) return set_error(EKF_ERR_BAD_ARG, "null handle");
     HIP_TRY(hipSetDevice(h->device));
-    return close_set(h);
+    return close_set(h, true);
+}
+
+extern "C" int ekf_close_window(ekf_handle h) {
+    if (!h) return set_error(EKF_ERR_BAD_ARG, "null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    return close_set(h, false);
 }
 
 extern "C" int ekf_batch_get_pose(ekf_handle h, double *pose_out) {
@@ -1040,6 +1081,14 @@ extern "C" int ekf_get_decisions(ekf_handle h, int index, ekf_decision *out, int
 extern "C" int ekf_get_stats(ekf_handle h, ekf_stats *out) {
     if (!h || !out) return set_error(EKF_ERR_BAD_ARG, "null argument");
     HIP_TRY(hipSetDevice(h->device));
+    if (h->mirror_by_chain && h->stats_in_mirror && h->chain_seq > 0) {
+        // the newest chain launch copies every filter's counters into the host-mapped mirror: no device-to-host copy
+        // (a copy into pageable memory costs 40-100 us, a sizeable part of a short run)
+        int rc = refresh_bounds(h, false);
+        if (rc) return rc;
+        for (int b = 0; b < h->dv.B; b++) out[b] = h->mirror_h[b].stats;
+        return EKF_OK;
+    }
     HIP_TRY(hipMemcpyAsync(out, h->dv.stats, sizeof(ekf_stats) * h->dv.B, hipMemcpyDeviceToHost, h->s_chain));
     HIP_TRY(stream_wait(h->s_chain));
     return EKF_OK;
@@ -1049,6 +1098,7 @@ extern "C" int ekf_reset_stats(ekf_handle h) {
     if (!h) return set_error(EKF_ERR_BAD_ARG, "null handle");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipMemsetAsync(h->dv.stats, 0, sizeof(ekf_stats) * h->dv.B, h->s_chain));
+    h->stats_in_mirror = false;  // until the next chain launch writes the mirror
     return EKF_OK;
 }
 
@@ -1200,7 +1250,7 @@ static int enqueue_script_steps(ekf_batch *h, const int *cursor, int k_first, in
     std::vector<unsigned char> consumes((size_t)ns * ops, 0);
     for (int q = 0; q < ns; q++)
         for (int m = 0; m < M; m++) consumes[(size_t)q * ops + 1 + m] = 1;
-    return launch_ops(h, h->script_d, cursor, k_first, consumes.data(), ns * ops);
+    return launch_ops(h, h->script_d, cursor, k_first, consumes.data(), ns * ops, /*defer_last_close*/ cursor == nullptr && h->overlap);
 }
 
 static int graph_block_steps(const ekf_batch *h) {

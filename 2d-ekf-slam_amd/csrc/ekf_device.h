@@ -60,6 +60,7 @@ struct EkfMirror {
     int status;
     long long log_count;
     long long seq;  // number of the chain launch that wrote this mirror last (stored last, system scope): the host may spin on it
+    ekf_stats stats;  // the filter's counters as of that launch (ekf_get_stats without a device-to-host copy)
     ekf_decision last[EKF_MIRROR_DECISIONS];  // entry i of the log lives at last[i % 64]
 };
 
@@ -70,6 +71,7 @@ struct EkfDev {
     int T;     // 64x64 tiles per side of P_LL
     int maxp;  // slots (measurements) per set
     int maxpairs;  // (maxp + 1) / 2 slot pairs per set; pair maxpairs is all zeros
+    int vs_cap;    // virtual slots per 64-landmark chunk of k_chain's own-row cache in LDS: maxp (in place) or 2 * maxp (overlap)
     int logcap;
     int rows;  // 64*T: rows of one slot in FA / FB
     int lpw;   // landmarks owned by one k_chain workgroup
@@ -92,6 +94,7 @@ struct EkfDev {
     ekf_stats *stats;
     EkfMirror *mirror;  // [B], host-mapped
     double gamma_max, gamma_min, cond_limit;
+    double cond_k2;  // ((L^2 - 1) / (2 (L^2 + 1)))^2 for L = cond_limit: the sweep's condition test without sqrt / division
 };
 
 // Offset (doubles) of P_LL element (i', j') inside one filter's Bm.  Requires tile(i') <= tile(j');

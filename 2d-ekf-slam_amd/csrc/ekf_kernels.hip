@@ -265,7 +265,7 @@ __device__ __forceinline__ SweepConst sweep_const(double c, double s, double px,
 // one landmark of the association sweep, Update.cpp:103-148.  S (:122) is assembled from the per-
 // measurement constants above plus C^T P_xy,Li C, a_phi C and C^T P_LiLi C; same value as the
 // reference's four products up to rounding (about 50 multiply-adds instead of 140).
-__device__ __forceinline__ void sweep_one(int lm, const LmState &st, double z0, double z1, const SweepConst &k, double cond_limit,
+__device__ __forceinline__ void sweep_one(int lm, const LmState &st, double z0, double z1, const SweepConst &k, double cond_k2,
                                           SweepBest &best) {
     const double c = k.c, s = k.s;
     double dp0 = st.x0 - k.px, dp1 = st.x1 - k.py;
@@ -293,11 +293,14 @@ __device__ __forceinline__ void sweep_one(int lm, const LmState &st, double z0, 
     double S00 = (k.M0[0] - 2.0 * k.u0 * h0 + k.pff * h0 * h0) + 2.0 * x00 + q00 + k.R00;
     double S11 = (k.M0[2] - 2.0 * k.u1 * h1 + k.pff * h1 * h1) + 2.0 * x11 + q11 + k.R11;
     double S01 = (k.M0[1] - k.u0 * h1 - k.u1 * h0 + k.pff * h0 * h1) + (x01 + x10) + 0.5 * (q01 + q10) + 0.5 * (k.R01 + k.R10);
-    // condition number = sigma_max / sigma_min of the symmetric 2x2 (:127-128)
+    // condition number = sigma_max / sigma_min of the symmetric 2x2 (:127-128) = (q + r) / |q - r| with q = |e|,
+    // r = sqrt(f^2 + S01^2).  Only "cond >= limit" is needed (:131), and (q + r) >= L |q - r|  <=>  q r >= kappa (q^2 + r^2)
+    // with kappa = (L^2 - 1) / (2 (L^2 + 1))  <=>  q^2 r^2 >= kappa^2 (q^2 + r^2)^2: no square root and no division on
+    // the measurement's critical path (about 25 dependent fp64 operations of 13 ns each).  NaN compares false: not skipped,
+    // as in the reference; q = r (cond = inf) is skipped.
     double e = 0.5 * (S00 + S11), f = 0.5 * (S00 - S11);
-    double q = fabs(e), r = sqrt(f * f + S01 * S01);
-    double cond = (q + r) / fabs(q - r);
-    if (!(cond >= cond_limit)) {  // :131, NaN is not skipped
+    double q2 = e * e, r2 = f * f + S01 * S01, sum = q2 + r2;
+    if (!(q2 * r2 >= cond_k2 * (sum * sum))) {
         double det = S00 * S11 - S01 * S01;
         double d = (res0 * (S11 * res0 - S01 * res1) + res1 * (S00 * res1 - S01 * res0)) / det;  // :135-136
         if (best.d > d) {  // :140 (false for NaN); ascending lm, so ties keep the lower index
@@ -309,11 +312,64 @@ __device__ __forceinline__ void sweep_one(int lm, const LmState &st, double z0, 
     }
 }
 
+// ---- the fold of the unflushed slots, software-pipelined by hand ---------------------------------------------------------
+// p[a][e] += sum over the virtual slots of (own cached row a of the slot) . (column e of the slot's 2x2 matrix M).  Per slot a
+// thread reads its own four components (two ds_read_b128, conflict-free) and the slot's M (two ds_read_b128 broadcasts) and
+// does eight fp64 FMAs (8 clocks each per wave, 32 clocks until the result can be used: four accumulators in rotation).  Written
+// from C the compiler waits for each trip's reads before it multiplies (1.5 us for 24 slots); here the reads of slot s+2 are
+// in flight while slot s is multiplied: three register sets in rotation, LDS results return in order, so "s_waitcnt
+// lgkmcnt(8)" = "everything but the 8 newest reads has arrived" (scripts/micro/fold_lab.hip: 40 ns per slot against 27 ns of
+// FMA issue alone; the component-major layout with four ds_read_b64 and run-time strides: 50 ns).  One
+// asm statement from first read to last FMA: the register sets are hard registers named in the clobber list, because a value
+// the compiler believes defined (an asm output) may be copied before the read has landed.
+__device__ __forceinline__ unsigned lds_off(const void *p) { return (unsigned)(size_t)p; }  // low half of a flat LDS address = the LDS byte offset
+#define FOLD_ISSUE(o01, o23, ma, mb, so, mo)                                                                             \
+    "ds_read_b128 " o01 ", %[a0] offset:" #so "\n\tds_read_b128 " o23 ", %[a0] offset:" #so "+1024\n\t"                     \
+    "ds_read_b128 " ma ", %[am] offset:" #mo "\n\tds_read_b128 " mb ", %[am] offset:" #mo "+16\n\t"
+#define FOLD_FMA(o0, o1, o2, o3, m0, m1, m2, m3)                                                                            \
+    "v_fma_f64 %[p00], " o0 ", " m0 ", %[p00]\n\tv_fma_f64 %[p01], " o0 ", " m1 ", %[p01]\n\t"                             \
+    "v_fma_f64 %[p10], " o2 ", " m0 ", %[p10]\n\tv_fma_f64 %[p11], " o2 ", " m1 ", %[p11]\n\t"                             \
+    "v_fma_f64 %[p00], " o1 ", " m2 ", %[p00]\n\tv_fma_f64 %[p01], " o1 ", " m3 ", %[p01]\n\t"                             \
+    "v_fma_f64 %[p10], " o3 ", " m2 ", %[p10]\n\tv_fma_f64 %[p11], " o3 ", " m3 ", %[p11]\n\t"
+// register set X (A, B, C) always holds a slot = X mod 3: immediate offsets, both bases advance by three slots per rotation
+#define FOLD_IA(so, mo) FOLD_ISSUE("v[208:211]", "v[212:215]", "v[216:219]", "v[220:223]", so, mo)
+#define FOLD_IB(so, mo) FOLD_ISSUE("v[224:227]", "v[228:231]", "v[232:235]", "v[236:239]", so, mo)
+#define FOLD_IC(so, mo) FOLD_ISSUE("v[240:243]", "v[244:247]", "v[248:251]", "v[252:255]", so, mo)
+#define FOLD_FA FOLD_FMA("v[208:209]", "v[210:211]", "v[212:213]", "v[214:215]", "v[216:217]", "v[218:219]", "v[220:221]", "v[222:223]")
+#define FOLD_FB FOLD_FMA("v[224:225]", "v[226:227]", "v[228:229]", "v[230:231]", "v[232:233]", "v[234:235]", "v[236:237]", "v[238:239]")
+#define FOLD_FC FOLD_FMA("v[240:241]", "v[242:243]", "v[244:245]", "v[246:247]", "v[248:249]", "v[250:251]", "v[252:253]", "v[254:255]")
+#define FOLD_ADV "v_add_u32 %[a0], 6144, %[a0]\n\tv_add_u32 %[am], 96, %[am]\n\t"
+#define FOLD_W(n) "s_waitcnt lgkmcnt(" #n ")\n\t"
+// n = slots not multiplied yet (>= 1).  Loop invariant at Lfl: two slots in flight (current, next), n >= 3.
+#define FOLD_STEP(issue, fma, tail) issue FOLD_W(8) fma "s_sub_u32 %[n], %[n], 1\n\ts_cmp_gt_u32 %[n], 2\n\ts_cbranch_scc0 " tail "\n\t"
+#define FOLD_ASM                                                                                                            \
+    FOLD_IA(0, 0)                                                                                                           \
+    "s_cmp_gt_u32 %[n], 1\n\ts_cbranch_scc0 Lf1_%=\n\t"                                                                   \
+    FOLD_IB(2048, 32)                                                                                                       \
+    "s_cmp_gt_u32 %[n], 2\n\ts_cbranch_scc0 LfAB_%=\n"                                                                    \
+    "Lfl_%=:\n\t"                                                                                                          \
+    FOLD_STEP(FOLD_IC(4096, 64), FOLD_FA, "LfBC_%=")                                                                        \
+    FOLD_STEP(FOLD_IA(6144, 96), FOLD_FB, "LfCA_%=")                                                                        \
+    FOLD_STEP(FOLD_IB(8192, 128) FOLD_ADV, FOLD_FC, "LfAB_%=")                                                              \
+    "s_branch Lfl_%=\n"                                                                                                    \
+    "LfBC_%=:\n\t" FOLD_W(4) FOLD_FB FOLD_W(0) FOLD_FC "s_branch Lfe_%=\n"                                                \
+    "LfCA_%=:\n\t" FOLD_W(4) FOLD_FC FOLD_W(0) FOLD_FA "s_branch Lfe_%=\n"                                                \
+    "LfAB_%=:\n\t" FOLD_W(4) FOLD_FA FOLD_W(0) FOLD_FB "s_branch Lfe_%=\n"                                                \
+    "Lf1_%=:\n\t" FOLD_W(0) FOLD_FA                                                                                        \
+    "Lfe_%=:\n\t"
+#define FOLD_CLOBBERS                                                                                                       \
+    "scc", "memory", "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223", \
+        "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240",     \
+        "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255"
+
 __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, const double *in, const int *cursor, int k0,
                                                                 int nops, int slot0, int set, int buf_read, int n_prev, long long launch_seq, int need_pass, int b_off) {
     __shared__ ChainLds L;
     __shared__ double recs[EKF_CHAIN_MAX_OPS * 8];
-    extern __shared__ double own_rows[];  // [virtual slot][component 00 01 10 11][local landmark]: K rows (Old, compass), P_xL rows (New), zeros (dead)
+    // own-row cache, per chunk of 64 local landmarks: [virtual slot][plane: components 00 01 | 10 11][lane][2 doubles] -- K rows (Old,
+    // compass), P_xL rows (New), zeros (dead).  A wave reads a slot of its 64 landmarks as two conflict-free ds_read_b128 at
+    // fixed strides (slot 2048 B, plane 1024 B), whatever the number of landmarks per workgroup.
+    extern __shared__ __attribute__((aligned(16))) double own_rows[];
     const int g = blockIdx.x, G = gridDim.x;
     const int b = blockIdx.y + b_off;  // batches beyond 256 resident workgroups go out as several launches (b_off)
     const int tid = threadIdx.x;
@@ -345,6 +401,9 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
     const double *FAb = dv.FA + (size_t)b * 2 * dv.f_stride, *FBb = dv.FB + (size_t)b * 2 * dv.f_stride;
     const size_t off_c = (size_t)set * dv.f_stride;
     const int lpw_ = dv.lpw;
+    (void)lpw_;
+    const int vs_cap = dv.vs_cap;  // virtual slots the cache holds per chunk (one or two windows)
+    auto own_at = [=](int vs, int cmp, int ll) { return (((ll >> 6) * vs_cap + vs) * 2 + (cmp >> 1)) * 128 + (ll & 63) * 2 + (cmp & 1); };
     long long *const dv_dbg = dv.dbg;
     (void)dv_dbg;
     const long long lim_x = xs, lim_R = 3LL * xs, lim_D = 3LL * dv.dn, lim_B = (long long)dv.bm_stride, lim_F = 2LL * (long long)dv.f_stride;
@@ -382,8 +441,9 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
     auto write_slot = [=](int lm, int slot, double a00, double a01, double a10, double a11, double b00, double b01, double b10, double b11, bool cache_a) {
         const size_t wo = CK(off_c + pair_offset(rows_, 2 * lm, slot >> 1), lim_F - 7) - off_c;
         double *fa = FAc + wo, *fb = FBc + wo;
-        double *cr = own_rows + (size_t)(n_prev + slot) * 4 * lpw_ + (lm - own_lo);  // the fold needs one side only: K S K^T is symmetric
-        cr[0] = cache_a ? a00 : b00, cr[lpw_] = cache_a ? a01 : b01, cr[2 * lpw_] = cache_a ? a10 : b10, cr[3 * lpw_] = cache_a ? a11 : b11;
+        double *cr = own_rows + own_at(n_prev + slot, 0, lm - own_lo);  // the fold needs one side only: K S K^T is symmetric
+        *(double2_t *)cr = cache_a ? (double2_t){a00, a01} : (double2_t){b00, b01};
+        *(double2_t *)(cr + 128) = cache_a ? (double2_t){a10, a11} : (double2_t){b10, b11};
         if ((slot & 1) == 0) {
             *(double4_t *)fa = (double4_t){a00, a01, 0, 0};
             *(double4_t *)(fa + 4) = (double4_t){a10, a11, 0, 0};
@@ -480,7 +540,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
         st.dxx = L.newdd[0], st.dxy = L.newdd[1], st.dyy = L.newdd[2];
         lm_store(lm, st);
         for (int sl = 0; sl < n_prev + slot; sl++)  // the landmark did not exist in the earlier slots of the open windows
-            for (int cmp = 0; cmp < 4; cmp++) own_rows[((size_t)sl * 4 + cmp) * lpw_ + (lm - own_lo)] = 0.0;
+            for (int cmp = 0; cmp < 4; cmp++) own_rows[own_at(sl, cmp, lm - own_lo)] = 0.0;
         write_slot(lm, slot, 0, 0, 0, 0, 1, 0, 0, 1, true);  // (its own P_xL rows are zero: the 2x2 block lives in D)
     };
 
@@ -554,8 +614,8 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
 #pragma unroll
                 for (int j = 0; j < 8; j++)
                     if (v0 + j < nv0) {
-                        double *cr = own_rows + (size_t)(v0 + j) * 4 * lpw_ + (lm - own_lo);
-                        cr[0] = lo2[j].x, cr[lpw_] = lo2[j].y, cr[2 * lpw_] = hi2[j].x, cr[3 * lpw_] = hi2[j].y;
+                        double *cr = own_rows + own_at(v0 + j, 0, lm - own_lo);
+                        *(double2_t *)cr = lo2[j], *(double2_t *)(cr + 128) = hi2[j];
                     }
             }
     }
@@ -722,10 +782,10 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                 double Prr[9];
                 for (int i = 0; i < 9; i++) Prr[i] = RS.Prr[i];
                 const SweepConst kc = sweep_const(RS.c, RS.s, RS.pose[0], RS.pose[1], Prr, Rm);
-                if (lm0 < sweep_hi) sweep_one(lm0, r0, z0, z1, kc, dv.cond_limit, best);
+                if (lm0 < sweep_hi) sweep_one(lm0, r0, z0, z1, kc, dv.cond_k2, best);
                 for (int lm = lm0 + nw; lm < sweep_hi; lm += nw) {
                     LmState st = lm_load(lm);
-                    sweep_one(lm, st, z0, z1, kc, dv.cond_limit, best);
+                    sweep_one(lm, st, z0, z1, kc, dv.cond_k2, best);
                 }
             }
             // workgroup arg-min with first-index tie-break
@@ -764,8 +824,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                 if (gi != 0x7fffffff) {
                     if (gi == best.lm)  // the lane that owns the local winner
                         for (int i = 0; i < 16; i++) put(rec + 2 * i, best.w[i]);
-                    const double *wr = own_rows + (gi - own_lo);
-                    for (int q = tid; q < slot * 4; q += bd) put(rec + 2 * (16 + q), wr[(size_t)(n_prev * 4 + q) * lpw_]);  // the open set's cached rows (dead slots hold zeros)
+                    for (int q = tid; q < slot * 4; q += bd) put(rec + 2 * (16 + q), own_rows[own_at(n_prev + (q >> 2), q & 3, gi - own_lo)]);  // the open set's cached rows (dead slots hold zeros)
                 }
                 // The control wave polls the heads (lane l reads workgroup l's), picks, and hands the result to the workers
                 // through LDS and one workgroup barrier: a third of the polling loads of "every wave for itself", and the
@@ -893,7 +952,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                         if (w_lo == best.lm)
                             for (int i = 0; i < 16; i++) L.w[i] = best.w[i];
                         if (slot_thread)
-                            for (int j = 0; j < 4; j++) c4[j] = own_rows[((size_t)tid * 4 + j) * lpw_ + (w_lo - own_lo)];
+                            for (int j = 0; j < 4; j++) c4[j] = own_rows[own_at(tid, j, w_lo - own_lo)];
                     }
                     if (slot_thread) {
                         const SlotMeta m = L.sm[tid];
@@ -930,32 +989,14 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                             }
 #endif
                             // the unflushed slots are not in Bm yet: P[lm rows, lo cols] += (own cached rows) * M_slot
-                            const double *own = own_rows + (lm - own_lo);
-                            double pe[2][2] = {{0, 0}, {0, 0}}, po[2][2] = {{0, 0}, {0, 0}};  // even / odd slots: two dependency chains
-                            int sl = 0;
-                            for (; sl + 4 <= nvs; sl += 4) {  // four slots per trip: every LDS read requested before the first multiply
-                                double ow[4][4];
-                                double2_t ma[4], mb[4];
-#pragma unroll
-                                for (int j = 0; j < 4; j++) {
-                                    const double *o = own + (size_t)(sl + j) * 4 * lpw_, *q = L.loM + (sl + j) * 4;
-                                    ow[j][0] = o[0], ow[j][1] = o[lpw_], ow[j][2] = o[2 * lpw_], ow[j][3] = o[3 * lpw_];
-                                    ma[j] = *(const double2_t *)q, mb[j] = *(const double2_t *)(q + 2);
-                                }
-#pragma unroll
-                                for (int j = 0; j < 4; j++) {
-                                    double(*acc)[2] = (j & 1) ? po : pe;
-                                    acc[0][0] = fma(ow[j][1], mb[j].x, fma(ow[j][0], ma[j].x, acc[0][0]));
-                                    acc[0][1] = fma(ow[j][1], mb[j].y, fma(ow[j][0], ma[j].y, acc[0][1]));
-                                    acc[1][0] = fma(ow[j][3], mb[j].x, fma(ow[j][2], ma[j].x, acc[1][0]));
-                                    acc[1][1] = fma(ow[j][3], mb[j].y, fma(ow[j][2], ma[j].y, acc[1][1]));
-                                }
-                            }
-                            for (; sl < nvs; sl++) {
-                                const double *o = own + (size_t)sl * 4 * lpw_, *q = L.loM + sl * 4;
-                                const double o00 = o[0], o01 = o[lpw_], o10 = o[2 * lpw_], o11 = o[3 * lpw_];
-                                pe[0][0] += o00 * q[0] + o01 * q[2], pe[0][1] += o00 * q[1] + o01 * q[3];
-                                pe[1][0] += o10 * q[0] + o11 * q[2], pe[1][1] += o10 * q[1] + o11 * q[3];
+                            double pe[2][2] = {{0, 0}, {0, 0}};
+                            if (nvs > 0) {  // (wave-uniform)
+                                unsigned a0 = lds_off(own_rows + own_at(0, 0, lm - own_lo)), am = lds_off(L.loM);
+                                int n = nvs;
+                                asm volatile(FOLD_ASM
+                                             : [p00] "+v"(pe[0][0]), [p01] "+v"(pe[0][1]), [p10] "+v"(pe[1][0]), [p11] "+v"(pe[1][1]), [a0] "+v"(a0), [am] "+v"(am), [n] "+s"(n)
+                                             :
+                                             : FOLD_CLOBBERS);
                             }
                             // a landmark appended in one of these slots holds its column pair in the OTHER landmarks' rows
                             for (unsigned long long nm = new_mask; nm; nm &= nm - 1) {
@@ -966,7 +1007,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                                 }
                             }
                             for (int a = 0; a < 2; a++)
-                                for (int e = 0; e < 2; e++) p[a][e] += pe[a][e] + po[a][e];
+                                for (int e = 0; e < 2; e++) p[a][e] += pe[a][e];
 #ifdef EKF_CHAIN_STAMPS
                             if (prefetched) {
                                 asm volatile("" ::"v"(p[0][0]), "v"(p[0][1]), "v"(p[1][0]), "v"(p[1][1]));
@@ -1162,6 +1203,7 @@ finish:  // (also the way out when a bounded wait ran out: the sticky status say
             for (int i = 0; i < 3; i++) mr->pose[i] = R.pose[i];
             mr->n_lm = R.n_lm;
             dv.stats[b] = L.st;
+            mr->stats = L.st;
             dv.log_count[b] = L.log_count;
             for (int i = 0; i < L.n_dec; i++) mr->last[(L.log_count - L.n_dec + i) % EKF_MIRROR_DECISIONS] = L.dec_buf[i];
             mr->status = dv.status[b];

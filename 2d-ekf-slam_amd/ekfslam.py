@@ -20,7 +20,7 @@ ABI_SYMBOLS = [
     "ekf_capacity", "ekf_window", "ekf_overlap", "ekf_propagate", "ekf_propagate_q", "ekf_update", "ekf_update_compass", "ekf_get_pose",
     "ekf_num_landmarks", "ekf_get_robot_cov", "ekf_get_x", "ekf_batch_propagate", "ekf_batch_propagate_q", "ekf_batch_update",
     "ekf_batch_update_compass", "ekf_batch_get_pose", "ekf_batch_num_landmarks", "ekf_get_state", "ekf_set_state",
-    "ekf_broadcast_state", "ekf_script_load", "ekf_script_run", "ekf_sync", "ekf_flush", "ekf_timer_start",
+    "ekf_broadcast_state", "ekf_script_load", "ekf_script_run", "ekf_sync", "ekf_flush", "ekf_close_window", "ekf_timer_start",
     "ekf_timer_stop", "ekf_flush_profile", "ekf_flush_profile_read", "ekf_get_decisions", "ekf_get_stats",
     "ekf_reset_stats", "ekf_record_truth", "ekf_stream", "ekf_device_bytes",
 ]
@@ -94,6 +94,7 @@ def load():
     L.ekf_script_run.argtypes = [_H, ctypes.c_int, ctypes.c_int, ctypes.c_int]
     L.ekf_sync.argtypes = [_H]
     L.ekf_flush.argtypes = [_H]
+    L.ekf_close_window.argtypes = [_H]
     L.ekf_timer_start.argtypes = [_H]
     L.ekf_timer_stop.argtypes = [_H, _dp]
     L.ekf_flush_profile.argtypes = [_H, ctypes.c_int]
@@ -260,6 +261,9 @@ class FilterBatch:
 
     def flush(self):
         _chk(self.L.ekf_flush(self.h))
+
+    def close_window(self):
+        _chk(self.L.ekf_close_window(self.h))
 
     def timer_start(self):
         _chk(self.L.ekf_timer_start(self.h))

@@ -61,7 +61,14 @@ def make_filters(pkg, mc, workload, lo, hi, steps, M, dev_id, max_pending, log_e
 def timed_steps(f, mc, torch, dist, coll_device, W, K, graph):
     """W untimed warm-up steps, then exactly K steps bracketed by barrier + synchronize on both sides; the timed region
     ends with P_LL fully folded (ekf_flush) and with the one collective, the all-gather of per-filter NIS / NEES."""
+    # the warm-up goes through every call of the timed region once (first calls pay for lazy imports, page faults of the
+    # host-mapped buffers and event creation: ~130 us, a tenth of a 20-step run) and ends like it, with P_LL fully folded:
+    # the timed region then holds exactly K steps of work
+    f.timer_start()
     f.script_run(0, W, use_graph=graph)
+    f.flush()
+    f.timer_stop()
+    mc.gather_stats(mc.summarise(f.stats()), device=coll_device)
     f.sync()
     f.reset_stats()
     f.flush_profile_read()
@@ -72,13 +79,19 @@ def timed_steps(f, mc, torch, dist, coll_device, W, K, graph):
     f.timer_start()
     f.script_run(W, K, use_graph=graph)
     f.flush()                # P_LL fully folded inside the timed region, whatever K*M modulo the window is
+    t1 = time.perf_counter()
     dev_ms = f.timer_stop()  # hipEvents on the handle's own stream
+    t2 = time.perf_counter()
     summary = mc.summarise(f.stats())
     gathered = mc.gather_stats(summary, device=coll_device)  # the one collective (RCCL all-gather)
+    t3 = time.perf_counter()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    if os.environ.get("BENCH_PHASES"):
+        print("phases (us): enqueue %.1f  wait %.1f  stats+gather %.1f  sync+barrier %.1f  device %.1f" %
+              ((t1 - t0) * 1e6, (t2 - t1) * 1e6, (t3 - t2) * 1e6, (t0 + elapsed - t3) * 1e6, dev_ms * 1e3), file=sys.stderr)
     if dist is not None:
         te = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
@@ -176,9 +189,11 @@ def main():
     alone_launches, alone_ms = 0, 0.0
     if not args.no_flush_profile:
         for r in range(4):
+            # a whole window, then its pipeline-style pass (buffer to buffer, on the pass's own stream) with the chain kernel
+            # already finished and nothing following
             f.script_run(W + K + r * win_steps, win_steps)
-            f.sync()   # chain kernels finished: the pass below runs alone
-            f.flush()
+            f.sync()
+            f.close_window()
             f.sync()
         alone_launches, alone_ms = f.flush_profile_read()
 

@@ -162,8 +162,12 @@ int ekf_script_run(ekf_handle h, int first_step, int n_steps, int use_graph);
 /* ---- synchronisation, timing, diagnostics ---------------------------------------------------- */
 
 int ekf_sync(ekf_handle h);  /* waits for the stream, returns a sticky error (EKF_ERR_CAPACITY, EKF_ERR_TIMEOUT) if any filter raised one */
-/* Fold the deferred slots into P_LL now (one dense pass, asynchronous). */
+/* Fold the deferred slots into P_LL now (one dense pass, asynchronous).  The caller says "nothing follows for now": in
+ * overlap mode the pass goes out on the chain's own stream, on all CUs and in place, and the pipeline restarts empty. */
 int ekf_flush(ekf_handle h);
+/* Close the open window with a pipeline pass (buffer to buffer on the pass's own stream, as when more measurements
+ * follow at once).  Same result as ekf_flush; only the scheduling differs (diagnostics: time that pass alone). */
+int ekf_close_window(ekf_handle h);
 /* hipEvent pair on the handle's stream. stop synchronises and returns elapsed milliseconds. */
 int ekf_timer_start(ekf_handle h);
 int ekf_timer_stop(ekf_handle h, double *ms_out);

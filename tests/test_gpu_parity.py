@@ -650,3 +650,52 @@ def test_batch_larger_than_the_resident_workgroups(pkg, oc):
     st = f.stats()
     assert all(s["n_old"] + s["n_new"] + s["n_ignore"] == steps * M for s in st)
     f.close()
+
+
+@pytest.mark.parametrize("overlap", ["0", "1"])
+def test_flush_and_close_window_anywhere_in_a_scripted_run(pkg, oc, monkeypatch, overlap):
+    """ekf_flush ("nothing follows": in overlap mode a terminal in-place pass on the chain's stream, pipeline restarts empty),
+    ekf_close_window (pipeline pass) and the deferred close of a window that a scripted run fills with its last
+    measurement, at every alignment: pieces that end mid-window, exactly on a window, on a deferred set that the next
+    piece / a flush / a state read must close.  Decisions, counters and the final state against the oracle."""
+    monkeypatch.setenv("EKF_OVERLAP", overlap)
+    steps, M, win = 160, 3, 8
+    script, ctrl, z, R, valid = lifecycle_as_script(pkg, steps, M)
+    f = pkg.FilterBatch(1, 64, max_pending=win, log_capacity=1024)
+    assert f.overlap == (overlap == "1") and f.window == win
+    f.script_load(ctrl, z, R, valid=valid)
+    f.script_run(0, 5)        # 15 slots: one window closed, 7 open
+    f.flush()
+    f.script_run(5, 11)       # 33 slots: 1 open
+    f.close_window()
+    f.script_run(16, 16)      # 48 slots = 6 windows: the last one's close is deferred (overlap mode)
+    mid = f.stats()[0]        # counters through the host mirror, nothing flushed
+    f.script_run(32, 8)       # 24 slots = 3 windows, starting on the deferred set
+    f.flush()
+    f.flush()                 # nothing open: no-op
+    f.script_run(40, 8)       # ends on a deferred set again ...
+    xm, Pm = f.get_state()    # ... which the state read closes
+    f.script_run(48, steps - 48)
+    f.sync()
+    x, P = np.zeros(3), np.zeros((3, 3))
+    decs, n32, at48 = [], None, None
+    for s, st in enumerate(script):
+        if s == 32:
+            n32 = len(decs)
+        if s == 48:
+            at48 = (x.copy(), P.copy())
+        x, P = oc.propagate(x, P, st["v"], st["w"], oc.make_Q(st["v"]), st["dt"])
+        for fx, fy in st["feats_mm"]:
+            zz, RR = oc.make_measurement(fx, fy)
+            x, P, dec, mat, _ = oc.update(x, P, zz.reshape(2, 1), RR)
+            decs.append((dec[0], mat[0]))
+    g = f.decisions(0, len(decs))
+    assert [(d[0], d[1]) for d in g] == decs
+    assert mid["n_new"] + mid["n_old"] + mid["n_ignore"] == n32
+    st = f.stats()[0]
+    assert (st["n_new"], st["n_old"], st["n_ignore"]) == tuple(sum(1 for d in decs if d[0] == k) for k in (pkg.ekfslam.NEW, pkg.ekfslam.OLD, pkg.ekfslam.IGNORE))
+    assert_state_close(xm, Pm, at48[0], at48[1], "state read on a deferred set")
+    xg, Pg = f.get_state()
+    assert_state_close(xg, Pg, x, P, "overlap %s" % overlap)
+    assert_bitwise_symmetric(Pg)
+    f.close()
