@@ -12,6 +12,7 @@
 
 #include <string>
 #include <mutex>
+#include <functional>
 #include <vector>
 
 #include "ekf_device.h"
@@ -58,6 +59,10 @@ struct ekf_batch {
     int need_pass;        // the pass the next chain launches have to wait for in-kernel, 0 = none
     bool inkernel_wait;   // chain kernels wait for their pass in-kernel (kernels of two streams run side by side), else by event
     long long chain_seq;  // chain launches so far; the kernel stores it into the host mirror when it is done
+    int ncu = 0;                            // CUs of the device
+    bool persist = true;                    // scripted runs in overlap mode: one chain launch for several windows (EKF_PERSIST=0 switches it off)
+    unsigned long long seg_count_base = 0;  // value dv.seg_count reaches when every multi-segment launch enqueued so far has finished
+    unsigned long long open_set_gate = 0;   // != 0: the open set was filled by that segment of a multi-segment launch (gate for its pass)
     bool stats_in_mirror = false;  // mirror.stats is current (a chain launch ran since the last ekf_reset_stats)
     bool mirror_by_chain; // the newest writer of the host mirror is chain launch number chain_seq (else: some other kernel, synchronise)
     int flush_keep;       // pool key of s_flush: CUs kept free for the chain, -1 = unmasked
@@ -359,6 +364,7 @@ static int create_impl(ekf_batch *h, int batch, int capacity_landmarks, int devi
         }
         g_cus_claimed[device_id] += need;
         h->claimed_cus = need;
+        h->ncu = prop.multiProcessorCount;
     }
     size_t B = batch;
     hipStream_t s = h->s_chain;
@@ -383,6 +389,7 @@ static int create_impl(ekf_batch *h, int batch, int capacity_landmarks, int devi
     HIP_TRY(dev_alloc_zero(&dv.slot_active, B * 2 * dv.maxp, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.slot_meta, B * 2 * dv.maxp, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.pass_flag, 1, &h->device_bytes, s));
+    HIP_TRY(dev_alloc_zero(&dv.seg_count, 1, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.bar, B * 2, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.dbg, 32, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.part, B * 2 * dv.gmax * EKF_REC_DOUBLES, &h->device_bytes, s));
@@ -467,6 +474,11 @@ static int create_impl(ekf_batch *h, int batch, int capacity_landmarks, int devi
         h->chain_signalled = false;
     }
     h->flush_alternate = getenv("EKF_FLUSH_ALTERNATE") ? atoi(getenv("EKF_FLUSH_ALTERNATE")) != 0 : true;
+    {
+        int can_wait_value = 0;
+        (void)hipDeviceGetAttribute(&can_wait_value, hipDeviceAttributeCanUseStreamWaitValue, device_id);
+        h->persist = (getenv("EKF_PERSIST") ? atoi(getenv("EKF_PERSIST")) != 0 : true) && can_wait_value != 0;
+    }
     h->flush_dir = 0;
     h->dbg_skip_flush = getenv("EKF_DEBUG_SKIP_FLUSH") && atoi(getenv("EKF_DEBUG_SKIP_FLUSH")) != 0;
     h->xcd_map = getenv("EKF_XCD_MAP") ? atoi(getenv("EKF_XCD_MAP")) != 0 : true;
@@ -500,7 +512,7 @@ extern "C" int ekf_destroy(ekf_handle h) {
     for (auto &g : h->graphs) hipGraphExecDestroy(g.exec);
     EkfDev &dv = h->dv;
     hipFree(dv.x), hipFree(dv.R), hipFree(dv.D), hipFree(dv.Bm[0]), hipFree(dv.FA), hipFree(dv.FB);
-    hipFree(dv.n_lm), hipFree(dv.n_lm_sweep), hipFree(dv.n_lm_flush), hipFree(dv.status), hipFree(dv.slot_active), hipFree(dv.slot_meta), hipFree(dv.pass_flag);
+    hipFree(dv.n_lm), hipFree(dv.n_lm_sweep), hipFree(dv.n_lm_flush), hipFree(dv.status), hipFree(dv.slot_active), hipFree(dv.slot_meta), hipFree(dv.pass_flag), hipFree(dv.seg_count);
     hipFree(dv.bar), hipFree(dv.part), hipFree(dv.dbg);
     hipFree(dv.log), hipFree(dv.log_count), hipFree(dv.stats);
     hipFree(h->cursor_d);
@@ -627,7 +639,9 @@ static const int *tile_map_for(ekf_batch *h, int nT) {
 //    k+1 read Bm[fin] and fold set k themselves (n_prev).  Pass k starts after the chain kernels of window k
 //    (ev_chain) and, by stream order, after pass k-1 whose output it reads; the chain kernels of window k+1
 //    start after pass k-1 (they read its output and overwrite the slot rows it read).
-static int close_set(ekf_batch *h, bool terminal = false) {
+typedef std::vector<std::function<hipError_t()>> EnqueueList;
+
+static int close_set(ekf_batch *h, bool terminal = false, EnqueueList *defer = nullptr) {
     if (h->pending == 0) return EKF_OK;
     int nT_hi = (2 * h->n_lm_hi + 63) / 64;
     const int fin = (h->overlap && h->prev_pending > 0) ? h->buf_in ^ 1 : h->buf_in;
@@ -636,19 +650,26 @@ static int close_set(ekf_batch *h, bool terminal = false) {
     // and in place (the faster form when nothing else uses the memory system); the pipeline restarts empty afterwards.
     terminal = terminal && h->overlap;
     const int fout = (h->overlap && !terminal) ? fin ^ 1 : fin;
-    hipStream_t sf = terminal ? h->s_chain : h->s_flush;
+    hipStream_t sf = terminal ? h->s_chain : h->s_flush, sc = h->s_chain;
+    // What the pass waits for.  A set filled by a segment of a multi-segment chain launch: the value dv.seg_count shows when
+    // every workgroup has finished that segment (a stream gate, hipStreamWaitValue64: the kernel is still running).  Otherwise
+    // the chain launch's event.
+    const unsigned long long gate_seq = terminal ? 0 : h->open_set_gate;
+    h->open_set_gate = 0;
+    bool record_chain = false, wait_chain = false;
+    hipEvent_t wait_prev = nullptr;
     if (terminal) {
-        if (h->prev_pending > 0) HIP_TRY(hipStreamWaitEvent(h->s_chain, h->ev_flush[h->ev_idx], 0));  // pass k-1 wrote Bm[fin]
+        if (h->prev_pending > 0) wait_prev = h->ev_flush[h->ev_idx];  // pass k-1 wrote Bm[fin]
         h->chain_signalled = false;
     } else if (h->overlap) {
-        if (!h->chain_signalled) HIP_TRY(hipEventRecord(h->ev_chain, h->s_chain));
+        if (!gate_seq) record_chain = !h->chain_signalled, wait_chain = true;
         h->chain_signalled = false;
-        HIP_TRY(hipStreamWaitEvent(sf, h->ev_chain, 0));
     }
-    if (!h->dbg_skip_flush && (nT_hi > 0 || h->overlap)) {
-        if (nT_hi < 1) nT_hi = 1;
-        int total = nT_hi * (nT_hi + 1) / 2;
-        hipEvent_t e0 = nullptr, e1 = nullptr;
+    const bool do_pass = !h->dbg_skip_flush && (nT_hi > 0 || h->overlap);
+    if (nT_hi < 1) nT_hi = 1;
+    const int total = nT_hi * (nT_hi + 1) / 2;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (do_pass) {
         if (h->overlap && !terminal) e1 = h->ev_flush[h->ev_idx ^ 1];  // pass k's completion, signalled by its own dispatch packet
         if (h->prof_flush) {
             while (h->prof_pool.size() < h->prof_used + 2) {
@@ -658,21 +679,20 @@ static int close_set(ekf_batch *h, bool terminal = false) {
             }
             e0 = h->prof_pool[h->prof_used++], e1 = h->prof_pool[h->prof_used++];  // (recycled after a read: never used for dependencies)
         }
-        // Passes alternate direction: a pass starts on the tiles the previous pass touched last, which are the ones the
-        // 256 MB Infinity Cache still holds (P_LL of N=4096 is 270 MB per buffer: walked the same way every time, the
-        // cache has evicted a tile long before the next pass comes back to it).
-        const int rev = h->flush_alternate ? h->flush_dir : 0;
-        h->flush_dir ^= 1;
-        const int nwg = cdiv(total, 4);
-        // (start/stop events ride on the dispatch packet itself: no extra barrier packets)
-        if (h->dv.B > 1 && h->batch_interleave) {  // a filter's workgroups on one XCD
-            dim3 g1((unsigned)(cdiv(h->dv.B, 8) * 8 * nwg), 1);
-            hipExtLaunchKernelGGL(k_flush_rb, g1, dim3(256), 0, sf, e0, e1, 0, h->dv, nT_hi, h->cur_set, h->pending, fin, fout, (const int *)nullptr, nwg, rev);
-        } else {
-            hipExtLaunchKernelGGL(k_flush_rb, dim3(nwg, h->dv.B), dim3(256), 0, sf, e0, e1, 0, h->dv, nT_hi, h->cur_set, h->pending, fin, fout,
-                                  h->dv.B == 1 ? tile_map_for(h, nT_hi) : (const int *)nullptr, 0, rev);
-        }
     }
+    // Passes alternate direction: a pass starts on the tiles the previous pass touched last, which are the ones the
+    // 256 MB Infinity Cache still holds (P_LL of N=4096 is 270 MB per buffer: walked the same way every time, the
+    // cache has evicted a tile long before the next pass comes back to it).
+    const int rev = h->flush_alternate ? h->flush_dir : 0;
+    if (do_pass) h->flush_dir ^= 1;
+    const int nwg = cdiv(total, 4);
+    const bool interleave = h->dv.B > 1 && h->batch_interleave;  // a filter's workgroups on one XCD
+    const int *tmap = (do_pass && !interleave && h->dv.B == 1) ? tile_map_for(h, nT_hi) : (const int *)nullptr;
+    const EkfDev dv = h->dv;
+    const int set = h->cur_set, nslots = h->pending, B = h->dv.B;
+    bool mark = false, record_done = false, wait_done_on_chain = false, serial = false;
+    int mark_value = 0;
+    hipEvent_t done_ev = nullptr;
     if (terminal) {
         h->need_pass = 0;
         h->buf_in = fin;
@@ -685,18 +705,51 @@ static int close_set(ekf_batch *h, bool terminal = false) {
             h->need_pass = h->prev_pending > 0 ? h->pass_seq : 0;  // pass_seq still names pass k-1 here
         } else {
             h->need_pass = 0;
-            if (h->prev_pending > 0) HIP_TRY(hipStreamWaitEvent(h->s_chain, h->ev_flush[h->ev_idx], 0));  // pass k-1
+            if (h->prev_pending > 0) wait_prev = h->ev_flush[h->ev_idx];  // pass k-1, awaited by the chain's stream
         }
-        hipLaunchKernelGGL(k_mark, dim3(1), dim3(64), 0, sf, h->dv.pass_flag, ++h->pass_seq);  // pass k
+        mark = true, mark_value = ++h->pass_seq;  // pass k
         h->ev_idx ^= 1;  // ev_flush[ev_idx] is pass k's completion: its stop event, or, when profiling took that, a marker
-        if (h->prof_flush) HIP_TRY(hipEventRecord(h->ev_flush[h->ev_idx], sf));
-        if (getenv("EKF_OVERLAP_SERIAL")) HIP_TRY(hipStreamWaitEvent(h->s_chain, h->ev_flush[h->ev_idx], 0));  // experiment: no concurrency
+        record_done = h->prof_flush;
+        done_ev = h->ev_flush[h->ev_idx];
+        serial = getenv("EKF_OVERLAP_SERIAL") != nullptr;  // experiment: no concurrency
+        wait_done_on_chain = serial;
         h->buf_in = fin;
         h->prev_pending = h->pending;
     }
     h->cur_set ^= 1;
     h->pending = 0;
-    return check_launch();
+    hipEvent_t ev_chain = h->ev_chain;
+    auto enqueue = [=]() -> hipError_t {
+        hipError_t e = hipSuccess;
+        if (terminal) {
+            if (wait_prev && (e = hipStreamWaitEvent(sc, wait_prev, 0)) != hipSuccess) return e;
+        } else {
+            if (gate_seq && (e = hipStreamWaitValue64(sf, dv.seg_count, gate_seq, hipStreamWaitValueGte, 0xffffffffffffffffull)) != hipSuccess) return e;
+            if (record_chain && (e = hipEventRecord(ev_chain, sc)) != hipSuccess) return e;
+            if (wait_chain && (e = hipStreamWaitEvent(sf, ev_chain, 0)) != hipSuccess) return e;
+        }
+        if (do_pass) {
+            // (start/stop events ride on the dispatch packet itself: no extra barrier packets)
+            if (interleave) {
+                dim3 g1((unsigned)(cdiv(B, 8) * 8 * nwg), 1);
+                hipExtLaunchKernelGGL(k_flush_rb, g1, dim3(256), 0, sf, e0, e1, 0, dv, nT_hi, set, nslots, fin, fout, (const int *)nullptr, nwg, rev);
+            } else {
+                hipExtLaunchKernelGGL(k_flush_rb, dim3(nwg, B), dim3(256), 0, sf, e0, e1, 0, dv, nT_hi, set, nslots, fin, fout, tmap, 0, rev);
+            }
+        }
+        if (!terminal && wait_prev && (e = hipStreamWaitEvent(sc, wait_prev, 0)) != hipSuccess) return e;
+        if (mark) hipLaunchKernelGGL(k_mark, dim3(1), dim3(64), 0, sf, dv.pass_flag, mark_value);
+        if (record_done && (e = hipEventRecord(done_ev, sf)) != hipSuccess) return e;
+        if (wait_done_on_chain && (e = hipStreamWaitEvent(sc, done_ev, 0)) != hipSuccess) return e;
+        return hipGetLastError();
+    };
+    if (defer) {
+        defer->push_back(enqueue);
+        return EKF_OK;
+    }
+    hipError_t e = enqueue();
+    if (e != hipSuccess) return set_error(EKF_ERR_HIP, hipGetErrorString(e));
+    return EKF_OK;
 }
 
 // Everything folded into Bm[buf_in], streams idle.
@@ -724,6 +777,44 @@ static int launch_ops(ekf_batch *h, const double *in, const int *cursor, int k0,
         int rc = close_set(h);
         if (rc) return rc;
     }
+    // Scripted runs in overlap mode: the launches of one call become the segments of one launch (up to EKF_PLAN_MAX at a
+    // time).  The workgroups stay resident across window boundaries -- no launch gap (5 us), no refill of the LDS caches
+    // from memory (7 us per 16-measurement window at N = 4096) -- and the dense passes are enqueued behind stream gates that
+    // the running kernel opens (dv.seg_count).  Needs kernels of two streams side by side (the in-kernel pass wait's probe).
+    // ... and CUs on which a pass can run while the chain workgroups stay resident: a chain wave leaves too few registers
+    // on its SIMD for a pass wave, so a pass only runs on CUs without a chain workgroup.  Multi-segment launches are used
+    // while the chain workgroups of ALL live handles hold at most half of the GPU (256 filters of one workgroup each would
+    // wait forever for a pass that cannot start: that batch keeps one launch per segment).
+    bool persist = h->persist && defer_last_close && cursor == nullptr && h->overlap && h->inkernel_wait && h->chain_filters == h->dv.B;
+    if (persist) {
+        std::lock_guard<std::mutex> lk(g_res_mu);
+        persist = g_cus_claimed[h->device] * 2 <= h->ncu;
+    }
+    ChainPlan plan;
+    memset(&plan, 0, sizeof plan);
+    EnqueueList passes;
+    int next_drop = 0;
+    auto launch_plan = [&](hipEvent_t stop_ev) -> int {
+        if (plan.nseg == 0) return EKF_OK;
+        for (int b0 = 0; b0 < h->dv.B; b0 += h->chain_filters) {
+            const int nb = h->dv.B - b0 < h->chain_filters ? h->dv.B - b0 : h->chain_filters;
+            const bool last = b0 + nb >= h->dv.B;
+            hipExtLaunchKernelGGL(k_chain, dim3(h->chain_wgs, nb), dim3(h->chain_threads), h->chain_lds, h->s_chain, nullptr, last ? stop_ev : nullptr, 0, h->dv, in,
+                                  cursor, plan, b0);
+        }
+        if (plan.signal) h->seg_count_base += (unsigned long long)plan.nseg * h->chain_wgs * h->dv.B;
+        plan.nseg = 0;
+        next_drop = 0;
+        for (auto &enq : passes) {
+            hipError_t e = enq();
+            if (e != hipSuccess) {
+                passes.clear();
+                return set_error(EKF_ERR_HIP, hipGetErrorString(e));
+            }
+        }
+        passes.clear();
+        return check_launch();
+    };
     while (i < nops) {
         int start = i, used = h->pending;
         while (i < nops && i - start < EKF_CHAIN_MAX_OPS) {
@@ -734,30 +825,46 @@ static int launch_ops(ekf_batch *h, const double *in, const int *cursor, int k0,
             i++;
         }
         if (i == start) {  // set already full (cannot happen: full sets are closed above and below)
-            int rc = close_set(h);
+            int rc = close_set(h, false, persist ? &passes : nullptr);
             if (rc) return rc;
             continue;
         }
         // overlap: the launch that fills the set signals ev_chain from its own dispatch packet (no marker packet)
         const bool closes = h->overlap && used == h->dv.maxp;
-        ++h->chain_seq;  // (one number per logical launch: every filter's mirror reaches it)
-        for (int b0 = 0; b0 < h->dv.B; b0 += h->chain_filters) {
-            const int nb = h->dv.B - b0 < h->chain_filters ? h->dv.B - b0 : h->chain_filters;
-            const bool last = b0 + nb >= h->dv.B;
-            hipExtLaunchKernelGGL(k_chain, dim3(h->chain_wgs, nb), dim3(h->chain_threads), h->chain_lds, h->s_chain, nullptr,
-                                  closes && last ? h->ev_chain : nullptr, 0, h->dv, in, cursor, k0 + start, i - start, h->pending, h->cur_set, h->buf_in,
-                                  h->prev_pending, h->chain_seq, h->need_pass, b0);
+        ChainSeg sg;
+        sg.k0 = k0 + start, sg.nops = i - start, sg.slot0 = h->pending, sg.set = h->cur_set, sg.buf_read = h->buf_in, sg.n_prev = h->prev_pending;
+        if (next_drop > 0 && next_drop < h->prev_pending) {  // (the LDS shift moves whole windows: start a new launch instead)
+            int rc = launch_plan(nullptr);
+            if (rc) return rc;
         }
+        sg.need_pass = h->need_pass, sg.drop = next_drop;
+        sg.seq = ++h->chain_seq;  // (one number per segment: every filter's mirror reaches it)
+        next_drop = 0;
+        plan.s[plan.nseg++] = sg;
+        plan.signal = persist ? 1 : 0;
+        plan.count_base = h->seg_count_base;
         h->mirror_by_chain = true;
         h->stats_in_mirror = true;
-        h->chain_signalled = closes;
         h->pending = used;
+        if (!persist) {
+            int rc = launch_plan(closes ? h->ev_chain : nullptr);
+            if (rc) return rc;
+            h->chain_signalled = closes;
+        } else {
+            h->chain_signalled = false;
+            if (used == h->dv.maxp) h->open_set_gate = h->seg_count_base + (unsigned long long)plan.nseg * h->chain_wgs * h->dv.B;  // every workgroup has finished this segment
+        }
         if (used == h->dv.maxp && !(defer_last_close && i == nops)) {
-            int rc = close_set(h);
+            int rc = close_set(h, false, persist ? &passes : nullptr);
+            if (rc) return rc;
+            next_drop = sg.n_prev;  // the next segment starts a window: the set whose pass has finished leaves the LDS caches
+        }
+        if (persist && plan.nseg == EKF_PLAN_MAX) {
+            int rc = launch_plan(nullptr);
             if (rc) return rc;
         }
     }
-    return check_launch();
+    return launch_plan(nullptr);
 }
 
 static void bump_bound(ekf_batch *h, int measurements) {

@@ -64,6 +64,25 @@ struct EkfMirror {
     ekf_decision last[EKF_MIRROR_DECISIONS];  // entry i of the log lives at last[i % 64]
 };
 
+// One k_chain launch runs a list of segments; a segment is what used to be a launch of its own: a run of operations inside one
+// slot set.  Several segments per launch keep the workgroups (their LDS caches, their registers) alive across window boundaries.
+#define EKF_PLAN_MAX 12
+struct ChainSeg {
+    int k0, nops;        // operations [k0, k0 + nops) of the input
+    int slot0;           // slots of the open set filled before this segment
+    int set, buf_read;   // the open slot set; the P_LL buffer the segment reads
+    int n_prev;          // slots of the other set still being folded by a dense pass (overlap mode)
+    int need_pass;       // dense pass (number) that must have finished before this segment starts, 0 = none
+    int drop;            // segments after the first: virtual slots that leave the LDS caches in front (the set whose pass has finished)
+    long long seq;       // launch number (the host mirror shows the newest one that has finished)
+};
+struct ChainPlan {
+    int nseg;
+    int signal;                     // != 0: every workgroup counts each segment it finishes in dv.seg_count
+    unsigned long long count_base;  // value of seg_count before this launch
+    ChainSeg s[EKF_PLAN_MAX];
+};
+
 struct EkfDev {
     int B, Ncap;
     int xs;    // stride of x and of each R row (doubles), multiple of 64, >= 3 + 2*Ncap
@@ -86,6 +105,8 @@ struct EkfDev {
     int *slot_active;  // [B][2][maxp]
     SlotMeta *slot_meta;  // [B][2][maxp], written with the slot
     int *pass_flag;    // [1]: number of dense passes completed (overlap mode; stored by k_mark behind each pass)
+    unsigned long long *seg_count;  // [1]: (workgroup, segment) pairs finished by the handle's multi-segment chain launches; the dense passes' stream
+                                    // gates (hipStreamWaitValue64) and the next segment wait for it to reach "every workgroup, this segment"
     int *bar;          // [B][2]: [0] = cross-workgroup exchanges done so far (tags of the records continue from it)
     long long *dbg;    // [32] diagnostics: tick counters of the control lane [0..7] and of the first worker [16..23] (EKF_CHAIN_STAMPS), first bad index [8..11] (EKF_CHAIN_CHECK)
     double *part;      // [B][2][gmax][EKF_REC_DOUBLES]: per-workgroup arg-min records, double-buffered by exchange parity

@@ -13,6 +13,7 @@
 //             C/D operand.  This is the K S K^T update + symmetrisation of Update.cpp:188,193-194
 //             (and the block copies of :170-177) for all measurements of a step in ONE pass.
 // Every input record is 8 doubles per (op, filter): in[(op*B + b)*8 + k], r[7] = op type.
+#include <stddef.h>
 #include "ekf_device.h"
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
@@ -362,8 +363,14 @@ __device__ __forceinline__ unsigned lds_off(const void *p) { return (unsigned)(s
         "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240",     \
         "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255"
 
-__global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, const double *in, const int *cursor, int k0,
-                                                                int nops, int slot0, int set, int buf_read, int n_prev, long long launch_seq, int need_pass, int b_off) {
+struct ChainKArgs {  // k_chain's arguments as they lie in the kernel-argument segment
+    EkfDev dv;
+    const double *in;
+    const int *cursor;
+    ChainPlan plan;
+    int b_off;
+};
+__global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, const double *in, const int *cursor, ChainPlan plan, int b_off) {
     __shared__ ChainLds L;
     __shared__ double recs[EKF_CHAIN_MAX_OPS * 8];
     // own-row cache, per chunk of 64 local landmarks: [virtual slot][plane: components 00 01 | 10 11][lane][2 doubles] -- K rows (Old,
@@ -384,10 +391,6 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
     double *x = dv.x + (size_t)b * xs;
     double *R0 = dv.R + (size_t)b * 3 * xs;
     double *Dx = dv.D + (size_t)b * 3 * dv.dn;
-    const double *Bmr = dv.Bm[buf_read] + (size_t)b * dv.bm_stride;
-    double *FAc = dv.FA + ((size_t)b * 2 + set) * dv.f_stride;
-    double *FBc = dv.FB + ((size_t)b * 2 + set) * dv.f_stride;
-    int *act_c = dv.slot_active + ((size_t)b * 2 + set) * dv.maxp;
     int *bar = dv.bar + (size_t)b * 2;
     double *part = dv.part + (size_t)b * 2 * dv.gmax * EKF_REC_DOUBLES;
     int epoch = 0;  // cross-workgroup exchanges done in this launch
@@ -395,11 +398,10 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
 #ifdef EKF_CHAIN_STAMPS
     unsigned long long stamp_t;
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_t)::"memory");
-    long long stamp_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // [8], [9]: the first worker's wait for its P_LL entries, its fold
+    long long stamp_acc[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // [8], [9]: the first worker's wait for its P_LL entries, its fold; [10..12]: parts of the segment prologue
 #endif
     // slot arrays addressed as base + set offset: a 4-way pointer select would become a scratch table
     const double *FAb = dv.FA + (size_t)b * 2 * dv.f_stride, *FBb = dv.FB + (size_t)b * 2 * dv.f_stride;
-    const size_t off_c = (size_t)set * dv.f_stride;
     const int lpw_ = dv.lpw;
     (void)lpw_;
     const int vs_cap = dv.vs_cap;  // virtual slots the cache holds per chunk (one or two windows)
@@ -409,6 +411,27 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
     const long long lim_x = xs, lim_R = 3LL * xs, lim_D = 3LL * dv.dn, lim_B = (long long)dv.bm_stride, lim_F = 2LL * (long long)dv.f_stride;
     (void)lim_x, (void)lim_R, (void)lim_D, (void)lim_B, (void)lim_F;
     const int T_ = dv.T, rows_ = dv.rows, dn_ = dv.dn;  // by-value captures: a reference to dv would push the kernel arguments to scratch
+
+    // state that lives across the segments of the launch: robot-state buffer in use, the worker's landmark, New-slot mask
+    int cur = 0;
+    unsigned long long new_mask = 0;  // virtual slots that appended a landmark (wave-uniform, kept by every thread)
+    LmState r0 = {0, 0, {0, 0, 0, 0, 0, 0}, 0, 0, 0};
+    const int nseg = plan.nseg;
+    // the segment table is read where it lies, in the kernel-argument segment (scalar loads at a run-time index; indexing the
+    // by-value argument itself makes the compiler copy it to scratch)
+    typedef __attribute__((address_space(4))) const ChainSeg *SegPtr;
+    const SegPtr segs = (SegPtr)((__attribute__((address_space(4))) const char *)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(ChainKArgs, plan) + offsetof(ChainPlan, s));
+    const long long last_seq = segs[nseg - 1].seq;
+    const unsigned long long seg_wgs = (unsigned long long)gridDim.x * gridDim.y;
+    if (tid == 0) L.abort = 0;
+    for (int seg = 0; seg < nseg; seg++) {  // ======== one segment (the body reads like the single-segment kernel it was) ========
+    const int k0 = segs[seg].k0, nops = segs[seg].nops, slot0 = segs[seg].slot0, set = segs[seg].set, buf_read = segs[seg].buf_read;
+    const int n_prev = segs[seg].n_prev, need_pass = segs[seg].need_pass, drop = segs[seg].drop;
+    const double *Bmr = dv.Bm[buf_read] + (size_t)b * dv.bm_stride;
+    double *FAc = dv.FA + ((size_t)b * 2 + set) * dv.f_stride;
+    double *FBc = dv.FB + ((size_t)b * 2 + set) * dv.f_stride;
+    int *act_c = dv.slot_active + ((size_t)b * 2 + set) * dv.maxp;
+    const size_t off_c = (size_t)set * dv.f_stride;
 
     auto lm_load = [=](int lm) {
         LmState st;
@@ -544,35 +567,49 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
         write_slot(lm, slot, 0, 0, 0, 0, 1, 0, 0, 1, true);  // (its own P_xL rows are zero: the 2x2 block lives in D)
     };
 
-    // Overlap mode: wait for the dense pass this launch depends on (MI355X_MICROARCH.md consumer form: one relaxed poll,
-    // one agent acquire, vmcnt(0), workgroup barrier, then plain loads).  Normally the pass finished long ago.
-    if (tid == 0) L.abort = 0;
-    if (need_pass > 0) {
+    // Overlap mode: wait for the dense pass this segment depends on (MI355X_MICROARCH.md consumer form: one relaxed poll, one
+    // agent acquire, vmcnt(0), workgroup barrier, then plain loads; normally the pass finished long ago).
+    // There is no wait for the other workgroups between segments.  What a workgroup reads of the others' previous segment --
+    // the matched landmark's rows of the set just closed -- it reads after an exchange of the new segment, i.e. after every
+    // workgroup has published a head from the new segment, which each does behind its own write-back of the old one; its own
+    // L2 holds no older copy of those rows (last read two windows ago, an acquire at every segment start since).
+    auto open_gates = [=]() {  // a launch that gives up must not leave the dense passes of its later segments waiting
+        if (plan.signal) __hip_atomic_fetch_max(dv.seg_count, plan.count_base + (unsigned long long)nseg * seg_wgs, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto give_up = [=]() {  // a bounded wait ran out (uniform over the workgroup; the other workgroups of the filter time out the same way)
         if (tid == 0) {
-            long spins = 0;
-            while ((int)(__hip_atomic_load(dv.pass_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - need_pass) < 0) {
-                __builtin_amdgcn_s_sleep(8);
-                if (++spins > (1L << 24)) {  // bounded: the launch then applies nothing (the pass's output is not there)
-                    dv.status[b] = EKF_ERR_TIMEOUT;
-                    L.abort = 1;
-                    break;
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __syncthreads();
-        if (L.abort) {  // (uniform over the workgroup; the other workgroups of the filter time out the same way)
-            if (lead && tid == 0) {
+            if (lead) {
                 EkfMirror *mr = dv.mirror + b;
                 mr->status = EKF_ERR_TIMEOUT;
                 __atomic_thread_fence(__ATOMIC_RELEASE);
-                __hip_atomic_store(&mr->seq, launch_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(&mr->seq, last_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
+            open_gates();
+        }
+    };
+    if (need_pass > 0 && tid == 0) {
+        long spins = 0;
+        while ((int)(__hip_atomic_load(dv.pass_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - need_pass) < 0) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > (1L << 24)) {  // bounded: the launch then applies nothing more (the pass's output is not there)
+                dv.status[b] = EKF_ERR_TIMEOUT;
+                L.abort = 1;
+                break;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    // (first segment: everybody waits here.  Later segments: only the control lane has waited; the workers prepare the
+    // segment meanwhile and meet it at the barrier below.)
+    if (seg == 0 && need_pass > 0) {
+        __syncthreads();
+        if (L.abort) {
+            give_up();
             return;
         }
     }
-
+    STAMP(10);  // epilogue and count of the segment before, waits, acquire
     // the control lane records what kind of slot the operation leaves (every workgroup in LDS, workgroup 0 also in HBM
     // for later launches)
     auto note_slot = [=](int slot, int type, int ln, double S00, double S01, double S11) {
@@ -583,19 +620,54 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
     };
 
     // stage this filter's operation records in LDS (one trip to HBM / host memory for the whole list)
-    for (int q = tid; q < nops * 8; q += bd) recs[q] = op_record(in, cursor, k0 + (q >> 3), dv.B, b)[q & 7];
-    // slots filled by earlier launches: their kinds, then the own rows back into LDS
-    for (int q = tid; q < n_prev + slot0; q += bd)
-        L.sm[q] = dv.slot_meta[((size_t)b * 2 + (q < n_prev ? (set ^ 1) : set)) * dv.maxp + (q < n_prev ? q : q - n_prev)];
+    // slots filled before this segment: their kinds, then the own rows.  First segment: from memory (earlier launches left
+    // them there).  Later segments: both are still in LDS; when a new window begins, the `drop` slots of the set whose dense
+    // pass has finished leave in front and the set just closed moves down into their place (source and destination do not
+    // overlap: the host only plans drop = 0 or drop >= n_prev) -- all by the workers, while the control lane waits above.
+    if (seg == 0) {
+        for (int q = tid; q < nops * 8; q += bd) recs[q] = op_record(in, cursor, k0 + (q >> 3), dv.B, b)[q & 7];
+        for (int q = tid; q < n_prev + slot0; q += bd)
+            L.sm[q] = dv.slot_meta[((size_t)b * 2 + (q < n_prev ? (set ^ 1) : set)) * dv.maxp + (q < n_prev ? q : q - n_prev)];
+    } else if (worker) {
+        for (int q = wtid; q < nops * 8; q += nw) recs[q] = op_record(in, cursor, k0 + (q >> 3), dv.B, b)[q & 7];
+        if (drop > 0) {
+            for (int q = wtid; q < n_prev + slot0; q += nw) L.sm[q] = L.sm[q + drop];
+            for (int lm = lm0; lm < own_hi; lm += nw)
+                for (int v0 = 0; v0 < n_prev + slot0; v0 += 4) {  // four slots per trip, every read requested before the first write
+                    double2_t t[8];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int vs = v0 + j < n_prev + slot0 ? v0 + j : v0;
+                        const double2_t *from = (const double2_t *)(own_rows + own_at(vs + drop, 0, lm - own_lo));
+                        t[2 * j] = from[0], t[2 * j + 1] = from[64];  // both planes
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if (v0 + j < n_prev + slot0) {
+                            double2_t *to = (double2_t *)(own_rows + own_at(v0 + j, 0, lm - own_lo));
+                            to[0] = t[2 * j], to[64] = t[2 * j + 1];
+                        }
+                }
+        }
+    }
     __syncthreads();
+    if (seg > 0 && L.abort) {
+        give_up();
+        return;
+    }
+    STAMP(11);  // records, slot kinds (later segments: the LDS shift as well)
     if (tid < nops) {
         int k = tid + 1;
         while (k < nops && (int)recs[k * 8 + 7] == OP_TRUTH) k++;
         L.ap_tab[tid] = (signed char)((k < nops && (int)recs[k * 8 + 7] == OP_PROP) ? k : -1);
     }
-    unsigned long long new_mask = 0;  // virtual slots that appended a landmark (wave-uniform, kept by every thread)
-    for (int q = 0; q < n_prev + slot0; q++) new_mask |= (uni(L.sm[q].type) == SLOT_NEW ? 1ull : 0ull) << q;
-    if (worker) {
+    if (seg == 0) {
+        new_mask = 0;
+        for (int q = 0; q < n_prev + slot0; q++) new_mask |= (uni(L.sm[q].type) == SLOT_NEW ? 1ull : 0ull) << q;
+    } else if (drop > 0) {
+        new_mask >>= drop;
+    }
+    if (worker && seg == 0) {
         // eight slots per trip, every load requested before the first LDS write (a dead slot's rows are zeros in HBM too)
         const int n_now = dv.n_lm[b];
         const int hi = own_hi < n_now ? own_hi : n_now;
@@ -620,22 +692,23 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
             }
     }
     if (tid == 0) {
-        RobotState &R = L.rs[0];
-        for (int i = 0; i < 3; i++) {
-            R.pose[i] = x[i];
-            for (int j = 0; j < 3; j++) R.Prr[i * 3 + j] = R0[(size_t)i * xs + j];
+        if (seg == 0) {
+            RobotState &R = L.rs[0];
+            for (int i = 0; i < 3; i++) {
+                R.pose[i] = x[i];
+                for (int j = 0; j < 3; j++) R.Prr[i * 3 + j] = R0[(size_t)i * xs + j];
+            }
+            sincos(R.pose[2], &R.s, &R.c);
+            R.n_lm = dv.n_lm[b];
+            R.n_sweep = dv.n_lm_sweep[b];
+            if (lead) {
+                L.st = dv.stats[b];
+                L.log_count = dv.log_count[b];
+            }
         }
-        sincos(R.pose[2], &R.s, &R.c);
-        R.n_lm = dv.n_lm[b];
-        R.n_sweep = dv.n_lm_sweep[b];
-        if (lead) {
-            L.st = dv.stats[b];
-            L.log_count = dv.log_count[b];
-            L.n_dec = 0;
-        }
+        if (lead) L.n_dec = 0;
     }
-    LmState r0 = {0, 0, {0, 0, 0, 0, 0, 0}, 0, 0, 0};
-    if (worker && lm0 < own_hi && lm0 < dv.n_lm[b]) r0 = lm_load(lm0);
+    if (seg == 0 && worker && lm0 < own_hi && lm0 < dv.n_lm[b]) r0 = lm_load(lm0);
     __syncthreads();
 
     // ---- the operation loop -------------------------------------------------------------------------------
@@ -698,9 +771,8 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
     // touch their own rows, no barrier), operations before it are skipped.  Wave-uniform, kept by every thread.
     int ahead_prop = -1;
 
-    STAMP(7);  // launch prologue: pass wait, records, slot kinds, LDS refill, robot state
+    STAMP(7);  // segment prologue: waits, records, slot kinds, LDS refill / shift, robot state
     int slot = slot0;
-    int cur = 0;
     for (int op = 0; op < nops; op++) {
         const double *rec = recs + op * 8;
         const int type = uni((int)rec[7]);  // uniform over the filter's workgroups
@@ -922,7 +994,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                         if (slot_thread && !cur_thread && L.sm[tid].type != SLOT_DEAD) {
                             const size_t off_p = (size_t)(set ^ 1) * dv.f_stride;
                             const double *F = (L.sm[tid].type == SLOT_NEW ? FAb : FBb) + CK(off_p + pair_offset(rows_, 2 * w_lo, tid >> 1), lim_F - 7) + (tid & 1) * 2;
-                            c4[0] = F[0], c4[1] = F[1], c4[2] = F[4], c4[3] = F[5];
+                            c4[0] = F[0], c4[1] = F[1], c4[2] = F[4], c4[3] = F[5];  // (written in an earlier segment or launch: behind an acquire)
                         }
                         const unsigned long long *wrec = (const unsigned long long *)(part + ((size_t)((epoch - 1) & 1) * dv.gmax + src) * EKF_REC_DOUBLES);
                         const unsigned long long tag = (unsigned long long)(unsigned)(ebase + epoch) << 32;
@@ -1187,34 +1259,61 @@ finish:  // (also the way out when a bounded wait ran out: the sticky status say
 
 #ifdef EKF_CHAIN_STAMPS
     if ((tid == 0 || tid == 64) && g == 0 && b == 0)
-        for (int i = 0; i < (tid == 0 ? 8 : 10); i++) dv.dbg[(tid == 0 ? 0 : 16) + i] += stamp_acc[i];
+        for (int i = 0; i < (tid == 0 ? 8 : 13); i++) dv.dbg[(tid == 0 ? 0 : 16) + i] += stamp_acc[i], stamp_acc[i] = 0;
 #endif
     if (tid == 0) {
         if (lead) {
             const RobotState &R = L.rs[cur];
-            for (int i = 0; i < 3; i++) {
-                x[i] = R.pose[i];
-                for (int j = 0; j < 3; j++) R0[(size_t)i * xs + j] = R.Prr[i * 3 + j];
-            }
-            dv.n_lm[b] = R.n_lm;
-            dv.n_lm_sweep[b] = R.n_sweep;
-            dv.n_lm_flush[(size_t)b * 2 + set] = R.n_lm;
+            const bool last_seg = seg + 1 == nseg || L.abort;  // state for later launches and for the host: once per launch
+            dv.n_lm_flush[(size_t)b * 2 + set] = R.n_lm;  // (read by the set's dense pass)
             EkfMirror *mr = dv.mirror + b;
-            for (int i = 0; i < 3; i++) mr->pose[i] = R.pose[i];
-            mr->n_lm = R.n_lm;
-            dv.stats[b] = L.st;
-            mr->stats = L.st;
-            dv.log_count[b] = L.log_count;
-            for (int i = 0; i < L.n_dec; i++) mr->last[(L.log_count - L.n_dec + i) % EKF_MIRROR_DECISIONS] = L.dec_buf[i];
-            mr->status = dv.status[b];
-            mr->log_count = L.log_count;
-            // everything above is in host memory before the sequence number is: a host thread spinning on seq reads a complete mirror
-            __atomic_thread_fence(__ATOMIC_RELEASE);
-            __hip_atomic_store(&mr->seq, launch_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            // (between segments the decisions go to the host-mapped mirror behind the count below: nobody waits for writes over PCIe)
+            if (last_seg)
+                for (int i = 0; i < L.n_dec; i++) mr->last[(L.log_count - L.n_dec + i) % EKF_MIRROR_DECISIONS] = L.dec_buf[i];
+            if (last_seg) {
+                for (int i = 0; i < 3; i++) {
+                    x[i] = R.pose[i];
+                    for (int j = 0; j < 3; j++) R0[(size_t)i * xs + j] = R.Prr[i * 3 + j];
+                }
+                dv.n_lm[b] = R.n_lm;
+                dv.n_lm_sweep[b] = R.n_sweep;
+                for (int i = 0; i < 3; i++) mr->pose[i] = R.pose[i];
+                mr->n_lm = R.n_lm;
+                dv.stats[b] = L.st;
+                mr->stats = L.st;
+                dv.log_count[b] = L.log_count;
+                mr->status = dv.status[b];
+                mr->log_count = L.log_count;
+                // everything above is in host memory before the sequence number is: a host thread spinning on seq reads a complete mirror
+                __atomic_thread_fence(__ATOMIC_RELEASE);
+                __hip_atomic_store(&mr->seq, last_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
         // (a workgroup can only get here after every workgroup of the filter has read ebase: it took part in each exchange)
         if (lead && epoch > 0) bar[0] = ebase + epoch;
     }
+    if (plan.signal) {
+        // End of a segment of a multi-segment launch.  What a kernel boundary used to do: this workgroup's stores (slot rows,
+        // slot_active, n_lm_flush) complete and written back, then one count.  The count reaching "every workgroup, this
+        // segment" opens the stream gate in front of the set's dense pass and lets the next segment start.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __hip_atomic_fetch_add(dv.seg_count, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lead && seg + 1 < nseg && !L.abort) {
+                EkfMirror *mr = dv.mirror + b;
+                for (int i = 0; i < L.n_dec; i++) mr->last[(L.log_count - L.n_dec + i) % EKF_MIRROR_DECISIONS] = L.dec_buf[i];
+            }
+        }
+    } else if (seg + 1 < nseg) {
+        __syncthreads();
+    }
+    if (L.abort) {  // (read behind a barrier every thread has passed since it was set)
+        if (tid == 0) open_gates();
+        break;
+    }
+    }  // ======== next segment ========
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -699,3 +699,50 @@ def test_flush_and_close_window_anywhere_in_a_scripted_run(pkg, oc, monkeypatch,
     assert_state_close(xg, Pg, x, P, "overlap %s" % overlap)
     assert_bitwise_symmetric(Pg)
     f.close()
+
+
+@pytest.mark.parametrize("B,N,max_pending,steps,lifecycle", [(1, 256, 8, 40, False), (8, 256, 8, 40, False), (1, 4096, 16, 48, False),
+                                                             (1, 1120, 8, 60, False), (1, 700, 6, 150, True)])
+def test_multi_segment_chain_launches_equal_one_launch_per_segment(pkg, monkeypatch, pipeline_mode, B, N, max_pending, steps, lifecycle):
+    """Scripted runs in overlap mode execute several windows per k_chain launch (the workgroups stay resident, the LDS caches
+    shift instead of being refilled, the dense passes wait behind stream gates that the running kernel opens).  Same
+    arithmetic in the same order as one launch per window: decisions and final states must be IDENTICAL, bit for bit --
+    steady Old-only maps on 1 to 32 workgroups, a batch, and a lifecycle that appends landmarks across window boundaries
+    (New slots, dead slots, masked slots in the shifted caches) on two workgroups per filter."""
+    if pipeline_mode != "overlap":
+        pytest.skip("overlap mode only")
+    M = 3 if lifecycle else 4
+    monkeypatch.setenv("EKF_OVERLAP", "1")
+    if lifecycle:
+        monkeypatch.setenv("EKF_CHAIN_WGS", "2")
+        script, ctrl, z, R, valid = lifecycle_as_script(pkg, steps, M)
+    outs = []
+    for persist in ("0", "1"):
+        monkeypatch.setenv("EKF_PERSIST", persist)
+        f = pkg.FilterBatch(B, N, max_pending=max_pending, log_capacity=steps * M)
+        assert f.overlap
+        if lifecycle:
+            f.script_load(ctrl, z, R, valid=valid)
+        else:
+            scripts = []
+            for b in range(B):
+                x0, P0 = pkg.scenarios.injected_state(N, seed=100 + b, extent=12.5 if N <= 256 else 50.0)
+                f.set_state(x0, P0, index=b)
+                scripts.append(pkg.scenarios.steady_script(x0, steps=steps, M=M, seed=200 + b, min_separation=1.0))
+            f.script_load(np.stack([s["ctrl"] for s in scripts], axis=1), np.stack([s["z"] for s in scripts], axis=2), np.stack([s["R"] for s in scripts], axis=2))
+        f.script_run(0, steps // 2)     # two calls: the second starts on the window the first left open
+        f.script_run(steps // 2, steps - steps // 2)
+        f.sync()
+        res = []
+        for b in sorted({0, B // 2, B - 1}):
+            n_dec = sum(int(v) for v in valid[:, :, 0].ravel()) if lifecycle else steps * M
+            res.append((f.decisions(b, n_dec),) + f.get_state(b))
+        outs.append((res, f.stats()))
+        f.close()
+    (r0, s0), (r1, s1) = outs
+    assert s0 == s1
+    for (d0, x0, P0), (d1, x1, P1) in zip(r0, r1):
+        assert d0 == d1
+        assert np.array_equal(x0, x1) and np.array_equal(P0, P1)
+    if lifecycle:
+        assert {d[0] for d in r1[0][0]} >= {pkg.ekfslam.NEW, pkg.ekfslam.OLD} and (r1[0][1].size - 3) // 2 > 8
