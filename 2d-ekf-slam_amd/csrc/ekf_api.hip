@@ -294,9 +294,9 @@ static int create_impl(ekf_batch *h, int batch, int capacity_landmarks, int devi
     // enough workgroups in total (<= 256) that all of them are resident at once: the cross-workgroup
     // barrier needs every workgroup of a filter running.  Every workgroup keeps its landmarks' rows of every
     // slot of the open window in LDS (64 bytes per landmark and slot), so landmarks-per-workgroup x window
-    // must fit the CU's LDS next to the kernel's static 12 KB: more workgroups first, then a shorter window.
+    // must fit the CU's LDS next to the kernel's static 16 KB: more workgroups first, then a shorter window.
     const int max_workers = EKF_CHAIN_MAX_THREADS - 64;
-    const long lds_budget = (long)prop.sharedMemPerBlock - 12288;
+    const long lds_budget = (long)prop.sharedMemPerBlock - 16384;  // (k_chain's static LDS: 16.2 KB)
     if (lds_budget < 64 * 64) return set_error(EKF_ERR_NO_DEVICE, "device reports too little LDS per workgroup");
     int maxp = h->params.max_pending;
     // overlap (params.overlap, EKF_OVERLAP overrides): automatic = on when two windows of every landmark's slot rows fit
@@ -349,6 +349,7 @@ static int create_impl(ekf_batch *h, int batch, int capacity_landmarks, int devi
     HIP_TRY(hipFuncSetAttribute((const void *)k_chain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_budget));  // one setting for every handle
     int workers = (dv.lpw + 63) / 64 * 64;
     if (workers > max_workers) workers = max_workers;
+    if (dv.lpw > 64 && dv.lpw <= 128) workers = 192;  // two owner waves and a third that shares their fold (k_chain: helper_on)
     h->chain_threads = 64 + workers;  // wave 0 is the control wave
     {
         int per_cu = 0;

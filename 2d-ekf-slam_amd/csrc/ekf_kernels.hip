@@ -116,6 +116,9 @@ struct ChainLds {
     SlotMeta sm[2 * EKF_MAX_PENDING];
     alignas(16) double loC[2 * EKF_MAX_PENDING * 4];
     alignas(16) double loM[2 * EKF_MAX_PENDING * 4];
+    // the helper wave's share of the fold: component-major partial sums for up to 128 landmarks, and the number of the fold they belong to
+    double hp[4 * 128];
+    int hflag;
 };
 
 // Header of the Old branch (Update.cpp:181-189): a pure function of the heading the sweep ran with and of the
@@ -423,7 +426,8 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
     const SegPtr segs = (SegPtr)((__attribute__((address_space(4))) const char *)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(ChainKArgs, plan) + offsetof(ChainPlan, s));
     const long long last_seq = segs[nseg - 1].seq;
     const unsigned long long seg_wgs = (unsigned long long)gridDim.x * gridDim.y;
-    if (tid == 0) L.abort = 0;
+    if (tid == 0) L.abort = 0, L.hflag = -1;
+    int fold_no = 0;  // Old measurements whose fold the helper wave shared (wave-uniform, kept by every thread)
     for (int seg = 0; seg < nseg; seg++) {  // ======== one segment (the body reads like the single-segment kernel it was) ========
     const int k0 = segs[seg].k0, nops = segs[seg].nops, slot0 = segs[seg].slot0, set = segs[seg].set, buf_read = segs[seg].buf_read;
     const int n_prev = segs[seg].n_prev, need_pass = segs[seg].need_pass, drop = segs[seg].drop;
@@ -1041,8 +1045,25 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                 __syncthreads();  // (3) staged rows visible
                 if (L.abort) goto finish;
                 STAMP(4);
+                // The fold is bound by FMA issue of the one wave a SIMD holds (8 clocks each, 8 per slot).  With 128 landmarks on two
+                // worker waves the third worker wave is idle: it takes the last third of the slots for both (64 landmarks each),
+                // leaves its partial sums in LDS and raises a flag; the owners fold the first two thirds and add.
+                const bool helper_on = uni((bd == 256 && lpw_ > 64 && lpw_ <= 128 && nvs >= 6) ? 1 : 0) != 0;
+                const int n_help = helper_on ? nvs / 3 : 0, n_own = nvs - n_help;
+                if (helper_on) fold_no++;
                 if (worker) {
                     const OldHdr h = old_header(RS.c, RS.s, L.w);
+                    if (helper_on && (wtid >> 6) == 2) {
+                        for (int half = 0; half < 2; half++) {
+                            const int ll = half * 64 + (wtid & 63);
+                            double q00 = 0, q01 = 0, q10 = 0, q11 = 0;
+                            unsigned a0 = lds_off(own_rows + own_at(n_own, 0, ll)), am = lds_off(L.loM + n_own * 4);
+                            int n = n_help;
+                            asm volatile(FOLD_ASM : [p00] "+v"(q00), [p01] "+v"(q01), [p10] "+v"(q10), [p11] "+v"(q11), [a0] "+v"(a0), [am] "+v"(am), [n] "+s"(n) : : FOLD_CLOBBERS);
+                            L.hp[ll] = q00, L.hp[128 + ll] = q01, L.hp[256 + ll] = q10, L.hp[384 + ll] = q11;
+                        }
+                        __hip_atomic_store(&L.hflag, fold_no, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
                     auto gain_one = [&](int lm, LmState &st, bool prefetched) {
                         double p[2][2] = {{0, 0}, {0, 0}};
                         if (lm == w_lo) {
@@ -1062,9 +1083,9 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
 #endif
                             // the unflushed slots are not in Bm yet: P[lm rows, lo cols] += (own cached rows) * M_slot
                             double pe[2][2] = {{0, 0}, {0, 0}};
-                            if (nvs > 0) {  // (wave-uniform)
+                            if (n_own > 0) {  // (wave-uniform)
                                 unsigned a0 = lds_off(own_rows + own_at(0, 0, lm - own_lo)), am = lds_off(L.loM);
-                                int n = nvs;
+                                int n = n_own;
                                 asm volatile(FOLD_ASM
                                              : [p00] "+v"(pe[0][0]), [p01] "+v"(pe[0][1]), [p10] "+v"(pe[1][0]), [p11] "+v"(pe[1][1]), [a0] "+v"(a0), [am] "+v"(am), [n] "+s"(n)
                                              :
@@ -1080,6 +1101,12 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                             }
                             for (int a = 0; a < 2; a++)
                                 for (int e = 0; e < 2; e++) p[a][e] += pe[a][e];
+                            if (helper_on) {  // the helper wave's share (it has had the same time for the same number of slots)
+                                while (__hip_atomic_load(&L.hflag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != fold_no) {
+                                }
+                                const int ll = lm - own_lo;
+                                p[0][0] += L.hp[ll], p[0][1] += L.hp[128 + ll], p[1][0] += L.hp[256 + ll], p[1][1] += L.hp[384 + ll];
+                            }
 #ifdef EKF_CHAIN_STAMPS
                             if (prefetched) {
                                 asm volatile("" ::"v"(p[0][0]), "v"(p[0][1]), "v"(p[1][0]), "v"(p[1][1]));
