@@ -21,6 +21,19 @@ def filter_seed(base_seed, global_index):
 
 def summarise(stats):
     """ekf_stats dicts -> [n, 2] array of (mean NIS, mean NEES) per filter (NaN when no samples)."""
+    if isinstance(stats, np.ndarray) and stats.dtype.names:  # FilterBatch.stats_array(): vectorised
+        out = np.full((stats.shape[0], 2), np.nan)
+        if stats.shape[0] <= 4:  # (a handful of rows: scalar arithmetic beats the masked array operations)
+            for i, r in enumerate(stats.tolist()):  # field order of ekf_stats: nis_sum, nees_sum, nis_count, nees_count, ...
+                if r[2]:
+                    out[i, 0] = r[0] / r[2]
+                if r[3]:
+                    out[i, 1] = r[1] / r[3]
+            return out
+        nis, nees = stats["nis_count"] > 0, stats["nees_count"] > 0
+        out[nis, 0] = stats["nis_sum"][nis] / stats["nis_count"][nis]
+        out[nees, 1] = stats["nees_sum"][nees] / stats["nees_count"][nees]
+        return out
     out = np.full((len(stats), 2), np.nan)
     for i, s in enumerate(stats):
         if s["nis_count"]:

@@ -26,6 +26,10 @@ def test_summarise_and_consistency(pkg):
     stats = [dict(nis_sum=20.0, nis_count=10, nees_sum=33.0, nees_count=11), dict(nis_sum=0.0, nis_count=0, nees_sum=0.0, nees_count=0)]
     s = mc.summarise(stats)
     assert np.allclose(s[0], [2.0, 3.0]) and np.isnan(s[1]).all()
+    arr = np.zeros(2, dtype=[("nis_sum", "f8"), ("nees_sum", "f8"), ("nis_count", "i8"), ("nees_count", "i8")])  # FilterBatch.stats_array() form
+    arr[0] = (20.0, 33.0, 10, 11)
+    sa = mc.summarise(arr)
+    assert np.allclose(sa[0], [2.0, 3.0]) and np.isnan(sa[1]).all()
     rng = np.random.default_rng(0)
     k, m = 64, 50
     summ = np.stack([rng.chisquare(2, size=(k, m)).mean(axis=1), rng.chisquare(3, size=(k, m)).mean(axis=1)], axis=1)
