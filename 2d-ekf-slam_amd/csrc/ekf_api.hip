@@ -85,6 +85,7 @@ struct ekf_batch {
     bool flush_alternate; // EKF_FLUSH_ALTERNATE (default on): dense passes walk the tiles alternately first-to-last and last-to-first
     int flush_dir;        // direction of the next dense pass (0 = first to last)
     bool dbg_skip_flush;  // EKF_DEBUG_SKIP_FLUSH=1: timing experiments only, results are wrong
+    int dbg_drop_marks_from = 0;  // EKF_DEBUG_DROP_MARKS_FROM=k: dense passes k, k+1, ... never report completion (tests of the bounded waits)
     // immediate-mode input ring (host-mapped pinned)
     double *ring_h;
     double *ring_d;
@@ -282,6 +283,7 @@ static int create_impl(ekf_batch *h, int batch, int capacity_landmarks, int devi
     dv.rows = 64 * dv.T;
     dv.gamma_max = h->params.gamma_max;
     dv.gamma_min = h->params.gamma_min;
+    dv.spin_limit = getenv("EKF_DEBUG_SPIN_LIMIT") ? atoll(getenv("EKF_DEBUG_SPIN_LIMIT")) : (1LL << 24);
     dv.cond_limit = h->params.cond_limit;
     {
         // cond >= L  <=>  q r >= kappa (q^2 + r^2); kappa = 1/2 - 1/(L^2 + 1) (-> 1/2 for L = inf: only q = r is skipped).
@@ -482,6 +484,7 @@ static int create_impl(ekf_batch *h, int batch, int capacity_landmarks, int devi
     }
     h->flush_dir = 0;
     h->dbg_skip_flush = getenv("EKF_DEBUG_SKIP_FLUSH") && atoi(getenv("EKF_DEBUG_SKIP_FLUSH")) != 0;
+    h->dbg_drop_marks_from = getenv("EKF_DEBUG_DROP_MARKS_FROM") ? atoi(getenv("EKF_DEBUG_DROP_MARKS_FROM")) : 0;
     h->xcd_map = getenv("EKF_XCD_MAP") ? atoi(getenv("EKF_XCD_MAP")) != 0 : true;
     h->batch_interleave = getenv("EKF_BATCH_INTERLEAVE") ? atoi(getenv("EKF_BATCH_INTERLEAVE")) != 0 : true;
     h->script_d = nullptr;
@@ -709,6 +712,7 @@ static int close_set(ekf_batch *h, bool terminal = false, EnqueueList *defer = n
             if (h->prev_pending > 0) wait_prev = h->ev_flush[h->ev_idx];  // pass k-1, awaited by the chain's stream
         }
         mark = true, mark_value = ++h->pass_seq;  // pass k
+        if (h->dbg_drop_marks_from > 0 && mark_value >= h->dbg_drop_marks_from) mark = false;  // (test hook: a pass that never reports)
         h->ev_idx ^= 1;  // ev_flush[ev_idx] is pass k's completion: its stop event, or, when profiling took that, a marker
         record_done = h->prof_flush;
         done_ev = h->ev_flush[h->ev_idx];

@@ -115,6 +115,7 @@ struct EkfDev {
     ekf_stats *stats;
     EkfMirror *mirror;  // [B], host-mapped
     double gamma_max, gamma_min, cond_limit;
+    long long spin_limit;  // polls of the in-kernel pass wait before a launch gives up (EKF_ERR_TIMEOUT)
     double cond_k2;  // ((L^2 - 1) / (2 (L^2 + 1)))^2 for L = cond_limit: the sweep's condition test without sqrt / division
 };
 

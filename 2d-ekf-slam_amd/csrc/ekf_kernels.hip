@@ -595,7 +595,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
         long spins = 0;
         while ((int)(__hip_atomic_load(dv.pass_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - need_pass) < 0) {
             __builtin_amdgcn_s_sleep(8);
-            if (++spins > (1L << 24)) {  // bounded: the launch then applies nothing more (the pass's output is not there)
+            if (++spins > dv.spin_limit) {  // bounded (2^24 polls, seconds): the launch then applies nothing more (the pass's output is not there)
                 dv.status[b] = EKF_ERR_TIMEOUT;
                 L.abort = 1;
                 break;

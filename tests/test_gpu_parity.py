@@ -746,3 +746,41 @@ def test_multi_segment_chain_launches_equal_one_launch_per_segment(pkg, monkeypa
         assert np.array_equal(x0, x1) and np.array_equal(P0, P1)
     if lifecycle:
         assert {d[0] for d in r1[0][0]} >= {pkg.ekfslam.NEW, pkg.ekfslam.OLD} and (r1[0][1].size - 3) // 2 > 8
+
+
+@pytest.mark.parametrize("persist", ["0", "1"])
+def test_a_dense_pass_that_never_reports_ends_in_a_timeout_not_a_hang(pkg, monkeypatch, pipeline_mode, persist):
+    """The last line of defence of the overlapped pipeline: from the third dense pass on, completion is never reported
+    (test hook) -- a chain window that depends on such a pass must give up after its bounded wait (shortened here), report
+    EKF_ERR_TIMEOUT through every accessor, apply nothing further, and leave no stream waiting: multi-segment launches open
+    the stream gates of their remaining passes themselves.  A fresh handle then works normally."""
+    if pipeline_mode != "overlap":
+        pytest.skip("overlap mode only")
+    monkeypatch.setenv("EKF_OVERLAP", "1")
+    monkeypatch.setenv("EKF_PERSIST", persist)
+    monkeypatch.setenv("EKF_DEBUG_DROP_MARKS_FROM", "3")
+    monkeypatch.setenv("EKF_DEBUG_SPIN_LIMIT", str(1 << 13))
+    N, M, steps = 700, 4, 40
+    x0, P0 = pkg.scenarios.injected_state(N, seed=5)
+    sc = pkg.scenarios.steady_script(x0, steps=steps, M=M, seed=6)
+    f = pkg.FilterBatch(1, N, max_pending=8)
+    f.set_state(x0, P0)
+    load_script(f, sc)
+    f.script_run(0, steps)
+    with pytest.raises(pkg.ekfslam.EkfError) as e:
+        f.sync()
+    assert e.value.code == pkg.ekfslam.ERR_TIMEOUT
+    with pytest.raises(pkg.ekfslam.EkfError):
+        f.get_state()
+    with pytest.raises(pkg.ekfslam.EkfError):
+        f.poses()
+    f.close()
+    monkeypatch.delenv("EKF_DEBUG_DROP_MARKS_FROM")
+    monkeypatch.delenv("EKF_DEBUG_SPIN_LIMIT")
+    g = pkg.FilterBatch(1, N, max_pending=8)
+    g.set_state(x0, P0)
+    load_script(g, sc)
+    g.script_run(0, steps)
+    g.sync()
+    assert g.stats()[0]["n_old"] == steps * M
+    g.close()
