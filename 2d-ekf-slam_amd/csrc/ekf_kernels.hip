@@ -212,21 +212,24 @@ __device__ __forceinline__ size_t chk_idx(long long *dbg, int line, long long id
 // updates the robot block; New / Ignore / compass: the control lane prepares a header first.
 // Every workgroup keeps an identical copy of the robot state; only workgroup 0 writes logs, statistics,
 // slot flags and, at the end, the robot state and the host-mapped mirror.
-//   in/cursor/k0/nops : the operation list
-//   slot0             : first free slot of set `set`
-//   n_prev            : > 0 while the other set (its first n_prev slots) is being folded by a dense pass that
-//                       reads Bm[buf_read] and writes the other buffer: those slots are not in Bm[buf_read] either.
-//                       The LDS copy of the own rows and the exchanged rows cover n_prev + slot "virtual" slots,
-//                       the other set's first.
-//   buf_read          : Bm buffer to read P_LL columns from
-//   b_off             : first filter of this launch (a batch larger than the GPU keeps resident at once is cut into launches)
-//   need_pass         : > 0: dense pass number need_pass wrote Bm[buf_read] and read the slot rows this launch is about to
-//                       overwrite; the launch waits for dv.pass_flag to reach it before touching either (an in-kernel
+//   in/cursor         : the operation records (8 doubles each, per filter); cursor: device-side start index (graph replays)
+//   plan              : the segments of this launch (ChainPlan, ekf_device.h); a segment is a run of operations inside one slot
+//                       set -- what a launch of its own does when the host launches once per window.  Per segment:
+//     k0, nops        : its operations
+//     slot0           : first free slot of set `set`
+//     n_prev          : > 0 while the other set (its first n_prev slots) is being folded by a dense pass that reads
+//                       Bm[buf_read] and writes the other buffer: those slots are not in Bm[buf_read] either.  The LDS copy
+//                       of the own rows and the exchanged rows cover n_prev + slot "virtual" slots, the other set's first.
+//     buf_read        : Bm buffer to read P_LL columns from
+//     need_pass       : > 0: dense pass number need_pass wrote Bm[buf_read] and read the slot rows this segment is about to
+//                       overwrite; the segment waits for dv.pass_flag to reach it before touching either (an in-kernel
 //                       wait instead of a cross-stream event: the event's barrier packet cost 6 us per window)
-// Dynamic LDS: every landmark's own rows of every slot of the set being filled (64 bytes per landmark and
-// slot, component-major so that a wave reads one component of consecutive landmarks conflict-free); the fold
-// of the not-yet-flushed slots into P[own rows, matched columns] then needs no trip to memory.  The host sizes
-// lpw * maxp * 64 bytes to fit the CU's 160 KB (ekf_batch_create).
+//     drop            : segments after the first: virtual slots that leave the LDS caches in front when a new window begins
+//   b_off             : first filter of this launch (a batch larger than the GPU keeps resident at once is cut into launches)
+// Dynamic LDS: every landmark's own rows of every virtual slot (32 bytes per landmark and slot; per chunk of 64 landmarks
+// [slot][plane 00 01 | 10 11][lane][2], so that a wave reads a slot as two conflict-free 16-byte accesses at fixed strides);
+// the fold of the not-yet-flushed slots into P[own rows, matched columns] then needs no trip to memory.  The host sizes
+// ceil64(lpw) * maxp * sets * 32 bytes to fit the CU's 160 KB next to 16 KB of static LDS (ekf_batch_create).
 // ---------------------------------------------------------------------------------------------
 struct LmState {  // everything the chain keeps per landmark
     double x0, x1;   // position estimate
