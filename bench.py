@@ -242,9 +242,10 @@ def main():
                 roofline["traffic"] = tj.get("hbm_bytes_per_launch")
                 break
 
-    cpu = None
+    cpu = cpu_strong = None
     if world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(pkg, N, M, seed, extent, min_sep)
+        cpu_strong = cpu_baseline_structured(pkg, N, M, seed, extent, min_sep)
 
     rep = mc.consistency_report(gathered, K * M, K)
     # the steady workload feeds 0.5-sigma measurement noise and a noise-free truth (margins
@@ -269,6 +270,8 @@ def main():
         "device_ms_per_step": dev_ms / K,
         "roofline": roofline,
         "cpu_baseline": cpu,
+        "cpu_baseline_structured": cpu_strong,
+        "per_update_us": elapsed / (K * M) * 1e6,
         "mc_stats": mc_stats,
         "config5": config5,
     }
@@ -299,6 +302,35 @@ def cpu_baseline(pkg, N, M, seed, extent, min_sep):
     return {"value": sample_steps / t, "unit": "steps/s", "cores": 1, "kind": "port",
             "sample": "%d step(s) of the same workload (1 Propagate + %d Old Updates each) at N=%d, faithful-dense oracle, %.1f s" % (sample_steps, M, N, t),
             "host_cpus": os.cpu_count()}
+
+
+def cpu_baseline_structured(pkg, N, M, seed, extent, min_sep):
+    """The strong CPU baseline of SURVEY.md 8(d): the oracle's structured mode (state advanced in place, only the O(n) rows
+    and the one rank-2 pass over P per update, OpenMP over the element-wise loops) on this GPU's share of the host cores.
+    Not the reference's algorithmic cost -- what a CPU can do with the same restructuring."""
+    from oracle import oracle_c as oc
+
+    threads = min(16, os.cpu_count() or 1)   # (a one-GPU box's CPU share)
+    sample_steps = {4096: 40, 1024: 400, 256: 2000}.get(N, 20)
+    x, P = pkg.scenarios.injected_state(N, seed=seed, extent=extent)
+    sc = pkg.scenarios.steady_script(x, steps=sample_steps + 2, M=M, seed=seed + 7919, min_separation=min_sep)
+    oc.build()
+    oc.set_threads(threads)
+    ses = oc.Session(x, P)
+    del P
+    t0 = None
+    for s in range(sample_steps + 2):
+        if s == 2:
+            t0 = time.perf_counter()   # (two warm-up steps: page faults of the session's buffers, thread start)
+        v, w, dt = sc["ctrl"][s]
+        ses.propagate(v, w, oc.make_Q(v), dt)
+        for m in range(M):
+            dec, _, _ = ses.update(sc["z"][s, m].reshape(2, 1), sc["R"][s, m].reshape(2, 2, order="F"))
+            assert dec == [oc.OLD]
+    t = time.perf_counter() - t0
+    oc.set_threads(1)
+    return {"value": sample_steps / t, "unit": "steps/s", "cores": threads, "kind": "port",
+            "sample": "%d step(s) of the same workload at N=%d, structured oracle (in place, one rank-2 pass per update), %d OpenMP threads, %.1f s" % (sample_steps, N, threads, t)}
 
 
 if __name__ == "__main__":

@@ -7,6 +7,7 @@ mkdir -p gpurun_out
 python bench.py > gpurun_out/r02_bench_n4096.json 2> gpurun_out/r02_bench_n4096.err || exit 1
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/r02_bench_n4096_driver20.json 2>/dev/null || exit 1
 EKF_OVERLAP=0 python bench.py --no-cpu-baseline > gpurun_out/r02_bench_n4096_inplace.json 2>/dev/null || exit 1
+python bench.py --M 1 --no-cpu-baseline > gpurun_out/r02_bench_n4096_M1.json 2>/dev/null || exit 1
 python bench.py --workload n1024 > gpurun_out/r02_bench_n1024.json 2>/dev/null || exit 1
 python bench.py --workload batch256 > gpurun_out/r02_bench_batch256.json 2>/dev/null || exit 1
 python bench.py --workload n8192 --no-cpu-baseline > gpurun_out/r02_bench_n8192.json 2>/dev/null || exit 1
