@@ -784,3 +784,68 @@ def test_a_dense_pass_that_never_reports_ends_in_a_timeout_not_a_hang(pkg, monke
     g.sync()
     assert g.stats()[0]["n_old"] == steps * M
     g.close()
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_operation_sequences_vs_oracle(pkg, oc, monkeypatch, seed):
+    """Randomised API traffic against the oracle, decision for decision and state for state: random capacity, window and
+    workgroup count; Propagates with random controls (v = 0 included: Q = 0), doUpdate chunks of 1-3 measurements of a hidden
+    world (re-observations, first sightings, outliers in the Ignore band, a chunk that sees the same new landmark twice),
+    compass updates, and state reads / flushes / window closes at random points (each forces a different way of folding the
+    open window)."""
+    rng = np.random.default_rng(9000 + seed)
+    cap = int(rng.integers(6, 90))
+    max_pending = int(rng.choice([1, 2, 3, 4, 7, 8, 16]))
+    if seed % 4 == 3:
+        monkeypatch.setenv("EKF_CHAIN_WGS", str(int(rng.integers(2, 5))))
+    world = rng.uniform(-9.0, 9.0, size=(int(rng.integers(4, 40)), 2))
+    f = pkg.FilterBatch(1, cap, max_pending=max_pending, log_capacity=4096)
+    x, P = np.zeros(3), np.zeros((3, 3))
+    pose = np.zeros(3)  # hidden truth
+    n_checks = 0
+    for step in range(60):
+        v = 0.0 if rng.random() < 0.1 else float(rng.uniform(0.05, 0.6))
+        w, dt = float(rng.uniform(-0.4, 0.4)), float(rng.uniform(0.02, 0.3))
+        pose = pose + dt * np.array([v * np.cos(pose[2]), v * np.sin(pose[2]), w])
+        f.propagate(v, w, dt)
+        x, P = oc.propagate(x, P, v, w, oc.make_Q(v), dt)
+        if rng.random() < 0.15:
+            zc = float(pose[2] % 6.283185307 + rng.normal(0, 0.02))
+            f.update_compass(zc, 0.0005)
+            x, P = oc.compass(x, P, zc, 0.0005)
+        n_z = int(rng.integers(0, 4))
+        if n_z:
+            c, s = np.cos(pose[2]), np.sin(pose[2])
+            zs = []
+            for k in range(n_z):
+                lm = world[int(rng.integers(0, world.shape[0]))]
+                d = lm - pose[:2]
+                z = np.array([c * d[0] + s * d[1], -s * d[0] + c * d[1]]) + rng.normal(0, 0.03, 2)
+                if rng.random() < 0.1:
+                    z = z + rng.uniform(0.3, 0.8, 2)   # somewhere between the gates
+                if k and rng.random() < 0.2:
+                    z = zs[0] + rng.normal(0, 0.005, 2)  # the chunk sees its first landmark again (Update.cpp:26: still New if it was New)
+                zs.append(z)
+            zs = np.array(zs)
+            Rs = np.stack([oc.make_measurement(1000.0 * z[0], 1000.0 * z[1])[1] for z in zs])
+            if (x.size - 3) // 2 + n_z > cap:
+                continue  # (capacity overflow has its own test)
+            dec = f.update(zs.reshape(1, n_z, 2), Rs.reshape(1, n_z, 2, 2))[0]
+            x, P, deco, mato, _ = oc.update(x, P, zs.T, np.concatenate(list(Rs), axis=1))
+            assert [(d[0], d[1]) for d in dec] == list(zip(deco, mato)), (seed, step)
+        r = rng.random()
+        if r < 0.12:
+            xg, Pg = f.get_state()
+            assert_state_close(xg, Pg, x, P, "seed %d step %d" % (seed, step))
+            assert_bitwise_symmetric(Pg)
+            n_checks += 1
+        elif r < 0.2:
+            f.flush()
+        elif r < 0.28:
+            f.close_window()
+        elif r < 0.4:
+            assert np.allclose(f.poses()[0], x[:3], rtol=1e-9, atol=1e-12) and int(f.num_landmarks()[0]) == (x.size - 3) // 2
+    xg, Pg = f.get_state()
+    assert_state_close(xg, Pg, x, P, "seed %d final" % seed)
+    assert_bitwise_symmetric(Pg)
+    f.close()
