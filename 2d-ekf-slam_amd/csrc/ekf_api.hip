@@ -53,6 +53,7 @@ struct ekf_batch {
     bool overlap;         // a window's dense pass runs beside the next window's chain kernels (two slot sets, two Bm buffers)
     int prev_pending;     // overlap: slots of the other set whose dense pass has been launched but is not in Bm[buf_in]
     hipEvent_t ev_chain, ev_flush[2];
+    hipEvent_t pass_done[2] = {nullptr, nullptr};  // completion of the pass that ev_flush[i] stands for: ev_flush[i] itself, or, while passes are profiled, that pass's stop event
     int ev_idx;           // ev_flush[ev_idx] belongs to the dense pass launched last
     bool chain_signalled; // the last chain launch carried ev_chain as its stop event
     int pass_seq;         // dense passes launched so far (overlap mode); k_mark stores it into dv.pass_flag behind each pass
@@ -663,7 +664,7 @@ static int close_set(ekf_batch *h, bool terminal = false, EnqueueList *defer = n
     bool record_chain = false, wait_chain = false;
     hipEvent_t wait_prev = nullptr;
     if (terminal) {
-        if (h->prev_pending > 0) wait_prev = h->ev_flush[h->ev_idx];  // pass k-1 wrote Bm[fin]
+        if (h->prev_pending > 0) wait_prev = h->pass_done[h->ev_idx];  // pass k-1 wrote Bm[fin]
         h->chain_signalled = false;
     } else if (h->overlap) {
         if (!gate_seq) record_chain = !h->chain_signalled, wait_chain = true;
@@ -681,7 +682,7 @@ static int close_set(ekf_batch *h, bool terminal = false, EnqueueList *defer = n
                 HIP_TRY(hipEventCreate(&e));
                 h->prof_pool.push_back(e);
             }
-            e0 = h->prof_pool[h->prof_used++], e1 = h->prof_pool[h->prof_used++];  // (recycled after a read: never used for dependencies)
+            e0 = h->prof_pool[h->prof_used++], e1 = h->prof_pool[h->prof_used++];  // (recycled after a read, which leaves both streams idle; e1 doubles as the pass's completion event)
         }
     }
     // Passes alternate direction: a pass starts on the tiles the previous pass touched last, which are the ones the
@@ -709,13 +710,15 @@ static int close_set(ekf_batch *h, bool terminal = false, EnqueueList *defer = n
             h->need_pass = h->prev_pending > 0 ? h->pass_seq : 0;  // pass_seq still names pass k-1 here
         } else {
             h->need_pass = 0;
-            if (h->prev_pending > 0) wait_prev = h->ev_flush[h->ev_idx];  // pass k-1, awaited by the chain's stream
+            if (h->prev_pending > 0) wait_prev = h->pass_done[h->ev_idx];  // pass k-1, awaited by the chain's stream
         }
         mark = true, mark_value = ++h->pass_seq;  // pass k
         if (h->dbg_drop_marks_from > 0 && mark_value >= h->dbg_drop_marks_from) mark = false;  // (test hook: a pass that never reports)
-        h->ev_idx ^= 1;  // ev_flush[ev_idx] is pass k's completion: its stop event, or, when profiling took that, a marker
-        record_done = h->prof_flush;
-        done_ev = h->ev_flush[h->ev_idx];
+        h->ev_idx ^= 1;  // pass_done[ev_idx] is pass k's completion: ev_flush[ev_idx] as its stop event, or the profiling pair's stop event
+        record_done = false;
+        done_ev = (h->prof_flush && do_pass) ? e1 : h->ev_flush[h->ev_idx];
+        if (!do_pass) record_done = true, done_ev = h->ev_flush[h->ev_idx];  // (no pass kernel to carry the event: a marker)
+        h->pass_done[h->ev_idx] = done_ev;
         serial = getenv("EKF_OVERLAP_SERIAL") != nullptr;  // experiment: no concurrency
         wait_done_on_chain = serial;
         h->buf_in = fin;
@@ -1462,7 +1465,7 @@ extern "C" int ekf_timer_start(ekf_handle h) {
 extern "C" int ekf_timer_stop(ekf_handle h, double *ms_out) {
     if (!h || !ms_out) return set_error(EKF_ERR_BAD_ARG, "null argument");
     HIP_TRY(hipSetDevice(h->device));
-    if (h->overlap && h->prev_pending > 0) HIP_TRY(hipStreamWaitEvent(h->s_chain, h->ev_flush[h->ev_idx], 0));  // the pass in flight counts
+    if (h->overlap && h->prev_pending > 0) HIP_TRY(hipStreamWaitEvent(h->s_chain, h->pass_done[h->ev_idx], 0));  // the pass in flight counts
     HIP_TRY(hipEventRecord(h->t1, h->s_chain));
     HIP_TRY(event_wait(h->t1));
     float ms = 0;
