@@ -455,15 +455,27 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
         Dx[CK(lm, lim_D)] = st.dxx, Dx[CK(dn_ + lm, lim_D)] = st.dxy, Dx[CK(2 * (size_t)dn_ + lm, lim_D)] = st.dyy;
     };
     // P[rows of lm, columns of lo] as stored in Bm[buf_read] (row index = the older landmark)
-    auto load_old_inputs = [=](int lm, int lo, double p[2][2]) {
+    // Two steps, so that the request can be issued before a barrier and the values used behind it: the loads only (no
+    // arithmetic on their results -- a select on a loaded value makes the wave wait for the load where the select stands:
+    // 1 us in front of the winner's record, every measurement) ...
+    auto request_old_inputs = [=](int lm, int lo, double raw[4]) {
         // the 2x2 block (rows 2lm, 2lm+1; columns 2lo, 2lo+1) never straddles a 16x16 chain: one offset, then +2 per column and
         // +32 per row of the stored orientation (bm_offset: lane = 16 (row & 3) + column, two doubles per lane)
         const bool below = lm < lo;
         const int ri = below ? 2 * lm : 2 * lo, ci = below ? 2 * lo : 2 * lm;  // stored as (row of the older landmark, column of the younger)
         const double *q = Bmr + CK(bm_offset(T_, ri, ci), lim_B - 34);
-        const double v00 = q[0], v01 = q[2], v10 = q[32], v11 = q[34];  // stored (row + a, column + e)
-        p[0][0] = v00, p[1][1] = v11;
-        p[0][1] = below ? v01 : v10, p[1][0] = below ? v10 : v01;  // p[a][e] = P[2lm + a, 2lo + e]
+        raw[0] = q[0], raw[1] = q[2], raw[2] = q[32], raw[3] = q[34];  // stored (row + a, column + e)
+    };
+    // ... and the orientation: p[a][e] = P[2lm + a, 2lo + e]
+    auto orient_old_inputs = [=](int lm, int lo, const double raw[4], double p[2][2]) {
+        const bool below = lm < lo;
+        p[0][0] = raw[0], p[1][1] = raw[3];
+        p[0][1] = below ? raw[1] : raw[2], p[1][0] = below ? raw[2] : raw[1];
+    };
+    auto load_old_inputs = [=](int lm, int lo, double p[2][2]) {
+        double raw[4];
+        request_old_inputs(lm, lo, raw);
+        orient_old_inputs(lm, lo, raw, p);
     };
     // One landmark's two rows of a measurement's rank-2 slot: A rows (a00 a01 / a10 a11), B rows likewise.
     // Slots are stored in pairs (one k=4 MFMA operand): an even slot writes whole 32-byte rows and
@@ -900,7 +912,9 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                     put(rec + 2 * EKF_REC_HEAD, gd);
                     __hip_atomic_store(rec + 2 * EKF_REC_HEAD + 2, tag | (unsigned)gi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-                if (gi != 0x7fffffff) {
+                // (only a workgroup whose candidate passes the Old gate publishes a record: the record is read in the Old branch only,
+                // and the filter-wide winner of an Old decision is such a candidate -- 31 of 32 records used to be written for nothing)
+                if (gi != 0x7fffffff && gd < dv.gamma_min) {
                     if (gi == best.lm)  // the lane that owns the local winner
                         for (int i = 0; i < 16; i++) put(rec + 2 * i, best.w[i]);
                     for (int q = tid; q < slot * 4; q += bd) put(rec + 2 * (16 + q), own_rows[own_at(n_prev + (q >> 2), q & 3, gi - own_lo)]);  // the open set's cached rows (dead slots hold zeros)
@@ -983,8 +997,8 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                 // ---- Old, Update.cpp:181-189.  Workers: request the matched landmark's slot rows (into LDS) and their
                 // own P_LL entries and slot rows (into registers), barrier, fold, gain, store.  Control lane: robot block.
                 const int hi = own_hi < n_lm_before ? own_hi : n_lm_before;
-                double pf_p[2][2] = {{0, 0}, {0, 0}};
-                if (worker && lm0 < hi && lm0 != w_lo) load_old_inputs(lm0, w_lo, pf_p);  // in flight across the barrier
+                double pf_raw[4] = {0, 0, 0, 0};
+                if (worker && lm0 < hi && lm0 != w_lo) request_old_inputs(lm0, w_lo, pf_raw);  // in flight across the barrier
                 // winner record and the matched landmark's slot rows into LDS: from the owner's published record, or,
                 // with one workgroup per filter, straight from registers and the own-row cache
                 // The matched landmark's cached rows of every unflushed slot -> loC, and from them the slot's 2x2 matrix M
@@ -1073,8 +1087,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                             p[0][0] = st.dxx, p[0][1] = st.dxy, p[1][0] = st.dxy, p[1][1] = st.dyy;
                         } else {
                             if (prefetched) {
-                                for (int a = 0; a < 2; a++)
-                                    for (int e = 0; e < 2; e++) p[a][e] = pf_p[a][e];
+                                orient_old_inputs(lm, w_lo, pf_raw, p);
                             } else {
                                 load_old_inputs(lm, w_lo, p);
                             }
