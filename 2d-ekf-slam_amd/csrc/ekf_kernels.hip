@@ -431,6 +431,13 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
     const unsigned long long seg_wgs = (unsigned long long)gridDim.x * gridDim.y;
     if (tid == 0) L.abort = 0, L.hflag = -1;
     int fold_no = 0;  // Old measurements whose fold the helper wave shared (wave-uniform, kept by every thread)
+    // Launches without a measurement (Propagate, compass, truth samples) have no exchange, hence nothing that keeps the filter's
+    // workgroups in step: workgroup 0 could finish the whole launch and write the new robot state, landmark count and counters
+    // over the old ones before a workgroup that started late has read them (seen as a landmark slice propagated with the heading
+    // AFTER the Propagate, once in a few hundred API-mode launches).  Every workgroup therefore counts itself in bar[1] once it has
+    // read the shared state; workgroup 0 waits for the count before it writes (only when no exchange has done that for it).
+    int arrive_base = 0;  // (thread 0: bar[1] at the start of this launch; a multiple of G, kernels of a stream do not overlap)
+    bool arrived = false;
     for (int seg = 0; seg < nseg; seg++) {  // ======== one segment (the body reads like the single-segment kernel it was) ========
     const int k0 = segs[seg].k0, nops = segs[seg].nops, slot0 = segs[seg].slot0, set = segs[seg].set, buf_read = segs[seg].buf_read;
     const int n_prev = segs[seg].n_prev, need_pass = segs[seg].need_pass, drop = segs[seg].drop;
@@ -596,6 +603,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
         if (plan.signal) __hip_atomic_fetch_max(dv.seg_count, plan.count_base + (unsigned long long)nseg * seg_wgs, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     };
     auto give_up = [=]() {  // a bounded wait ran out (uniform over the workgroup; the other workgroups of the filter time out the same way)
+        if (tid == 0 && G > 1 && !arrived) __hip_atomic_fetch_add(&bar[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (keeps the count a multiple of G)
         if (tid == 0) {
             if (lead) {
                 EkfMirror *mr = dv.mirror + b;
@@ -729,6 +737,11 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
     }
     if (seg == 0 && worker && lm0 < own_hi && lm0 < dv.n_lm[b]) r0 = lm_load(lm0);
     __syncthreads();
+    if (seg == 0 && G > 1 && tid == 0) {  // (behind the barrier: this workgroup's loads of the shared state have been consumed)
+        const int old_count = __hip_atomic_fetch_add(&bar[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        arrive_base = old_count - old_count % G;
+        arrived = true;
+    }
 
     // ---- the operation loop -------------------------------------------------------------------------------
     // Rules that make the loop race-free:
@@ -927,11 +940,14 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                     const unsigned long long *hd = (const unsigned long long *)(part + ((size_t)(epoch & 1) * dv.gmax + (lane < G ? lane : 0)) * EKF_REC_DOUBLES) + 2 * EKF_REC_HEAD;
                     unsigned long long h0 = 0, h1 = 0, h2 = 0;
                     long spins = 0;
+                    bool ok = lane >= G;
                     for (;;) {
-                        h0 = __hip_atomic_load(hd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        h1 = __hip_atomic_load(hd + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        h2 = __hip_atomic_load(hd + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        const bool ok = lane >= G || (((h0 ^ tag) >> 32) == 0 && ((h1 ^ tag) >> 32) == 0 && ((h2 ^ tag) >> 32) == 0);
+                        if (!ok) {  // (a lane whose head has arrived does not read it again: every poll lengthens everybody's)
+                            h0 = __hip_atomic_load(hd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            h1 = __hip_atomic_load(hd + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            h2 = __hip_atomic_load(hd + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            ok = ((h0 ^ tag) >> 32) == 0 && ((h1 ^ tag) >> 32) == 0 && ((h2 ^ tag) >> 32) == 0;
+                        }
                         if (__all(ok)) break;
                         if (++spins > (1L << 22)) {  // bounded: a workgroup that is not running must not hang the GPU
                             if (lane == 0) dv.status[b] = EKF_ERR_TIMEOUT, L.abort = 1;
@@ -1308,6 +1324,16 @@ finish:  // (also the way out when a bounded wait ran out: the sticky status say
         if (lead) {
             const RobotState &R = L.rs[cur];
             const bool last_seg = seg + 1 == nseg || L.abort;  // state for later launches and for the host: once per launch
+            if (last_seg && G > 1 && epoch == 0 && !L.abort) {  // no exchange in this launch: wait until every workgroup has read what is about to be overwritten
+                long spins = 0;
+                while ((int)(__hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (arrive_base + G)) < 0) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++spins > (1L << 22)) {  // bounded: a workgroup that never starts must not hang the GPU
+                        dv.status[b] = EKF_ERR_TIMEOUT;
+                        break;
+                    }
+                }
+            }
             dv.n_lm_flush[(size_t)b * 2 + set] = R.n_lm;  // (read by the set's dense pass)
             EkfMirror *mr = dv.mirror + b;
             // (between segments the decisions go to the host-mapped mirror behind the count below: nobody waits for writes over PCIe)

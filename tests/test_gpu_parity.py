@@ -849,3 +849,15 @@ def test_random_operation_sequences_vs_oracle(pkg, oc, monkeypatch, seed):
     assert_state_close(xg, Pg, x, P, "seed %d final" % seed)
     assert_bitwise_symmetric(Pg)
     f.close()
+
+
+def test_launches_without_an_exchange_keep_late_workgroups_consistent(pkg, oc, monkeypatch, pipeline_mode):
+    """Regression (found by the randomised test above, once in a few hundred runs): a Propagate or compass launch has no
+    exchange, so nothing kept the filter's workgroups in step, and workgroup 0 could write the new robot state over the old
+    one before a workgroup that started late had read it -- that workgroup then propagated its landmarks' P_RL rows with
+    the heading AFTER the Propagate.  The failing configuration (3 workgroups, small map, API-mode traffic beside the
+    overlapped pipeline) repeated often enough to have shown the race dozens of times."""
+    if pipeline_mode != "overlap":
+        pytest.skip("the overlapped pipeline showed it ten times as often")
+    for rep in range(250):
+        test_random_operation_sequences_vs_oracle(pkg, oc, monkeypatch, 15)
