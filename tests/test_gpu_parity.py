@@ -866,3 +866,60 @@ def test_launches_without_an_exchange_keep_late_workgroups_consistent(pkg, oc, m
         pytest.skip("the overlapped pipeline showed it ten times as often")
     for rep in range(250):
         test_random_operation_sequences_vs_oracle(pkg, oc, monkeypatch, 15)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_scripted_pieces_on_several_workgroups(pkg, oc, monkeypatch, seed):
+    """The scripted path on 2-4 workgroups per filter with everything that can sit between two script_run calls chosen at random:
+    nothing (the next call continues on a deferred window), ekf_flush (terminal pass), ekf_close_window (pipeline pass), a state
+    read, a pose read (host mirror), immediate-mode calls (their own launches, no exchange for Propagate / compass).  Lifecycle
+    script with New / Ignore / masked slots; decisions and final state against the oracle."""
+    rng = np.random.default_rng(7000 + seed)
+    monkeypatch.setenv("EKF_CHAIN_WGS", str(int(rng.integers(2, 5))))
+    steps, M = 120, 3
+    win = int(rng.choice([2, 4, 6, 8, 16]))
+    script, ctrl, z, R, valid = lifecycle_as_script(pkg, steps, M, seed=20260100 + seed)
+    f = pkg.FilterBatch(1, 64, max_pending=win, log_capacity=2048)
+    f.script_load(ctrl, z, R, valid=valid)
+    x, P = np.zeros(3), np.zeros((3, 3))
+    decs = []
+
+    def oracle_steps(a, b):
+        nonlocal x, P
+        for st in script[a:b]:
+            x, P = oc.propagate(x, P, st["v"], st["w"], oc.make_Q(st["v"]), st["dt"])
+            for fx, fy in st["feats_mm"]:
+                zz, RR = oc.make_measurement(fx, fy)
+                x, P, dec, mat, _ = oc.update(x, P, zz.reshape(2, 1), RR)
+                decs.append((dec[0], mat[0]))
+
+    s = 0
+    while s < steps:
+        n = int(min(steps - s, rng.integers(1, 14)))
+        f.script_run(s, n)
+        oracle_steps(s, s + n)
+        s += n
+        r = rng.random()
+        if r < 0.15:
+            f.flush()
+        elif r < 0.3:
+            f.close_window()
+        elif r < 0.4:
+            xg, Pg = f.get_state()
+            assert_state_close(xg, Pg, x, P, "seed %d after step %d" % (seed, s))
+        elif r < 0.55:
+            assert np.allclose(f.poses()[0], x[:3], rtol=1e-9, atol=1e-12)
+        elif r < 0.7:   # an immediate-mode Propagate + compass between two scripted pieces
+            v, w, dt = 0.2, 0.05, 0.1
+            f.propagate(v, w, dt)
+            x, P = oc.propagate(x, P, v, w, oc.make_Q(v), dt)
+            zc = float(x[2] % 6.283185307 + 0.004)
+            f.update_compass(zc, 0.0005)
+            x, P = oc.compass(x, P, zc, 0.0005)
+    f.sync()
+    g = f.decisions(0, len(decs))
+    assert [(d[0], d[1]) for d in g] == decs
+    xg, Pg = f.get_state()
+    assert_state_close(xg, Pg, x, P, "seed %d final" % seed)
+    assert_bitwise_symmetric(Pg)
+    f.close()
