@@ -369,6 +369,7 @@ __device__ __forceinline__ unsigned lds_off(const void *p) { return (unsigned)(s
         "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240",     \
         "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255"
 
+static_assert(sizeof(ChainSeg) == 40 && sizeof(ChainPlan) == 16 + EKF_PLAN_MAX * 40, "the segment table is read from the kernel-argument segment by offset");
 struct ChainKArgs {  // k_chain's arguments as they lie in the kernel-argument segment
     EkfDev dv;
     const double *in;

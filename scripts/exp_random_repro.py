@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """The randomised API-traffic test (tests/test_gpu_parity.py::test_random_operation_sequences_vs_oracle) as a harness with
 switches, to corner an intermittent mismatch.
-usage: exp_random_repro.py <seed> <overlap 0|1> <repeats> [wgs=N] [compass=0] [closes=0] [chunks=0] [reads=0] [KEY=VALUE env ...]"""
+usage: exp_random_repro.py <seed> <overlap 0|1> <repeats> [wgs=N] [compass=0] [closes=0] [chunks=0] [reads=0|2] [repeat=0] [cap=N] [world=N] [maxp=N] [KEY=VALUE env ...]
+reads=2 reads the state back after every update (which made the race disappear: every window settled).  Every failure prints the
+operations before it with the relative error of each measurement's Mahalanobis distance against the oracle (a fingerprint of robot
+and matched-landmark state before that measurement).  TRACE=1 / PARANOID=1 additionally read device-side traces that only exist in
+instrumented builds of the library (ekf_debug_trace, counters in dv.dbg: see DESIGN.md section 4.1 for what they recorded); with the
+shipped library leave them unset."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
