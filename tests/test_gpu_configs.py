@@ -90,6 +90,28 @@ def test_config3_benchmarked_configuration_vs_oracle(pkg, oc, pipeline_mode):
         del xg, Pg
 
 
+def test_config3_sixty_steps_across_several_multi_segment_launches(pkg, oc, pipeline_mode):
+    """The benchmarked configuration for 60 steps = 15 windows: in overlap mode two multi-segment chain launches (12 + 3
+    windows, LDS caches shifted at every window boundary, 14 gated dense passes and a terminal one), fed in two script_run
+    calls so that the second starts on a window the first left open.  Decisions and the full 8195 x 8195 state against the
+    oracle (structured mode, OpenMP)."""
+    M, steps = 4, 60
+    N, x0, P0, sc = bench_inputs(pkg, "n4096", steps)
+    ref = cached("config3_60", lambda: oracle_checkpoints(oc, x0, P0, sc, M, (steps,)))[steps]
+    f = pkg.FilterBatch(1, N, max_pending=16)
+    assert f.window == 16 and f.overlap == (pipeline_mode == "overlap")
+    f.set_state(x0, P0)
+    load_script(f, [sc])
+    f.script_run(0, 26)
+    f.script_run(26, steps - 26)
+    f.sync()
+    assert [(d[0], d[1]) for d in f.decisions(0, steps * M)] == ref["decs"]
+    xg, Pg = f.get_state()
+    assert_state_close(xg, Pg, ref["x"], ref["P"], "N=4096 after step %d" % steps)
+    assert_bitwise_symmetric(Pg)
+    f.close()
+
+
 def test_config2_n1024_after_steps_1_10_200(pkg, oc):
     """N = 1024, default window, bench.py's inputs: oracle check after steps 1, 10 and 200."""
     M = 4
