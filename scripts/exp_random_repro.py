@@ -170,12 +170,12 @@ def run(seed):
 fails = 0
 for r in range(reps):
     try:
-        run(seed)
+        run(seed + (r if os.environ.get('SWEEP_SEEDS') else 0))
     except AssertionError as e:
         fails += 1
         msg = str(e).strip().splitlines()
         if fails <= 4:
-            print("rep %d FAILED: %s" % (r, msg[0][:900] if msg else "?"), flush=True)
+            print("rep %d (seed %d) FAILED: %s" % (r, seed + (r if os.environ.get("SWEEP_SEEDS") else 0), msg[0][:900] if msg else "?"), flush=True)
             for t in getattr(e, "trace", [])[-14:]:
                 print("     ", t, flush=True)
 print("seed %d overlap %s %r: %d failures in %d runs; paranoid: %d winner-data mismatches in %d Old updates" % (seed, overlap, opt, fails, reps, PAR[0], PAR[1]), flush=True)
