@@ -923,3 +923,65 @@ def test_random_scripted_pieces_on_several_workgroups(pkg, oc, monkeypatch, seed
     assert_state_close(xg, Pg, x, P, "seed %d final" % seed)
     assert_bitwise_symmetric(Pg)
     f.close()
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_random_batch_traffic_on_several_workgroups_per_filter(pkg, oc, monkeypatch, seed):
+    """Three filters behind one handle, two or three workgroups each (the exchange, the arrival count and the mirrors are per
+    filter), random API traffic with per-filter validity masks: chunks with holes, compass for some filters only, state reads
+    and flushes in between.  Every filter against its own oracle run."""
+    rng = np.random.default_rng(8000 + seed)
+    B = 3
+    monkeypatch.setenv("EKF_CHAIN_WGS", str(int(rng.integers(2, 4))))
+    cap = int(rng.integers(20, 70))
+    f = pkg.FilterBatch(B, cap, max_pending=int(rng.choice([2, 4, 8])), log_capacity=2048)
+    worlds = [rng.uniform(-9.0, 9.0, size=(int(rng.integers(5, 30)), 2)) for _ in range(B)]
+    xs, Ps = [np.zeros(3) for _ in range(B)], [np.zeros((3, 3)) for _ in range(B)]
+    poses = [np.zeros(3) for _ in range(B)]
+    for step in range(40):
+        v = rng.uniform(0.05, 0.6, B)
+        w, dt = rng.uniform(-0.4, 0.4, B), rng.uniform(0.02, 0.3, B)
+        f.propagate(v, w, dt)
+        for b in range(B):
+            poses[b] = poses[b] + dt[b] * np.array([v[b] * np.cos(poses[b][2]), v[b] * np.sin(poses[b][2]), w[b]])
+            xs[b], Ps[b] = oc.propagate(xs[b], Ps[b], float(v[b]), float(w[b]), oc.make_Q(float(v[b])), float(dt[b]))
+        if rng.random() < 0.2:
+            valid = rng.random(B) < 0.6
+            zc = np.array([poses[b][2] % 6.283185307 + rng.normal(0, 0.02) for b in range(B)])
+            f.update_compass(zc, 0.0005, valid=valid)
+            for b in range(B):
+                if valid[b]:
+                    xs[b], Ps[b] = oc.compass(xs[b], Ps[b], float(zc[b]), 0.0005)
+        n_z = int(rng.integers(1, 4))
+        z = np.zeros((B, n_z, 2))
+        Rm = np.zeros((B, n_z, 2, 2))
+        valid = rng.random((B, n_z)) < 0.7
+        for b in range(B):
+            c, s = np.cos(poses[b][2]), np.sin(poses[b][2])
+            for k in range(n_z):
+                d = worlds[b][int(rng.integers(0, worlds[b].shape[0]))] - poses[b][:2]
+                z[b, k] = np.array([c * d[0] + s * d[1], -s * d[0] + c * d[1]]) + rng.normal(0, 0.03, 2)
+                Rm[b, k] = oc.make_measurement(1000.0 * z[b, k, 0], 1000.0 * z[b, k, 1])[1]
+            if (xs[b].size - 3) // 2 + int(valid[b].sum()) > cap:
+                valid[b] = False
+        dec = f.update(z, Rm, valid=valid)
+        for b in range(B):
+            idx = [k for k in range(n_z) if valid[b, k]]
+            if idx:
+                xs[b], Ps[b], deco, mato, _ = oc.update(xs[b], Ps[b], z[b, idx].T, np.concatenate([Rm[b, k] for k in idx], axis=1))
+                got = [(d[0], d[1]) for d in dec[b][-len(idx):]]  # (masked measurements leave no entry: a filter's real decisions sit at the end)
+                assert got == list(zip(deco, mato)), (seed, step, b)
+        r = rng.random()
+        if r < 0.15:
+            b = int(rng.integers(0, B))
+            xg, Pg = f.get_state(b)
+            assert_state_close(xg, Pg, xs[b], Ps[b], "seed %d step %d filter %d" % (seed, step, b))
+        elif r < 0.25:
+            f.flush()
+        elif r < 0.4:
+            assert np.allclose(f.poses(), np.stack([x[:3] for x in xs]), rtol=1e-9, atol=1e-12)
+    for b in range(B):
+        xg, Pg = f.get_state(b)
+        assert_state_close(xg, Pg, xs[b], Ps[b], "seed %d final filter %d" % (seed, b))
+        assert_bitwise_symmetric(Pg)
+    f.close()
