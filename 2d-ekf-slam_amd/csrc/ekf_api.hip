@@ -19,6 +19,7 @@
 
 // single translation unit: the kernels are compiled together with their launch sites
 #include "ekf_kernels.hip"
+#include "ekf_solo.hip"
 
 static thread_local std::string g_last_error;
 
@@ -67,6 +68,16 @@ struct ekf_batch {
     bool stats_in_mirror = false;  // mirror.stats is current (a chain launch ran since the last ekf_reset_stats)
     bool mirror_by_chain; // the newest writer of the host mirror is chain launch number chain_seq (else: some other kernel, synchronise)
     int flush_keep;       // pool key of s_flush: CUs kept free for the chain, -1 = unmasked
+    bool solo = false;    // one workgroup per filter and one slot set (phase groups are possible)
+    bool solo_kernel = false;  // ... run by k_solo (ekf_solo.hip: maps of up to 256 landmarks, one landmark per thread, one barrier per measurement)
+    // Phase groups (solo batches): the filters are cut into ngroups ranges, each with a stream of its own on which its chain
+    // launches and its dense passes alternate; the groups run out of phase, so that at any moment some groups are in their
+    // (latency-bound) chain kernels while another streams its pass through HBM.  s_grp[0] == s_chain.
+    int ngroups = 1;
+    std::vector<hipStream_t> s_grp;
+    hipEvent_t ev_fork = nullptr;
+    std::vector<hipEvent_t> ev_join;
+    int stagger_ticks = 0; // phase shift between consecutive groups at the start of a grouped run, in ticks of the 100 MHz clock
     int chain_wgs;        // k_chain workgroups per filter
     int chain_filters;    // filters per k_chain launch (all of the batch when its workgroups are resident together)
     int claimed_cus;      // CUs this handle's chain workgroups occupy when they run (residency registry, below)
@@ -331,8 +342,17 @@ static int create_impl(ekf_batch *h, int batch, int capacity_landmarks, int devi
         const int g_cap = batch >= 256 ? 1 : (EKF_CHAIN_MAX_WGS < 256 / batch ? EKF_CHAIN_MAX_WGS : 256 / batch);
         while (G < g_cap && lds_need(G) > lds_budget) G++;
     }
+    // One workgroup per filter and one slot set ("solo").  Maps of up to 256 landmarks whose window fits one CU's LDS are run by
+    // k_solo (ekf_solo.hip): one landmark per thread, no control wave, no exchange, one barrier per measurement.  EKF_SOLO=0
+    // keeps k_chain for them (A/B comparisons, tests of k_chain's one-workgroup path).
+    const bool want_solo_kernel = !h->overlap && (getenv("EKF_SOLO") ? atoi(getenv("EKF_SOLO")) != 0 : true) && !getenv("EKF_CHAIN_WGS");
+    if (want_solo_kernel && capacity_landmarks <= 256 && ((long)capacity_landmarks + 63) / 64 * 64 * maxp * 32 <= lds_budget) G = 1;
     if (getenv("EKF_CHAIN_WGS")) G = atoi(getenv("EKF_CHAIN_WGS")) > 0 ? atoi(getenv("EKF_CHAIN_WGS")) : G;
     if (G > EKF_CHAIN_MAX_WGS) G = EKF_CHAIN_MAX_WGS;
+    if (G * batch > 256) G = 256 / batch > 0 ? 256 / batch : 1;
+    h->solo = !h->overlap && G == 1;
+    h->solo_kernel = h->solo && want_solo_kernel && capacity_landmarks <= 256;
+    h->stagger_ticks = getenv("EKF_SOLO_STAGGER_US") ? atoi(getenv("EKF_SOLO_STAGGER_US")) * 100 : 3500;
     h->chain_wgs = G;
     h->chain_filters = batch * G <= 256 ? batch : 256 / G;  // every workgroup of a launch resident at once
     dv.gmax = G;
@@ -350,20 +370,23 @@ static int create_impl(ekf_batch *h, int batch, int capacity_landmarks, int devi
     dv.vs_cap = maxp * sets_in_lds;
     h->chain_lds = (size_t)lpw64 * maxp * sets_in_lds * 32;
     HIP_TRY(hipFuncSetAttribute((const void *)k_chain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_budget));  // one setting for every handle
+    HIP_TRY(hipFuncSetAttribute((const void *)k_solo, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_budget));
     int workers = (dv.lpw + 63) / 64 * 64;
     if (workers > max_workers) workers = max_workers;
     if (dv.lpw > 64 && dv.lpw <= 128) workers = 192;  // two owner waves and a third that shares their fold (k_chain: helper_on)
     h->chain_threads = 64 + workers;  // wave 0 is the control wave
+    if (h->solo_kernel) h->chain_threads = (capacity_landmarks + 63) / 64 * 64;  // k_solo: one landmark per thread, no control wave
     {
         int per_cu = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_chain, h->chain_threads, h->chain_lds));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, h->solo_kernel ? (const void *)k_solo : (const void *)k_chain, h->chain_threads, h->chain_lds));
         if (per_cu < 1) return set_error(EKF_ERR_STATE, "the chain kernel does not fit a CU with this capacity / window");
-        const int need = (G * h->chain_filters + per_cu - 1) / per_cu;
+        // (one-workgroup filters wait for nobody: they need no co-residency and claim nothing)
+        const int need = h->solo ? 0 : (G * h->chain_filters + per_cu - 1) / per_cu;
         std::lock_guard<std::mutex> lk(g_res_mu);
         if (g_cus_claimed[device_id] + need > prop.multiProcessorCount) {
             char buf[256];
             snprintf(buf, sizeof buf, "this handle's %d chain workgroups need %d CUs, %d of %d are claimed by live handles: they could not all be resident at once",
-                     G * batch, need, g_cus_claimed[device_id], prop.multiProcessorCount);
+                     G * h->chain_filters, need, g_cus_claimed[device_id], prop.multiProcessorCount);
             return set_error(EKF_ERR_STATE, buf);
         }
         g_cus_claimed[device_id] += need;
@@ -477,6 +500,20 @@ static int create_impl(ekf_batch *h, int batch, int capacity_landmarks, int devi
         for (int i = 0; i < 2; i++) HIP_TRY(hipEventCreate(&h->ev_flush[i]));
         h->chain_signalled = false;
     }
+    if (h->solo) {
+        int ng = getenv("EKF_SOLO_GROUPS") ? atoi(getenv("EKF_SOLO_GROUPS")) : 1;
+        if (ng > 8) ng = 8;
+        if (ng < 1 || batch < 16 * ng) ng = 1;  // (small batches: one launch for all filters)
+        h->ngroups = ng;
+        h->s_grp.assign(ng, nullptr);
+        h->s_grp[0] = h->s_chain;
+        h->ev_join.assign(ng, nullptr);
+        if (ng > 1) HIP_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        for (int g = 1; g < ng; g++) {
+            if (!pool_take(device_id, -1, &h->s_grp[g])) HIP_TRY(hipStreamCreateWithFlags(&h->s_grp[g], hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&h->ev_join[g], hipEventDisableTiming));
+        }
+    }
     h->flush_alternate = getenv("EKF_FLUSH_ALTERNATE") ? atoi(getenv("EKF_FLUSH_ALTERNATE")) != 0 : true;
     {
         int can_wait_value = 0;
@@ -510,6 +547,14 @@ extern "C" int ekf_destroy(ekf_handle h) {
         hipStreamSynchronize(h->s_flush);
         pool_give(h->device, h->flush_keep, h->s_flush);
     }
+    for (size_t g = 1; g < h->s_grp.size(); g++)
+        if (h->s_grp[g]) {
+            hipStreamSynchronize(h->s_grp[g]);
+            pool_give(h->device, -1, h->s_grp[g]);
+        }
+    if (h->ev_fork) hipEventDestroy(h->ev_fork);
+    for (auto e : h->ev_join)
+        if (e) hipEventDestroy(e);
     if (h->ev_chain) hipEventDestroy(h->ev_chain);
     for (int i = 0; i < 2; i++)
         if (h->ev_flush[i]) hipEventDestroy(h->ev_flush[i]);
@@ -740,9 +785,9 @@ static int close_set(ekf_batch *h, bool terminal = false, EnqueueList *defer = n
             // (start/stop events ride on the dispatch packet itself: no extra barrier packets)
             if (interleave) {
                 dim3 g1((unsigned)(cdiv(B, 8) * 8 * nwg), 1);
-                hipExtLaunchKernelGGL(k_flush_rb, g1, dim3(256), 0, sf, e0, e1, 0, dv, nT_hi, set, nslots, fin, fout, (const int *)nullptr, nwg, rev);
+                hipExtLaunchKernelGGL(k_flush_rb, g1, dim3(256), 0, sf, e0, e1, 0, dv, nT_hi, set, nslots, fin, fout, (const int *)nullptr, nwg, rev, 0, B);
             } else {
-                hipExtLaunchKernelGGL(k_flush_rb, dim3(nwg, B), dim3(256), 0, sf, e0, e1, 0, dv, nT_hi, set, nslots, fin, fout, tmap, 0, rev);
+                hipExtLaunchKernelGGL(k_flush_rb, dim3(nwg, B), dim3(256), 0, sf, e0, e1, 0, dv, nT_hi, set, nslots, fin, fout, tmap, 0, rev, 0, B);
             }
         }
         if (!terminal && wait_prev && (e = hipStreamWaitEvent(sc, wait_prev, 0)) != hipSuccess) return e;
@@ -779,6 +824,8 @@ static int settle(ekf_batch *h) {
 // consumes[i] != 0 when op i takes a slot (measurement, masked measurement, compass).
 // defer_last_close: when the last launch of this call fills the set, leave the set closed-to-be: the next call closes it
 // (regular pass) or ekf_flush / a state read does (terminal pass, close_set).  Scripted runs use it; never while capturing.
+static int launch_ops_grouped(ekf_batch *h, const double *in, int k0, const unsigned char *consumes, int nops);
+
 static int launch_ops(ekf_batch *h, const double *in, const int *cursor, int k0, const unsigned char *consumes, int nops, bool defer_last_close = false) {
     int i = 0;
     if (h->pending == h->dv.maxp && nops > 0) {  // a set whose close the previous call deferred: more work follows, regular pass
@@ -798,6 +845,12 @@ static int launch_ops(ekf_batch *h, const double *in, const int *cursor, int k0,
         std::lock_guard<std::mutex> lk(g_res_mu);
         persist = g_cus_claimed[h->device] * 2 <= h->ncu;
     }
+    const bool solo = h->solo_kernel;  // one-workgroup filters run by k_solo
+    if (h->solo && h->ngroups > 1 && cursor == nullptr) {
+        long slots = h->pending;
+        for (int q = 0; q < nops; q++) slots += consumes[q] ? 1 : 0;
+        if (slots >= 2L * h->dv.maxp) return launch_ops_grouped(h, in, k0, consumes, nops);  // the call closes at least two windows
+    }
     ChainPlan plan;
     memset(&plan, 0, sizeof plan);
     EnqueueList passes;
@@ -807,8 +860,11 @@ static int launch_ops(ekf_batch *h, const double *in, const int *cursor, int k0,
         for (int b0 = 0; b0 < h->dv.B; b0 += h->chain_filters) {
             const int nb = h->dv.B - b0 < h->chain_filters ? h->dv.B - b0 : h->chain_filters;
             const bool last = b0 + nb >= h->dv.B;
-            hipExtLaunchKernelGGL(k_chain, dim3(h->chain_wgs, nb), dim3(h->chain_threads), h->chain_lds, h->s_chain, nullptr, last ? stop_ev : nullptr, 0, h->dv, in,
-                                  cursor, plan, b0);
+            if (solo)
+                hipExtLaunchKernelGGL(k_solo, dim3(1, nb), dim3(h->chain_threads), h->chain_lds, h->s_chain, nullptr, last ? stop_ev : nullptr, 0, h->dv, in, cursor, plan, b0);
+            else
+                hipExtLaunchKernelGGL(k_chain, dim3(h->chain_wgs, nb), dim3(h->chain_threads), h->chain_lds, h->s_chain, nullptr, last ? stop_ev : nullptr, 0, h->dv, in,
+                                      cursor, plan, b0);
         }
         if (plan.signal) h->seg_count_base += (unsigned long long)plan.nseg * h->chain_wgs * h->dv.B;
         plan.nseg = 0;
@@ -873,6 +929,80 @@ static int launch_ops(ekf_batch *h, const double *in, const int *cursor, int k0,
         }
     }
     return launch_plan(nullptr);
+}
+
+// One-workgroup filters in phase groups: a call that closes several windows (a scripted run) is cut by filter range instead of
+// running the whole batch in lock step.  Group g's stream carries chain launch, dense pass (in place), chain launch, ... for its
+// filters only; nothing orders the groups against each other (filters are independent), and a one-off delay in front of each
+// group's first launch spreads their phases, so that the passes take turns in HBM while the other groups' chain kernels -- which
+// are latency-bound and leave the memory system idle -- run.  Fork from and join into s_chain, so that every other entry point
+// keeps seeing one stream.
+static int launch_ops_grouped(ekf_batch *h, const double *in, int k0, const unsigned char *consumes, int nops) {
+    const int ng = h->ngroups, B = h->dv.B, maxp = h->dv.maxp;
+    const int per = (B + ng - 1) / ng;
+    hipError_t e;
+    if ((e = hipEventRecord(h->ev_fork, h->s_chain)) != hipSuccess) return set_error(EKF_ERR_HIP, hipGetErrorString(e));
+    for (int g = 1; g < ng; g++) {
+        if ((e = hipStreamWaitEvent(h->s_grp[g], h->ev_fork, 0)) != hipSuccess) return set_error(EKF_ERR_HIP, hipGetErrorString(e));
+        if (h->stagger_ticks > 0) hipLaunchKernelGGL(k_delay, dim3(1), dim3(64), 0, h->s_grp[g], (long long)g * h->stagger_ticks);
+    }
+    const bool interleave = h->batch_interleave;
+    int i = 0;
+    while (i < nops) {
+        int start = i, used = h->pending;
+        while (i < nops && i - start < EKF_CHAIN_MAX_OPS) {
+            if (consumes[i]) {
+                if (used == maxp) break;
+                used++;
+            }
+            i++;
+        }
+        ChainPlan plan;
+        memset(&plan, 0, sizeof plan);
+        ChainSeg &sg = plan.s[0];
+        sg.k0 = k0 + start, sg.nops = i - start, sg.slot0 = h->pending, sg.set = h->cur_set, sg.buf_read = h->buf_in;
+        sg.seq = ++h->chain_seq;
+        plan.nseg = 1;
+        h->mirror_by_chain = true;
+        h->stats_in_mirror = true;
+        h->pending = used;
+        const bool fold = used == maxp;
+        int nT_hi = (2 * h->n_lm_hi + 63) / 64;
+        const bool do_pass = fold && !h->dbg_skip_flush && nT_hi > 0;
+        const int total = nT_hi * (nT_hi + 1) / 2, nwg = cdiv(total, 4);
+        const int rev = h->flush_alternate ? h->flush_dir : 0;
+        for (int g = 0; g < ng; g++) {
+            const int b0 = g * per, nb = B - b0 < per ? B - b0 : per;
+            if (nb <= 0) break;
+            if (h->solo_kernel) hipLaunchKernelGGL(k_solo, dim3(1, nb), dim3(h->chain_threads), h->chain_lds, h->s_grp[g], h->dv, in, (const int *)nullptr, plan, b0);
+            else hipLaunchKernelGGL(k_chain, dim3(1, nb), dim3(h->chain_threads), h->chain_lds, h->s_grp[g], h->dv, in, (const int *)nullptr, plan, b0);
+            if (!do_pass) continue;
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (h->prof_flush) {
+                while (h->prof_pool.size() < h->prof_used + 2) {
+                    hipEvent_t ev;
+                    HIP_TRY(hipEventCreate(&ev));
+                    h->prof_pool.push_back(ev);
+                }
+                e0 = h->prof_pool[h->prof_used++], e1 = h->prof_pool[h->prof_used++];
+            }
+            if (interleave)
+                hipExtLaunchKernelGGL(k_flush_rb, dim3((unsigned)(cdiv(nb, 8) * 8 * nwg), 1), dim3(256), 0, h->s_grp[g], e0, e1, 0, h->dv, nT_hi, h->cur_set, maxp, h->buf_in, h->buf_in,
+                                      (const int *)nullptr, nwg, rev, b0, nb);
+            else
+                hipExtLaunchKernelGGL(k_flush_rb, dim3(nwg, nb), dim3(256), 0, h->s_grp[g], e0, e1, 0, h->dv, nT_hi, h->cur_set, maxp, h->buf_in, h->buf_in, (const int *)nullptr, 0, rev, b0, nb);
+        }
+        if (fold) {
+            if (do_pass) h->flush_dir ^= 1;
+            h->cur_set ^= 1;
+            h->pending = 0;
+        }
+    }
+    for (int g = 1; g < ng; g++) {
+        if ((e = hipEventRecord(h->ev_join[g], h->s_grp[g])) != hipSuccess) return set_error(EKF_ERR_HIP, hipGetErrorString(e));
+        if ((e = hipStreamWaitEvent(h->s_chain, h->ev_join[g], 0)) != hipSuccess) return set_error(EKF_ERR_HIP, hipGetErrorString(e));
+    }
+    return check_launch();
 }
 
 static void bump_bound(ekf_batch *h, int measurements) {

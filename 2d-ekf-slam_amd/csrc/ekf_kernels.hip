@@ -1490,17 +1490,19 @@ __device__ __forceinline__ void flush_tile_rb(const double *tp, double *tq, cons
 // filter b have id mod 8 = b mod 8, i.e. run on one XCD: a filter's slot operands are then fetched into ONE L2 instead
 // of eight (for 256 x N=256 the eightfold operand fetch was as large as the tile traffic itself).
 __global__ __launch_bounds__(256, 2) void k_flush_rb(EkfDev dv, int nT_hi, int set, int nslots, int buf, int buf_out, const int *tile_map,
-                                                     int wgs_per_filter, int reverse) {
+                                                     int wgs_per_filter, int reverse, int b_off, int nb) {
     // reverse: the grid walks the tiles (and filters) last to first.  Passes alternate direction, so a pass starts on the
     // tiles the previous one touched last -- the part of P_LL that is still in the 256 MB Infinity Cache.
+    // b_off, nb: the launch covers filters [b_off, b_off + nb) of the batch (phase groups of one-workgroup filters; else 0, B).
     const int bx = reverse ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;
     int b = reverse ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y, wg = bx;
     if (wgs_per_filter > 0) {
         const int per_group = 8 * wgs_per_filter, grp = bx / per_group, r = bx % per_group;
         b = grp * 8 + (r & 7);
         wg = r >> 3;
-        if (b >= dv.B) return;
+        if (b >= nb) return;
     }
+    b += b_off;
     int lane = threadIdx.x & 63;
     int u = wg * 4 + (threadIdx.x >> 6);
     int I, J;
@@ -1658,6 +1660,14 @@ __global__ void k_probe_set(int *flag) {
 // stored behind a dense pass on its stream: the pass's writes are in memory (kernel boundary) before the flag is
 __global__ void k_mark(int *flag, int value) {
     if (threadIdx.x == 0) __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Holds a stream for `ticks` of the 100 MHz wall clock: the phase shift between the groups of a batch of one-workgroup filters.
+__global__ void k_delay(long long ticks) {
+    if (threadIdx.x == 0) {
+        const long long t0 = (long long)wall_clock64();
+        while ((long long)wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+    }
 }
 
 __global__ void k_advance(int *cursor, int by) {

@@ -1,0 +1,682 @@
+// ekf_solo.hip -- k_solo: the sequential part of the hot path for filters that fit ONE workgroup (maps of up to 256
+// landmarks: every filter of the Monte-Carlo batches of BASELINE.json configs 4 and 5, config 1, small single maps).
+//
+// Same operations, same data layout, same results as k_chain (ekf_kernels.hip) -- Propagate (odometry/Propagate.cpp:15-75),
+// association sweep, gate, Old / New / Ignore branches of Update (odometry/Update.cpp:80-194), compass
+// (odometry/kalmanfilter.cpp:96-130) -- but organised for what one workgroup is: latency-bound at one wave per SIMD, so that
+// independent instruction streams in the SAME wave are free and barriers are what costs.
+//   * one landmark per thread, in registers for the whole launch (written back to x, R, D once, at the end); no control wave: EVERY thread carries the robot block
+//     (pose, cos/sin, P_RR) in registers and advances it itself -- the same instructions on the same inputs in every lane, so all
+//     copies stay bitwise equal -- which removes the control lane's serial section, the double-buffered robot state in LDS and
+//     every barrier that handed it over;
+//   * ONE workgroup barrier per measurement (the arg-min over the waves).  Each wave's winner lane leaves its winner record
+//     beside its candidate before that barrier; behind it every thread picks the winner, evaluates the gate and goes on alone.
+//     The 2x2 matrices of the unflushed slots (M = -S K_lo^T) are built per wave, by 16 lanes, into the wave's own LDS strip
+//     and read back by the same wave (LDS operations of a wave execute in order): no barrier there either.  Candidates and
+//     records are double-buffered by measurement parity: a wave can be at most one measurement ahead of the slowest one;
+//   * New, Ignore and compass headers are computed by every thread as well: no header hand-off.
+// Everything else -- slots, the own-row cache, the hand-scheduled fold, the fragment-major P_LL reads -- is k_chain's.
+#include "ekf_device.h"
+
+struct SoloLds {
+    ekf_stats st;
+    long long log_count;
+    ekf_decision dec_buf[EKF_CHAIN_MAX_OPS];
+    int n_dec;
+    // per measurement parity, per wave: arg-min candidate and the winner record res(2) S00,S01,S11 hcol(2) P_R,Lo(6) D(3)
+    double wd[2][4];
+    int wi[2][4];
+    double wcand[2][4][16];
+    SlotMeta sm[EKF_MAX_PENDING];
+    // per wave: the matched landmark's cached rows of every open slot and the slot's 2x2 matrix M (k_chain: loC / loM)
+    alignas(16) double loC[4][EKF_MAX_PENDING * 4];
+    alignas(16) double loM[4][EKF_MAX_PENDING * 4];
+};
+
+struct SoloRobot {  // the robot block as every thread holds it
+    double pose[3];
+    double c, s;
+    double Prr[9];
+};
+
+// robot block of Propagate.cpp:15-75; rec = (v, w, dt, q00, q10, q01, q11) -- expression for expression k_chain's propagate_robot
+__device__ __forceinline__ void solo_propagate_robot(SoloRobot &rb, const double *rec) {
+    const double v = rec[0], w = rec[1], dt = rec[2];
+    const double so = rb.s, co = rb.c;
+    const double pa = -dt * v * so, pb = dt * v * co;  // Phi_R = [[1,0,pa],[0,1,pb],[0,0,1]], :42-44
+    double Q[4] = {rec[3], rec[5], rec[4], rec[6]};    // row-major from column-major
+    double Prr[9], pose[3];
+#pragma unroll
+    for (int i = 0; i < 9; i++) Prr[i] = rb.Prr[i];
+#pragma unroll
+    for (int i = 0; i < 3; i++) pose[i] = rb.pose[i];
+    rb.pose[0] = pose[0] + dt * (v * co);  // :33-38
+    rb.pose[1] = pose[1] + dt * (v * so);
+    rb.pose[2] = pose[2] + dt * w;
+    double Phi[9] = {1, 0, pa, 0, 1, pb, 0, 0, 1};
+    double Gm[6] = {-dt * co, 0, -dt * so, 0, 0, -dt};  // :46-48
+    double t1[9], t2[9], GQ[6], Pn[9];
+    // (Phi * P_RR) * Phi^T + (G * Q) * G^T, :53
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) t1[i * 3 + j] = Phi[i * 3] * Prr[j] + Phi[i * 3 + 1] * Prr[3 + j] + Phi[i * 3 + 2] * Prr[6 + j];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) t2[i * 3 + j] = t1[i * 3] * Phi[j * 3] + t1[i * 3 + 1] * Phi[j * 3 + 1] + t1[i * 3 + 2] * Phi[j * 3 + 2];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) GQ[i * 2 + j] = Gm[i * 2] * Q[j] + Gm[i * 2 + 1] * Q[2 + j];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) Pn[i * 3 + j] = t2[i * 3 + j] + (GQ[i * 2] * Gm[j * 2] + GQ[i * 2 + 1] * Gm[j * 2 + 1]);
+    // 0.5 (P + P^T), :66-67 (a no-op outside this block: P enters bitwise symmetric)
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) rb.Prr[i * 3 + j] = 0.5 * (Pn[i * 3 + j] + Pn[j * 3 + i]);
+    sincos(rb.pose[2], &rb.s, &rb.c);
+}
+
+// NEES sample e^T P_RR^-1 e against rec = (x, y, phi) (thread 0)
+__device__ __forceinline__ void solo_nees_sample(const SoloRobot &R, const double *rec, ekf_stats &st) {
+    double e0 = R.pose[0] - rec[0], e1 = R.pose[1] - rec[1], e2 = R.pose[2] - rec[2];
+    e2 -= 6.283185307179586 * floor((e2 + 3.141592653589793) / 6.283185307179586);
+    double a = R.Prr[0], bb = R.Prr[1], c = R.Prr[2], d = R.Prr[4], e = R.Prr[5], f = R.Prr[8];
+    double A = d * f - e * e, Bc = c * e - bb * f, Cc = bb * e - c * d;
+    double det = a * A + bb * Bc + c * Cc;
+    double Dd = a * f - c * c, Ee = bb * c - a * e, Ff = a * d - bb * bb;
+    double q = e0 * (A * e0 + Bc * e1 + Cc * e2) + e1 * (Bc * e0 + Dd * e1 + Ee * e2) + e2 * (Cc * e0 + Ee * e1 + Ff * e2);
+    double nees = q / det;
+    if (det > 0.0 && nees >= 0.0 && nees < EKF_INF) {  // a fresh filter has P_RR = 0: no sample then
+        st.nees_sum += nees;
+        st.nees_count++;
+    }
+}
+
+// grid (1, filters of the launch), blockDim = 64 * ceil(capacity / 64) <= 256 threads; arguments as k_chain's (segments with
+// n_prev = 0, need_pass = 0, drop = 0: one slot set, dense passes in place between the launches that fill a window).
+__global__ __launch_bounds__(256) void k_solo(EkfDev dv, const double *in, const int *cursor, ChainPlan plan, int b_off) {
+    __shared__ SoloLds L;
+    __shared__ double recs[EKF_CHAIN_MAX_OPS * 8];
+    extern __shared__ __attribute__((aligned(16))) double own_rows[];  // own-row cache, layout as in k_chain: [chunk of 64][slot][plane][lane][2]
+    const int b = blockIdx.y + b_off;
+    const int tid = threadIdx.x, bd = blockDim.x;
+    const int wave = uni(tid >> 6), nwaves = bd >> 6, lane = tid & 63;
+    const int lm0 = tid;  // this thread's landmark
+    const int xs = dv.xs;
+    double *x = dv.x + (size_t)b * xs;
+    double *R0 = dv.R + (size_t)b * 3 * xs;
+    double *Dx = dv.D + (size_t)b * 3 * dv.dn;
+    const double *FAb = dv.FA + (size_t)b * 2 * dv.f_stride, *FBb = dv.FB + (size_t)b * 2 * dv.f_stride;
+    const int vs_cap = dv.vs_cap;
+    auto own_at = [=](int vs, int cmp, int ll) { return (((ll >> 6) * vs_cap + vs) * 2 + (cmp >> 1)) * 128 + (ll & 63) * 2 + (cmp & 1); };
+    const int T_ = dv.T, rows_ = dv.rows, dn_ = dv.dn;
+
+    typedef __attribute__((address_space(4))) const ChainSeg *SegPtr;
+    const SegPtr segs = (SegPtr)((__attribute__((address_space(4))) const char *)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(ChainKArgs, plan) + offsetof(ChainPlan, s));
+    const int nseg = plan.nseg;
+    const long long last_seq = segs[nseg - 1].seq;
+
+    // state that lives across the segments of the launch
+    unsigned long long new_mask = 0;  // slots of the open window that appended a landmark
+    LmState r0 = {0, 0, {0, 0, 0, 0, 0, 0}, 0, 0, 0};
+    SoloRobot rb;
+    int n_lm = 0, n_sweep = 0;  // (uniform; kept by every thread)
+    int par = 0;                // measurement parity of the candidate buffers
+#ifdef EKF_CHAIN_STAMPS
+    // diagnostic build: thread 0 of filter 0 adds up the 100 MHz ticks of [0] everything between measurements, [1] sweep + arg-min +
+    // barrier, [2] pick + gate + slot matrices, [3] the wait for the P_LL entries, [4] fold, [5] gain + robot block, [6] emit
+    unsigned long long stamp_t;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_t)::"memory");
+    long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+
+    for (int seg = 0; seg < nseg; seg++) {
+        const int k0 = segs[seg].k0, nops = segs[seg].nops, slot0 = segs[seg].slot0, set = segs[seg].set, buf_read = segs[seg].buf_read;
+        const double *Bmr = dv.Bm[buf_read] + (size_t)b * dv.bm_stride;
+        double *FAc = dv.FA + ((size_t)b * 2 + set) * dv.f_stride;
+        double *FBc = dv.FB + ((size_t)b * 2 + set) * dv.f_stride;
+        int *act_c = dv.slot_active + ((size_t)b * 2 + set) * dv.maxp;
+        const size_t off_c = (size_t)set * dv.f_stride;
+
+        auto lm_load = [=](int lm) {
+            LmState st;
+            int Li = 3 + 2 * lm;
+            st.x0 = x[Li], st.x1 = x[Li + 1];
+#pragma unroll
+            for (int i = 0; i < 3; i++) st.rc[i * 2] = R0[(size_t)i * xs + Li], st.rc[i * 2 + 1] = R0[(size_t)i * xs + Li + 1];
+            st.dxx = Dx[lm], st.dxy = Dx[dn_ + lm], st.dyy = Dx[2 * (size_t)dn_ + lm];
+            return st;
+        };
+        auto lm_store = [=](int lm, const LmState &st) {
+            int Li = 3 + 2 * lm;
+            x[Li] = st.x0, x[Li + 1] = st.x1;
+#pragma unroll
+            for (int i = 0; i < 3; i++) R0[(size_t)i * xs + Li] = st.rc[i * 2], R0[(size_t)i * xs + Li + 1] = st.rc[i * 2 + 1];
+            Dx[lm] = st.dxx, Dx[dn_ + lm] = st.dxy, Dx[2 * (size_t)dn_ + lm] = st.dyy;
+        };
+        // P[rows of lm, columns of lo] as stored in Bm (row index = the older landmark): the loads, then the orientation
+        auto request_old_inputs = [=](int lm, int lo, double raw[4]) {
+            const bool below = lm < lo;
+            const int ri = below ? 2 * lm : 2 * lo, ci = below ? 2 * lo : 2 * lm;
+            const double *q = Bmr + bm_offset(T_, ri, ci);
+            raw[0] = q[0], raw[1] = q[2], raw[2] = q[32], raw[3] = q[34];
+        };
+        auto orient_old_inputs = [=](int lm, int lo, const double raw[4], double p[2][2]) {
+            const bool below = lm < lo;
+            p[0][0] = raw[0], p[1][1] = raw[3];
+            p[0][1] = below ? raw[1] : raw[2], p[1][0] = below ? raw[2] : raw[1];
+        };
+        // One landmark's two rows of a measurement's rank-2 slot go to the own-row cache only: K rows of an Old / compass slot (the
+        // fold needs one side, K S K^T is symmetric), P_xL rows of a New one, zeros of a dead one.  What the dense pass reads --
+        // FA = -K S and FB = K, or FA = P_xL and FB = unit rows -- is rebuilt from the cache and written to HBM once, at the end
+        // of the segment (emit below): the measurement loop then holds no global store at all, and the one dependent memory trip
+        // of a measurement (the P_LL entries of the matched landmark) never queues behind the acknowledgements of earlier stores.
+        auto cache_rows = [=](int lm, int slot, double r00, double r01, double r10, double r11) {
+            double *cr = own_rows + own_at(slot, 0, lm);
+            *(double2_t *)cr = (double2_t){r00, r01};
+            *(double2_t *)(cr + 128) = (double2_t){r10, r11};
+        };
+        // thread 0 records what kind of slot the operation leaves (HBM gets it at the end of the segment)
+        auto note_slot = [=](int slot, int type, int ln, double S00, double S01, double S11) {
+            SlotMeta m;
+            m.type = type, m.ln = ln, m.S00 = S00, m.S01 = S01, m.S11 = S11;
+            L.sm[slot] = m;
+        };
+
+        // ---- segment prologue: operation records and, for a launch that continues a window, the open slots' kinds and own rows
+        for (int q = tid; q < nops * 8; q += bd) recs[q] = op_record(in, cursor, k0 + (q >> 3), dv.B, b)[q & 7];
+        if (seg == 0) {
+            for (int q = tid; q < slot0; q += bd) L.sm[q] = dv.slot_meta[((size_t)b * 2 + set) * dv.maxp + q];
+            n_lm = dv.n_lm[b], n_sweep = dv.n_lm_sweep[b];
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                rb.pose[i] = x[i];
+#pragma unroll
+                for (int j = 0; j < 3; j++) rb.Prr[i * 3 + j] = R0[(size_t)i * xs + j];
+            }
+            sincos(rb.pose[2], &rb.s, &rb.c);
+            if (tid == 0) {
+                L.st = dv.stats[b];
+                L.log_count = dv.log_count[b];
+            }
+            if (lm0 < n_lm) r0 = lm_load(lm0);
+        }
+        if (tid == 0) L.n_dec = 0;
+        __syncthreads();
+        if (seg == 0) {
+            new_mask = 0;
+            for (int q = 0; q < slot0; q++) new_mask |= (uni(L.sm[q].type) == SLOT_NEW ? 1ull : 0ull) << q;
+            if (lm0 < n_lm)
+                for (int v0 = 0; v0 < slot0; v0 += 8) {  // eight slots per trip, every load requested before the first LDS write
+                    double2_t lo2[8], hi2[8];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const int vs = v0 + j < slot0 ? v0 + j : v0;
+                        const double *F = ((new_mask >> vs) & 1 ? FAb : FBb) + off_c + pair_offset(rows_, 2 * lm0, vs >> 1) + (vs & 1) * 2;
+                        lo2[j] = *(const double2_t *)F, hi2[j] = *(const double2_t *)(F + 4);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; j++)
+                        if (v0 + j < slot0) {
+                            double *cr = own_rows + own_at(v0 + j, 0, lm0);
+                            *(double2_t *)cr = lo2[j], *(double2_t *)(cr + 128) = hi2[j];
+                        }
+                }
+        } else if (slot0 == 0) {
+            new_mask = 0;  // a new window: no slot is open
+        }
+
+        // ---- the operation loop ------------------------------------------------------------------------------------------
+        int slot = slot0;
+        for (int op = 0; op < nops; op++) {
+            const double *rec = recs + op * 8;
+            const int type = uni((int)rec[7]);
+
+            if (type == OP_PROP) {
+                // ---- Propagate.cpp:15-75: P_RL <- Phi_R P_RL for the own landmark (:56), then the robot block -------------
+                const double pa = -rec[2] * rec[0] * rb.s, pb = rec[2] * rec[0] * rb.c;  // Phi_R = [[1,0,pa],[0,1,pb],[0,0,1]], :42-44
+                if (lm0 < n_lm) {
+#pragma unroll
+                    for (int e = 0; e < 2; e++) {
+                        r0.rc[e] = r0.rc[e] + pa * r0.rc[4 + e];
+                        r0.rc[2 + e] = r0.rc[2 + e] + pb * r0.rc[4 + e];
+                    }
+                }
+                solo_propagate_robot(rb, rec);
+                continue;
+            }
+
+            if (type == OP_TRUTH) {
+                if (tid == 0) solo_nees_sample(rb, rec, L.st);
+                continue;
+            }
+
+            if (type == OP_SKIP_SLOT) {
+                // a masked measurement: consumes its slot, changes nothing
+                if (tid == 0) note_slot(slot, SLOT_DEAD, 0, 0, 0, 0);
+                if (rec[6] == 2.0) n_sweep = n_lm;
+                if (lm0 < n_lm) cache_rows(lm0, slot, 0, 0, 0, 0);
+                slot++;
+                continue;
+            }
+
+            if (type == OP_MEAS) {
+                // ---- association sweep, Update.cpp:98-148; rec = (z0, z1, R00, R10, R01, R11, last) ----------------------
+                STAMP(0);
+                const double z0 = rec[0], z1 = rec[1];
+                const double Rm[4] = {rec[2], rec[4], rec[3], rec[5]};  // row-major R
+                const int n_lm_before = n_lm;
+                SweepBest best;
+                best.d = EKF_INF, best.lm = 0x7fffffff;
+#pragma unroll
+                for (int i = 0; i < 16; i++) best.w[i] = 0;
+                {
+                    const SweepConst kc = sweep_const(rb.c, rb.s, rb.pose[0], rb.pose[1], rb.Prr, Rm);
+                    if (lm0 < n_sweep) sweep_one(lm0, r0, z0, z1, kc, dv.cond_k2, best);  // (Update.cpp:26: n_sweep is fixed for the whole chunk)
+                }
+                double rd = best.d;
+                int ri = best.lm, rwho = 0;
+                wave_argmin(rd, ri, rwho);
+                if (lane == 0) L.wd[par][wave] = rd, L.wi[par][wave] = ri;
+                if (best.lm == ri && ri != 0x7fffffff) {  // the lane that owns the wave's winner leaves its record
+#pragma unroll
+                    for (int i = 0; i < 16; i++) L.wcand[par][wave][i] = best.w[i];
+                }
+                __syncthreads();  // the one barrier of a measurement
+                STAMP(1);
+                double gd = L.wd[par][0];
+                int gi = L.wi[par][0], gw = 0;
+                for (int wv = 1; wv < nwaves; wv++)
+                    if (cand_better(L.wd[par][wv], L.wi[par][wv], gd, gi)) gd = L.wd[par][wv], gi = L.wi[par][wv], gw = wv;
+                gi = uni(gi), gw = uni(gw);
+                const double *wrec = L.wcand[par][gw];
+                par ^= 1;
+                // ---- gate, Update.cpp:152,181,191: a pure function of the winner, evaluated by every thread -------------
+                const int w_lo = gi;
+                const bool have = (w_lo != 0x7fffffff);
+                const double mahal = have ? gd : EKF_INF;
+                int hdr;
+                if (!have || mahal > dv.gamma_max) hdr = (n_lm_before >= dv.Ncap) ? HDR_NEW_NOFIT : HDR_NEW;  // :152
+                else if (mahal < dv.gamma_min) hdr = HDR_OLD;                                                // :181
+                else hdr = HDR_IGNORE;                                                                         // :191
+                hdr = uni(hdr);
+                if (tid == 0) {
+                    ekf_stats *st = &L.st;
+                    if (hdr == HDR_OLD) {
+                        st->n_old++;
+                        st->nis_sum += mahal;
+                        st->nis_count++;
+                    } else if (hdr == HDR_IGNORE) {
+                        st->n_ignore++;
+                    } else {
+                        st->n_new++;
+                        if (hdr == HDR_NEW_NOFIT) dv.status[b] = EKF_ERR_CAPACITY;
+                    }
+                    long long cnt = L.log_count;
+                    ekf_decision e;
+                    e.decision = hdr == HDR_OLD ? EKF_DECISION_OLD : (hdr == HDR_IGNORE ? EKF_DECISION_IGNORE : EKF_DECISION_NEW);
+                    e.matched = have ? 3 + 2 * w_lo : 0;
+                    e.mahal = mahal;
+                    L.dec_buf[L.n_dec++] = e;
+                    L.log_count = cnt + 1;
+                }
+
+                if (hdr == HDR_OLD) {
+                    // ---- Old, Update.cpp:181-189 ----------------------------------------------------------------------------
+                    const bool active = lm0 < n_lm_before;
+                    double pf_raw[4] = {0, 0, 0, 0};
+                    if (active && lm0 != w_lo) request_old_inputs(lm0, w_lo, pf_raw);  // in flight under everything up to the gain
+                    double wv[16];
+#pragma unroll
+                    for (int i = 0; i < 16; i++) wv[i] = wrec[i];
+                    // the matched landmark's cached rows of every open slot -> the wave's loC, and from them the slot's 2x2 matrix M
+                    // -> the wave's loM (P[own rows, matched columns] += own cached rows * M; Old: M = -S K_lo^T; New: identity
+                    // when the matched landmark is the new one): lanes 0..slot-1 of EVERY wave, read back by the same wave
+                    const int nvs = slot;
+                    double *wC = L.loC[wave], *wM = L.loM[wave];
+                    if (lane < nvs) {
+                        double c4[4];
+#pragma unroll
+                        for (int j = 0; j < 4; j++) c4[j] = own_rows[own_at(lane, j, w_lo)];
+                        const SlotMeta m = L.sm[lane];
+                        double M[4] = {0, 0, 0, 0};  // M[k*2+e]
+                        if (m.type == SLOT_OLD) {   // -S K_lo^T, K_lo rows e = c4[2e], c4[2e+1]
+                            M[0] = -(m.S00 * c4[0] + m.S01 * c4[1]), M[1] = -(m.S00 * c4[2] + m.S01 * c4[3]);
+                            M[2] = -(m.S01 * c4[0] + m.S11 * c4[1]), M[3] = -(m.S01 * c4[2] + m.S11 * c4[3]);
+                        } else if (m.type == SLOT_NEW && m.ln == w_lo) {
+                            M[0] = 1.0, M[3] = 1.0;
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; j++) wC[lane * 4 + j] = c4[j], wM[lane * 4 + j] = M[j];
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (LDS operations of one wave execute in order; this keeps the compiler from moving them)
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    STAMP(2);
+#ifdef EKF_CHAIN_STAMPS
+                    asm volatile("" ::"v"(pf_raw[0]), "v"(pf_raw[1]), "v"(pf_raw[2]), "v"(pf_raw[3]));  // (forces the wait for the loads)
+                    STAMP(3);
+#endif
+                    const OldHdr h = old_header(rb.c, rb.s, wv);
+                    // rows 0..2 of K and of T = K S (Update.cpp:186): for the robot block, and for the robot rows of the own landmark
+                    double KR[6], TR[6];
+#pragma unroll
+                    for (int r = 0; r < 3; r++) old_robot_row(h, rb.Prr + 3 * r, wv[7 + 2 * r], wv[8 + 2 * r], KR[r * 2], KR[r * 2 + 1], TR[r * 2], TR[r * 2 + 1]);
+                    if (active) {
+                        double p[2][2] = {{0, 0}, {0, 0}};
+                        if (lm0 == w_lo) {
+                            p[0][0] = r0.dxx, p[0][1] = r0.dxy, p[1][0] = r0.dxy, p[1][1] = r0.dyy;
+                        } else {
+                            // the unflushed slots are not in Bm yet: P[lm rows, lo cols] += (own cached rows) * M_slot
+                            double pe[2][2] = {{0, 0}, {0, 0}};
+                            if (nvs > 0) {  // (uniform)
+                                unsigned a0 = lds_off(own_rows + own_at(0, 0, lm0)), am = lds_off(wM);
+                                int n = uni(nvs);
+                                asm volatile(FOLD_ASM
+                                             : [p00] "+v"(pe[0][0]), [p01] "+v"(pe[0][1]), [p10] "+v"(pe[1][0]), [p11] "+v"(pe[1][1]), [a0] "+v"(a0), [am] "+v"(am), [n] "+s"(n)
+                                             :
+                                             : FOLD_CLOBBERS);
+                            }
+                            // a landmark appended in one of these slots holds its column pair in the OTHER landmarks' rows
+                            for (unsigned long long nm = new_mask; nm; nm &= nm - 1) {
+                                const int vs = __builtin_ctzll(nm);
+                                if (uni(L.sm[vs].ln) == lm0) {
+                                    const double *c = wC + vs * 4;  // rows e of the matched landmark, components k of the new one
+                                    pe[0][0] += c[0], pe[0][1] += c[2], pe[1][0] += c[1], pe[1][1] += c[3];
+                                }
+                            }
+                            orient_old_inputs(lm0, w_lo, pf_raw, p);
+#pragma unroll
+                            for (int a = 0; a < 2; a++)
+#pragma unroll
+                                for (int e = 0; e < 2; e++) p[a][e] += pe[a][e];
+#ifdef EKF_CHAIN_STAMPS
+                            asm volatile("" ::"v"(p[0][0]), "v"(p[0][1]), "v"(p[1][0]), "v"(p[1][1]));
+                            STAMP(4);
+#endif
+                        }
+                        // gain rows of the own landmark, x, robot rows and own block of P, the slot (k_chain: apply_old)
+                        const double c = h.c, s = h.s;
+                        const double HRt[6] = {-c, s, -s, -c, h.h0, h.h1};  // rows of H_R^T
+                        double K[2][2], Tt[2][2];
+#pragma unroll
+                        for (int a = 0; a < 2; a++) {
+                            double u0 = 0, u1 = 0;
+#pragma unroll
+                            for (int q = 0; q < 3; q++) {  // P[i,0:3] H_R^T, Update.cpp:186
+                                double pr = r0.rc[q * 2 + a];
+                                u0 += pr * HRt[q * 2];
+                                u1 += pr * HRt[q * 2 + 1];
+                            }
+                            double w0 = p[a][0] * c + p[a][1] * s, w1 = p[a][0] * (-s) + p[a][1] * c;  // P[i,Lo:Lo+2] H_Li^T
+                            double s0 = u0 + w0, s1 = u1 + w1;
+                            K[a][0] = s0 * h.Si00 + s1 * h.Si01;
+                            K[a][1] = s0 * h.Si01 + s1 * h.Si11;
+                            Tt[a][0] = K[a][0] * h.S00 + K[a][1] * h.S01;
+                            Tt[a][1] = K[a][0] * h.S01 + K[a][1] * h.S11;
+                        }
+                        r0.x0 = r0.x0 + (K[0][0] * h.res0 + K[0][1] * h.res1);  // x += K res (Update.cpp:187)
+                        r0.x1 = r0.x1 + (K[1][0] * h.res0 + K[1][1] * h.res1);
+#pragma unroll
+                        for (int r = 0; r < 3; r++)
+#pragma unroll
+                            for (int a = 0; a < 2; a++) r0.rc[r * 2 + a] -= sym_u(TR[r * 2], TR[r * 2 + 1], KR[r * 2], KR[r * 2 + 1], Tt[a][0], Tt[a][1], K[a][0], K[a][1]);
+                        r0.dxx -= sym_u(Tt[0][0], Tt[0][1], K[0][0], K[0][1], Tt[0][0], Tt[0][1], K[0][0], K[0][1]);
+                        r0.dxy -= sym_u(Tt[0][0], Tt[0][1], K[0][0], K[0][1], Tt[1][0], Tt[1][1], K[1][0], K[1][1]);
+                        r0.dyy -= sym_u(Tt[1][0], Tt[1][1], K[1][0], K[1][1], Tt[1][0], Tt[1][1], K[1][0], K[1][1]);
+                        // slot: P_LL -= T K^T (rank 2; K S K^T is symmetric, only one triangle is stored): A = -T = -K S, B = K
+                        cache_rows(lm0, slot, K[0][0], K[0][1], K[1][0], K[1][1]);
+                    }
+                    // robot block, by every thread: x_R += K_R res (:187), P_RR -= sym(K_R S K_R^T) (:188,193-194)
+                    {
+                        double pose_n[3], Pn[9];
+#pragma unroll
+                        for (int r = 0; r < 3; r++) pose_n[r] = rb.pose[r] + (KR[r * 2] * h.res0 + KR[r * 2 + 1] * h.res1);
+#pragma unroll
+                        for (int r = 0; r < 3; r++)
+#pragma unroll
+                            for (int q = r; q < 3; q++) {
+                                double u = sym_u(TR[r * 2], TR[r * 2 + 1], KR[r * 2], KR[r * 2 + 1], TR[q * 2], TR[q * 2 + 1], KR[q * 2], KR[q * 2 + 1]);
+                                double nv = rb.Prr[r * 3 + q] - u;
+                                Pn[r * 3 + q] = nv;
+                                Pn[q * 3 + r] = nv;
+                            }
+#pragma unroll
+                        for (int r = 0; r < 3; r++) rb.pose[r] = pose_n[r];
+#pragma unroll
+                        for (int i = 0; i < 9; i++) rb.Prr[i] = Pn[i];
+                        sincos(rb.pose[2], &rb.s, &rb.c);
+                    }
+                    if (rec[6] == 2.0) n_sweep = n_lm_before;  // last measurement of the chunk
+                    if (tid == 0) note_slot(slot, SLOT_OLD, 0, h.S00, h.S01, h.S11);
+#ifdef EKF_CHAIN_STAMPS
+                    asm volatile("" ::"v"(rb.c), "v"(rb.s), "v"(r0.dxx));
+                    STAMP(5);
+#endif
+                } else if (hdr == HDR_NEW) {
+                    // ---- New, Update.cpp:152-178: the header by every thread, then the own landmark's share --------------------
+                    const int ln = n_lm_before;
+                    const double c = rb.c, s = rb.s, px = rb.pose[0], py = rb.pose[1];
+                    double nl0 = px + (c * z0 - s * z1), nl1 = py + (s * z0 + c * z1);  // :155
+                    double dp0 = nl0 - px, dp1 = nl1 - py;
+                    double h0 = -s * dp0 + c * dp1, h1 = -c * dp0 - s * dp1;  // :166
+                    double HR[6] = {-c, -s, h0, s, -c, h1};
+                    if (lm0 < ln) {
+                        // an existing landmark: its slot rows carry the new covariance column pair, ((-P[i,0:3]) H_R^T) H_Li (:169)
+                        double v[2][2];
+#pragma unroll
+                        for (int a = 0; a < 2; a++) {
+                            double u0 = 0, u1 = 0;
+#pragma unroll
+                            for (int q = 0; q < 3; q++) {
+                                double pr = -r0.rc[q * 2 + a];
+                                u0 += pr * HR[q];
+                                u1 += pr * HR[3 + q];
+                            }
+                            v[a][0] = u0 * c + u1 * (-s);
+                            v[a][1] = u0 * s + u1 * c;
+                        }
+                        cache_rows(lm0, slot, v[0][0], v[0][1], v[1][0], v[1][1]);  // A = P_xL rows, B = 0
+                    } else if (lm0 == ln) {
+                        // the appended landmark itself (ln < capacity <= blockDim): state and blocks from the header, unit B rows
+                        double M[4];  // H_R P_RR H_R^T + R
+#pragma unroll
+                        for (int i = 0; i < 2; i++)
+#pragma unroll
+                            for (int j = 0; j < 2; j++) {
+                                double t = 0;
+#pragma unroll
+                                for (int q = 0; q < 3; q++) {
+                                    double hp = HR[i * 3] * rb.Prr[q] + HR[i * 3 + 1] * rb.Prr[3 + q] + HR[i * 3 + 2] * rb.Prr[6 + q];
+                                    t += hp * HR[j * 3 + q];
+                                }
+                                M[i * 2 + j] = t + Rm[i * 2 + j];
+                            }
+                        // P_LiLi = H_Li^T M H_Li = C M C^T (:168)
+                        double Cm[4] = {c, -s, s, c}, CM[4], Pl[4];
+#pragma unroll
+                        for (int i = 0; i < 2; i++)
+#pragma unroll
+                            for (int j = 0; j < 2; j++) CM[i * 2 + j] = Cm[i * 2] * M[j] + Cm[i * 2 + 1] * M[2 + j];
+#pragma unroll
+                        for (int i = 0; i < 2; i++)
+#pragma unroll
+                            for (int j = 0; j < 2; j++) Pl[i * 2 + j] = CM[i * 2] * Cm[j * 2] + CM[i * 2 + 1] * Cm[j * 2 + 1];
+                        r0.dxx = Pl[0];
+                        r0.dxy = 0.5 * (Pl[1] + Pl[2]);  // the 0.5 (P + P^T) of :193-194
+                        r0.dyy = Pl[3];
+                        // P_RLi rows 0..2 = ((-P_RR) H_R^T) H_Li (:169)
+#pragma unroll
+                        for (int r = 0; r < 3; r++) {
+                            double u0 = 0, u1 = 0;
+#pragma unroll
+                            for (int q = 0; q < 3; q++) {
+                                u0 += (-rb.Prr[r * 3 + q]) * HR[q];
+                                u1 += (-rb.Prr[r * 3 + q]) * HR[3 + q];
+                            }
+                            r0.rc[r * 2] = u0 * c + u1 * (-s);  // H_Li = C^T: [[c, s], [-s, c]]
+                            r0.rc[r * 2 + 1] = u0 * s + u1 * c;
+                        }
+                        r0.x0 = nl0, r0.x1 = nl1;
+                        for (int sl = 0; sl < slot; sl++)  // the landmark did not exist in the earlier slots of the open window
+#pragma unroll
+                            for (int cmp = 0; cmp < 4; cmp++) own_rows[own_at(sl, cmp, lm0)] = 0.0;
+                        cache_rows(lm0, slot, 0, 0, 0, 0);  // A = 0 (its own P_xL rows are zero: the 2x2 block lives in D), B = unit rows
+                    }
+                    n_lm = n_lm_before + 1;
+                    if (rec[6] == 2.0) n_sweep = n_lm;
+                    new_mask |= 1ull << slot;
+                    if (tid == 0) note_slot(slot, SLOT_NEW, ln, 0, 0, 0);
+                } else {
+                    // ---- Ignore (:191), no room: the slot changes nothing -------------------------------------------------------
+                    if (lm0 < n_lm_before) cache_rows(lm0, slot, 0, 0, 0, 0);
+                    if (rec[6] == 2.0) n_sweep = n_lm_before;
+                    if (tid == 0) note_slot(slot, SLOT_DEAD, n_lm_before, 0, 0, 0);
+                }
+                slot++;
+                continue;
+            }
+
+            if (type == OP_COMPASS) {
+                // ---- kalmanfilter.cpp:96-130; rec = (z, R): header by every thread ---------------------------------------------
+                double z = rec[0], Rc = rec[1];
+                double z_hat = rb.pose[2];
+                z_hat -= 6.283185307 * floor(z_hat / 6.283185307);  // :98-99
+                double res1 = z - z_hat, res2 = z - 6.283185307 - z_hat, res3 = z + 6.283185307 - z_hat;
+                double res;
+                if ((fabs(res1) <= fabs(res2)) && (fabs(res1) <= fabs(res3))) res = res1;  // :108-110
+                else if (fabs(res2) <= fabs(res3)) res = res2;
+                else res = res3;
+                double S = rb.Prr[8] + Rc;  // :114
+                double invS = 1 / S;
+                double KR[3], TR[3];
+#pragma unroll
+                for (int r = 0; r < 3; r++) {
+                    KR[r] = invS * rb.Prr[r * 3 + 2];  // :118
+                    TR[r] = S * KR[r];
+                }
+                if (lm0 < n_lm) {  // K = (1/S) P[:,2] for the own landmark (k_chain: apply_compass)
+                    double K[2], Tt[2];
+#pragma unroll
+                    for (int a = 0; a < 2; a++) {
+                        K[a] = invS * r0.rc[4 + a];
+                        Tt[a] = S * K[a];
+                    }
+                    r0.x0 = r0.x0 + (K[0] * res + 0.0 * 0.0);  // :121 (second column of K is zero)
+                    r0.x1 = r0.x1 + (K[1] * res + 0.0 * 0.0);
+#pragma unroll
+                    for (int r = 0; r < 3; r++)
+#pragma unroll
+                        for (int a = 0; a < 2; a++) r0.rc[r * 2 + a] -= sym_u(TR[r], 0, KR[r], 0, Tt[a], 0, K[a], 0);
+                    r0.dxx -= sym_u(Tt[0], 0, K[0], 0, Tt[0], 0, K[0], 0);
+                    r0.dxy -= sym_u(Tt[0], 0, K[0], 0, Tt[1], 0, K[1], 0);
+                    r0.dyy -= sym_u(Tt[1], 0, K[1], 0, Tt[1], 0, K[1], 0);
+                    cache_rows(lm0, slot, K[0], 0, K[1], 0);  // A = -K S, B = K with a zero second column
+                }
+                {
+                    double pose_n[3], Pn[9];
+#pragma unroll
+                    for (int r = 0; r < 3; r++) pose_n[r] = rb.pose[r] + res * KR[r];  // :121
+#pragma unroll
+                    for (int r = 0; r < 3; r++)
+#pragma unroll
+                        for (int q = r; q < 3; q++) {  // :122-124
+                            double nv = rb.Prr[r * 3 + q] - sym_u(TR[r], 0, KR[r], 0, TR[q], 0, KR[q], 0);
+                            Pn[r * 3 + q] = nv;
+                            Pn[q * 3 + r] = nv;
+                        }
+#pragma unroll
+                    for (int r = 0; r < 3; r++) rb.pose[r] = pose_n[r];
+#pragma unroll
+                    for (int i = 0; i < 9; i++) rb.Prr[i] = Pn[i];
+                    sincos(rb.pose[2], &rb.s, &rb.c);
+                }
+                if (tid == 0) note_slot(slot, SLOT_OLD, 0, S, 0, 0);  // K's second column is zero
+                slot++;
+                continue;
+            }
+            // OP_NOP
+        }
+
+        // ---- segment epilogue: what the set's dense pass and later launches read; the host mirror at the end of the launch ----
+        __syncthreads();  // (the slot kinds, thread 0's statistics and decisions are complete; the next segment's records may overwrite recs)
+        // emit: the rows of the slots this segment filled, rebuilt from the own-row cache, as the dense pass reads them -- two
+        // slots share one 64-byte row (slot 2p in [0..1], slot 2p+1 in [2..3]); a pair that is complete goes out as whole rows
+        if (lm0 < n_lm)
+            for (int p = slot0 >> 1; 2 * p < slot; p++) {
+#pragma clang fp contract(off)
+                double a[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, bq[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+                const bool in0 = 2 * p >= slot0, in1 = 2 * p + 1 < slot;
+#pragma unroll
+                for (int hh = 0; hh < 2; hh++) {
+                    const int sl = 2 * p + hh;
+                    if (hh == 0 ? in0 : in1) {
+                        const double2_t c01 = *(const double2_t *)(own_rows + own_at(sl, 0, lm0)), c23 = *(const double2_t *)(own_rows + own_at(sl, 2, lm0));
+                        const SlotMeta m = L.sm[sl];
+                        if (uni(m.type) == SLOT_OLD) {  // A = -(K S), B = K
+                            bq[hh][0] = c01.x, bq[hh][1] = c01.y, bq[hh][2] = c23.x, bq[hh][3] = c23.y;
+                            a[hh][0] = -(c01.x * m.S00 + c01.y * m.S01), a[hh][1] = -(c01.x * m.S01 + c01.y * m.S11);
+                            a[hh][2] = -(c23.x * m.S00 + c23.y * m.S01), a[hh][3] = -(c23.x * m.S01 + c23.y * m.S11);
+                        } else if (uni(m.type) == SLOT_NEW) {  // A = P_xL rows, B = unit rows at the appended landmark
+                            a[hh][0] = c01.x, a[hh][1] = c01.y, a[hh][2] = c23.x, a[hh][3] = c23.y;
+                            if (m.ln == lm0) bq[hh][0] = 1.0, bq[hh][3] = 1.0;
+                        }
+                    }
+                }
+                double *fa = FAc + pair_offset(rows_, 2 * lm0, p), *fb = FBc + pair_offset(rows_, 2 * lm0, p);
+                if (in0) {  // (the partner's half: its rows, or zeros while it has not been filled)
+                    *(double4_t *)fa = (double4_t){a[0][0], a[0][1], a[1][0], a[1][1]};
+                    *(double4_t *)(fa + 4) = (double4_t){a[0][2], a[0][3], a[1][2], a[1][3]};
+                    *(double4_t *)fb = (double4_t){bq[0][0], bq[0][1], bq[1][0], bq[1][1]};
+                    *(double4_t *)(fb + 4) = (double4_t){bq[0][2], bq[0][3], bq[1][2], bq[1][3]};
+                } else {    // (slot 2p was filled by an earlier launch)
+                    *(double2_t *)(fa + 2) = (double2_t){a[1][0], a[1][1]};
+                    *(double2_t *)(fa + 6) = (double2_t){a[1][2], a[1][3]};
+                    *(double2_t *)(fb + 2) = (double2_t){bq[1][0], bq[1][1]};
+                    *(double2_t *)(fb + 6) = (double2_t){bq[1][2], bq[1][3]};
+                }
+            }
+        STAMP(6);
+#ifdef EKF_CHAIN_STAMPS
+        if (tid == 0 && b == 0)
+            for (int i = 0; i < 8; i++) dv.dbg[i] += stamp_acc[i], stamp_acc[i] = 0;
+#endif
+        if (seg + 1 == nseg && lm0 < n_lm) lm_store(lm0, r0);  // the landmark lived in registers for the whole launch: x, its P_RL columns and its 2x2 block go back once
+        if (tid == 0) {
+            for (int sl = slot0; sl < slot; sl++) {
+                act_c[sl] = L.sm[sl].type != SLOT_DEAD ? 1 : 0;
+                dv.slot_meta[((size_t)b * 2 + set) * dv.maxp + sl] = L.sm[sl];
+            }
+            for (int i = 0; i < L.n_dec; i++) dv.log[(size_t)b * dv.logcap + ((L.log_count - L.n_dec + i) % dv.logcap)] = L.dec_buf[i];
+            dv.n_lm_flush[(size_t)b * 2 + set] = n_lm;
+            if (seg + 1 == nseg) {
+                EkfMirror *mr = dv.mirror + b;
+                for (int i = 0; i < L.n_dec; i++) mr->last[(L.log_count - L.n_dec + i) % EKF_MIRROR_DECISIONS] = L.dec_buf[i];
+                for (int i = 0; i < 3; i++) {
+                    x[i] = rb.pose[i];
+                    for (int j = 0; j < 3; j++) R0[(size_t)i * xs + j] = rb.Prr[i * 3 + j];
+                }
+                dv.n_lm[b] = n_lm;
+                dv.n_lm_sweep[b] = n_sweep;
+                for (int i = 0; i < 3; i++) mr->pose[i] = rb.pose[i];
+                mr->n_lm = n_lm;
+                dv.stats[b] = L.st;
+                mr->stats = L.st;
+                dv.log_count[b] = L.log_count;
+                mr->status = dv.status[b];
+                mr->log_count = L.log_count;
+                // everything above is in host memory before the sequence number is: a host thread spinning on seq reads a complete mirror
+                __atomic_thread_fence(__ATOMIC_RELEASE);
+                __hip_atomic_store(&mr->seq, last_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            } else {
+                EkfMirror *mr = dv.mirror + b;
+                for (int i = 0; i < L.n_dec; i++) mr->last[(L.log_count - L.n_dec + i) % EKF_MIRROR_DECISIONS] = L.dec_buf[i];
+            }
+        }
+        if (seg + 1 < nseg) __syncthreads();
+    }
+}
