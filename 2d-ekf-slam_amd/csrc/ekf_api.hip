@@ -63,8 +63,9 @@ struct ekf_batch {
     long long chain_seq;  // chain launches so far; the kernel stores it into the host mirror when it is done
     int ncu = 0;                            // CUs of the device
     bool persist = true;                    // scripted runs in overlap mode: one chain launch for several windows (EKF_PERSIST=0 switches it off)
-    unsigned long long seg_count_base = 0;  // value dv.seg_count reaches when every multi-segment launch enqueued so far has finished
-    unsigned long long open_set_gate = 0;   // != 0: the open set was filled by that segment of a multi-segment launch (gate for its pass)
+    unsigned long long seg_count_base[EKF_PLAN_MAX] = {};  // value dv.seg_count[i] reaches when every multi-segment launch enqueued so far has finished
+    unsigned long long open_set_gate = 0;   // != 0: the open set was filled by segment open_gate_idx of a multi-segment launch: dv.seg_count[open_gate_idx] >= this opens its pass
+    int open_gate_idx = 0;
     bool stats_in_mirror = false;  // mirror.stats is current (a chain launch ran since the last ekf_reset_stats)
     bool mirror_by_chain; // the newest writer of the host mirror is chain launch number chain_seq (else: some other kernel, synchronise)
     int flush_keep;       // pool key of s_flush: CUs kept free for the chain, -1 = unmasked
@@ -96,8 +97,11 @@ struct ekf_batch {
     int buf_in;     // Bm buffer the chain kernels read (complete up to the sets still open or in flight)
     bool flush_alternate; // EKF_FLUSH_ALTERNATE (default on): dense passes walk the tiles alternately first-to-last and last-to-first
     int flush_dir;        // direction of the next dense pass (0 = first to last)
-    bool dbg_skip_flush;  // EKF_DEBUG_SKIP_FLUSH=1: timing experiments only, results are wrong
-    int dbg_drop_marks_from = 0;  // EKF_DEBUG_DROP_MARKS_FROM=k: dense passes k, k+1, ... never report completion (tests of the bounded waits)
+    // Test / experiment hooks.  They exist only in the debug variant of the library (make debug: -DEKF_DEBUG_HOOKS,
+    // libekfslam_hip_debug.so); in the product build the fields keep these values and no environment variable can change them.
+    bool dbg_skip_flush = false;        // EKF_DEBUG_SKIP_FLUSH=1: timing experiments only, results are wrong
+    int dbg_drop_marks_from = 0;        // EKF_DEBUG_DROP_MARKS_FROM=k (and ..._TO=m, exclusive): dense passes k .. m-1 never report completion (tests of the bounded waits)
+    int dbg_drop_marks_to = 0x7fffffff;
     // immediate-mode input ring (host-mapped pinned)
     double *ring_h;
     double *ring_d;
@@ -239,6 +243,19 @@ static int g_cus_claimed[64];
 
 static int create_impl(ekf_batch *h, int batch, int capacity_landmarks, int device_id, const ekf_params *params, const hipDeviceProp_t &prop);
 
+// The debug variant reads its hooks when a handle is created and again at ekf_set_state (a test switches them off between the
+// two); the product build compiles to nothing.
+static void read_debug_hooks(ekf_batch *h) {
+#ifdef EKF_DEBUG_HOOKS
+    h->dv.spin_limit = getenv("EKF_DEBUG_SPIN_LIMIT") ? atoll(getenv("EKF_DEBUG_SPIN_LIMIT")) : (1LL << 24);
+    h->dbg_skip_flush = getenv("EKF_DEBUG_SKIP_FLUSH") && atoi(getenv("EKF_DEBUG_SKIP_FLUSH")) != 0;
+    h->dbg_drop_marks_from = getenv("EKF_DEBUG_DROP_MARKS_FROM") ? atoi(getenv("EKF_DEBUG_DROP_MARKS_FROM")) : 0;
+    h->dbg_drop_marks_to = getenv("EKF_DEBUG_DROP_MARKS_TO") ? atoi(getenv("EKF_DEBUG_DROP_MARKS_TO")) : 0x7fffffff;
+#else
+    (void)h;
+#endif
+}
+
 extern "C" int ekf_destroy(ekf_handle h);
 
 extern "C" int ekf_batch_create(ekf_handle *out, int batch, int capacity_landmarks, int device_id, const ekf_params *params) {
@@ -295,7 +312,7 @@ static int create_impl(ekf_batch *h, int batch, int capacity_landmarks, int devi
     dv.rows = 64 * dv.T;
     dv.gamma_max = h->params.gamma_max;
     dv.gamma_min = h->params.gamma_min;
-    dv.spin_limit = getenv("EKF_DEBUG_SPIN_LIMIT") ? atoll(getenv("EKF_DEBUG_SPIN_LIMIT")) : (1LL << 24);
+    dv.spin_limit = 1LL << 24;
     dv.cond_limit = h->params.cond_limit;
     {
         // cond >= L  <=>  q r >= kappa (q^2 + r^2); kappa = 1/2 - 1/(L^2 + 1) (-> 1/2 for L = inf: only q = r is skipped).
@@ -416,7 +433,7 @@ static int create_impl(ekf_batch *h, int batch, int capacity_landmarks, int devi
     HIP_TRY(dev_alloc_zero(&dv.slot_active, B * 2 * dv.maxp, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.slot_meta, B * 2 * dv.maxp, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.pass_flag, 1, &h->device_bytes, s));
-    HIP_TRY(dev_alloc_zero(&dv.seg_count, 1, &h->device_bytes, s));
+    HIP_TRY(dev_alloc_zero(&dv.seg_count, EKF_PLAN_MAX, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.bar, B * 2, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.dbg, 32, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.part, B * 2 * dv.gmax * EKF_REC_DOUBLES, &h->device_bytes, s));
@@ -521,8 +538,7 @@ static int create_impl(ekf_batch *h, int batch, int capacity_landmarks, int devi
         h->persist = (getenv("EKF_PERSIST") ? atoi(getenv("EKF_PERSIST")) != 0 : true) && can_wait_value != 0;
     }
     h->flush_dir = 0;
-    h->dbg_skip_flush = getenv("EKF_DEBUG_SKIP_FLUSH") && atoi(getenv("EKF_DEBUG_SKIP_FLUSH")) != 0;
-    h->dbg_drop_marks_from = getenv("EKF_DEBUG_DROP_MARKS_FROM") ? atoi(getenv("EKF_DEBUG_DROP_MARKS_FROM")) : 0;
+    read_debug_hooks(h);
     h->xcd_map = getenv("EKF_XCD_MAP") ? atoi(getenv("EKF_XCD_MAP")) != 0 : true;
     h->batch_interleave = getenv("EKF_BATCH_INTERLEAVE") ? atoi(getenv("EKF_BATCH_INTERLEAVE")) != 0 : true;
     h->script_d = nullptr;
@@ -705,6 +721,7 @@ static int close_set(ekf_batch *h, bool terminal = false, EnqueueList *defer = n
     // every workgroup has finished that segment (a stream gate, hipStreamWaitValue64: the kernel is still running).  Otherwise
     // the chain launch's event.
     const unsigned long long gate_seq = terminal ? 0 : h->open_set_gate;
+    const int gate_idx = h->open_gate_idx;
     h->open_set_gate = 0;
     bool record_chain = false, wait_chain = false;
     hipEvent_t wait_prev = nullptr;
@@ -758,7 +775,7 @@ static int close_set(ekf_batch *h, bool terminal = false, EnqueueList *defer = n
             if (h->prev_pending > 0) wait_prev = h->pass_done[h->ev_idx];  // pass k-1, awaited by the chain's stream
         }
         mark = true, mark_value = ++h->pass_seq;  // pass k
-        if (h->dbg_drop_marks_from > 0 && mark_value >= h->dbg_drop_marks_from) mark = false;  // (test hook: a pass that never reports)
+        if (h->dbg_drop_marks_from > 0 && mark_value >= h->dbg_drop_marks_from && mark_value < h->dbg_drop_marks_to) mark = false;  // (test hook of the debug variant: a pass that never reports)
         h->ev_idx ^= 1;  // pass_done[ev_idx] is pass k's completion: ev_flush[ev_idx] as its stop event, or the profiling pair's stop event
         record_done = false;
         done_ev = (h->prof_flush && do_pass) ? e1 : h->ev_flush[h->ev_idx];
@@ -777,7 +794,7 @@ static int close_set(ekf_batch *h, bool terminal = false, EnqueueList *defer = n
         if (terminal) {
             if (wait_prev && (e = hipStreamWaitEvent(sc, wait_prev, 0)) != hipSuccess) return e;
         } else {
-            if (gate_seq && (e = hipStreamWaitValue64(sf, dv.seg_count, gate_seq, hipStreamWaitValueGte, 0xffffffffffffffffull)) != hipSuccess) return e;
+            if (gate_seq && (e = hipStreamWaitValue64(sf, dv.seg_count + gate_idx, gate_seq, hipStreamWaitValueGte, 0xffffffffffffffffull)) != hipSuccess) return e;
             if (record_chain && (e = hipEventRecord(ev_chain, sc)) != hipSuccess) return e;
             if (wait_chain && (e = hipStreamWaitEvent(sf, ev_chain, 0)) != hipSuccess) return e;
         }
@@ -866,7 +883,8 @@ static int launch_ops(ekf_batch *h, const double *in, const int *cursor, int k0,
                 hipExtLaunchKernelGGL(k_chain, dim3(h->chain_wgs, nb), dim3(h->chain_threads), h->chain_lds, h->s_chain, nullptr, last ? stop_ev : nullptr, 0, h->dv, in,
                                       cursor, plan, b0);
         }
-        if (plan.signal) h->seg_count_base += (unsigned long long)plan.nseg * h->chain_wgs * h->dv.B;
+        if (plan.signal)
+            for (int q = 0; q < plan.nseg; q++) h->seg_count_base[q] = plan.s[q].gate;
         plan.nseg = 0;
         next_drop = 0;
         for (auto &enq : passes) {
@@ -903,10 +921,11 @@ static int launch_ops(ekf_batch *h, const double *in, const int *cursor, int k0,
         }
         sg.need_pass = h->need_pass, sg.drop = next_drop;
         sg.seq = ++h->chain_seq;  // (one number per segment: every filter's mirror reaches it)
+        sg.gate = h->seg_count_base[plan.nseg] + (unsigned long long)h->chain_wgs * h->dv.B;  // every workgroup of the launch has finished this segment
         next_drop = 0;
         plan.s[plan.nseg++] = sg;
         plan.signal = persist ? 1 : 0;
-        plan.count_base = h->seg_count_base;
+        plan.reserved_ = 0;
         h->mirror_by_chain = true;
         h->stats_in_mirror = true;
         h->pending = used;
@@ -916,7 +935,7 @@ static int launch_ops(ekf_batch *h, const double *in, const int *cursor, int k0,
             h->chain_signalled = closes;
         } else {
             h->chain_signalled = false;
-            if (used == h->dv.maxp) h->open_set_gate = h->seg_count_base + (unsigned long long)plan.nseg * h->chain_wgs * h->dv.B;  // every workgroup has finished this segment
+            if (used == h->dv.maxp) h->open_set_gate = sg.gate, h->open_gate_idx = plan.nseg - 1;
         }
         if (used == h->dv.maxp && !(defer_last_close && i == nops)) {
             int rc = close_set(h, false, persist ? &passes : nullptr);
@@ -962,6 +981,7 @@ static int launch_ops_grouped(ekf_batch *h, const double *in, int k0, const unsi
         ChainSeg &sg = plan.s[0];
         sg.k0 = k0 + start, sg.nops = i - start, sg.slot0 = h->pending, sg.set = h->cur_set, sg.buf_read = h->buf_in;
         sg.seq = ++h->chain_seq;
+        sg.gate = 0;
         plan.nseg = 1;
         h->mirror_by_chain = true;
         h->stats_in_mirror = true;
@@ -1381,6 +1401,15 @@ extern "C" int ekf_set_state(ekf_handle h, int index, const double *x, const dou
     if (rc) return rc;
     EkfDev &dv = h->dv;
     hipStream_t s = h->s_chain;
+    // Both streams are idle here.  A launch that gave up (EKF_ERR_TIMEOUT) leaves the segment counters ahead of the host's
+    // bases (workgroups that had not aborted kept counting, open_gates raised the rest) and possibly a pass that never reported:
+    // every later stream gate would open early, every later in-kernel wait would run out again.  Start both from zero / from the
+    // host's own count, so that a handle is usable again after ekf_set_state, as the sticky status promises.
+    read_debug_hooks(h);
+    HIP_TRY(hipMemsetAsync(dv.seg_count, 0, sizeof(unsigned long long) * EKF_PLAN_MAX, s));
+    for (int q = 0; q < EKF_PLAN_MAX; q++) h->seg_count_base[q] = 0;
+    h->open_set_gate = 0;
+    if (h->overlap) hipLaunchKernelGGL(k_mark, dim3(1), dim3(64), 0, s, dv.pass_flag, h->pass_seq);
     double *stage = nullptr;
     HIP_TRY(hipMalloc((void **)&stage, ((size_t)n * n + n) * sizeof(double)));
     double *xd = stage + (size_t)n * n;

@@ -75,11 +75,12 @@ struct ChainSeg {
     int need_pass;       // dense pass (number) that must have finished before this segment starts, 0 = none
     int drop;            // segments after the first: virtual slots that leave the LDS caches in front (the set whose pass has finished)
     long long seq;       // launch number (the host mirror shows the newest one that has finished)
+    unsigned long long gate;  // multi-segment launches: the value dv.seg_count[this segment's index] shows when every workgroup has finished the segment
 };
 struct ChainPlan {
     int nseg;
-    int signal;                     // != 0: every workgroup counts each segment it finishes in dv.seg_count
-    unsigned long long count_base;  // value of seg_count before this launch
+    int signal;                     // != 0: every workgroup counts segment i in dv.seg_count[i] when it has finished it
+    unsigned long long reserved_;
     ChainSeg s[EKF_PLAN_MAX];
 };
 
@@ -105,8 +106,11 @@ struct EkfDev {
     int *slot_active;  // [B][2][maxp]
     SlotMeta *slot_meta;  // [B][2][maxp], written with the slot
     int *pass_flag;    // [1]: number of dense passes completed (overlap mode; stored by k_mark behind each pass)
-    unsigned long long *seg_count;  // [1]: (workgroup, segment) pairs finished by the handle's multi-segment chain launches; the dense passes' stream
-                                    // gates (hipStreamWaitValue64) and the next segment wait for it to reach "every workgroup, this segment"
+    unsigned long long *seg_count;  // [EKF_PLAN_MAX]: counter i = workgroups that have finished segment i of the handle's multi-segment chain launches
+                                    // (all launches so far).  One counter PER SEGMENT: workgroups of different filters -- and of one filter, in a
+                                    // segment without an exchange -- do not wait for each other between segments, so a sum over segments could reach
+                                    // "every workgroup, segment s" while one workgroup is still inside s.  The dense pass of segment i sits behind
+                                    // hipStreamWaitValue64(seg_count[i] >= ChainSeg::gate)
     int *bar;          // [B][2]: [0] = cross-workgroup exchanges done so far (tags of the records continue from it)
     long long *dbg;    // [32] diagnostics: tick counters of the control lane [0..7] and of the first worker [16..23] (EKF_CHAIN_STAMPS), first bad index [8..11] (EKF_CHAIN_CHECK)
     double *part;      // [B][2][gmax][EKF_REC_DOUBLES]: per-workgroup arg-min records, double-buffered by exchange parity

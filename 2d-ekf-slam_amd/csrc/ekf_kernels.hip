@@ -369,7 +369,7 @@ __device__ __forceinline__ unsigned lds_off(const void *p) { return (unsigned)(s
         "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240",     \
         "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255"
 
-static_assert(sizeof(ChainSeg) == 40 && sizeof(ChainPlan) == 16 + EKF_PLAN_MAX * 40, "the segment table is read from the kernel-argument segment by offset");
+static_assert(sizeof(ChainSeg) == 48 && sizeof(ChainPlan) == 16 + EKF_PLAN_MAX * 48, "the segment table is read from the kernel-argument segment by offset");
 struct ChainKArgs {  // k_chain's arguments as they lie in the kernel-argument segment
     EkfDev dv;
     const double *in;
@@ -429,7 +429,6 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
     typedef __attribute__((address_space(4))) const ChainSeg *SegPtr;
     const SegPtr segs = (SegPtr)((__attribute__((address_space(4))) const char *)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(ChainKArgs, plan) + offsetof(ChainPlan, s));
     const long long last_seq = segs[nseg - 1].seq;
-    const unsigned long long seg_wgs = (unsigned long long)gridDim.x * gridDim.y;
     if (tid == 0) L.abort = 0, L.hflag = -1;
     int fold_no = 0;  // Old measurements whose fold the helper wave shared (wave-uniform, kept by every thread)
     // Launches without a measurement (Propagate, compass, truth samples) have no exchange, hence nothing that keeps the filter's
@@ -600,8 +599,9 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
     // the matched landmark's rows of the set just closed -- it reads after an exchange of the new segment, i.e. after every
     // workgroup has published a head from the new segment, which each does behind its own write-back of the old one; its own
     // L2 holds no older copy of those rows (last read two windows ago, an acquire at every segment start since).
-    auto open_gates = [=]() {  // a launch that gives up must not leave the dense passes of its later segments waiting
-        if (plan.signal) __hip_atomic_fetch_max(dv.seg_count, plan.count_base + (unsigned long long)nseg * seg_wgs, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    auto open_gates = [=]() {  // a launch that gives up must not leave the dense passes of its segments waiting
+        if (plan.signal)
+            for (int i = 0; i < nseg; i++) __hip_atomic_fetch_max(dv.seg_count + i, segs[i].gate, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     };
     auto give_up = [=]() {  // a bounded wait ran out (uniform over the workgroup; the other workgroups of the filter time out the same way)
         if (tid == 0 && G > 1 && !arrived) __hip_atomic_fetch_add(&bar[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (keeps the count a multiple of G)
@@ -1370,7 +1370,7 @@ finish:  // (also the way out when a bounded wait ran out: the sticky status say
         __syncthreads();
         if (tid == 0) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            __hip_atomic_fetch_add(dv.seg_count, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(dv.seg_count + seg, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (a counter per segment: ekf_device.h)
             if (lead && seg + 1 < nseg && !L.abort) {
                 EkfMirror *mr = dv.mirror + b;
                 for (int i = 0; i < L.n_dec; i++) mr->last[(L.log_count - L.n_dec + i) % EKF_MIRROR_DECISIONS] = L.dec_buf[i];

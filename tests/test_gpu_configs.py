@@ -66,6 +66,77 @@ def bench_inputs(pkg, workload, steps, g=0):
     return N, x0, P0, sc
 
 
+def state_digest(x, P):
+    """sha256 over the state rounded to 9 significant digits (what two implementations within the parity tolerance share)."""
+    import hashlib
+    def rnd(a):
+        a = np.asarray(a, dtype=np.float64)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            mag = np.where(a == 0, 0.0, np.floor(np.log10(np.abs(a))))
+        return np.where(a == 0, 0.0, np.round(a / 10.0 ** mag, 8) * 10.0 ** mag)
+    return hashlib.sha256(np.ascontiguousarray(rnd(x)).tobytes() + np.ascontiguousarray(rnd(P)).tobytes()).hexdigest()[:16]
+
+
+def test_config1_as_stated_1000_steps(pkg, oc):
+    """BASELINE.json config 1 exactly as stated: one robot, N = 50 landmarks, 1000 steps of synthetic
+    odometry + range/bearing measurements (seed 20260001) from the reference's initial condition x = 0_3, P = 0
+    (kalmanfilter.cpp:4-12), driven through the KalmanFilter mirror call for call as slam.cpp:130-171 drives the reference:
+    every decision and matched index, Num_Landmarks and the pose after every call sequence, the full state every 100 steps
+    and at the end, against the oracle in lock step; then the same 1000 steps as ONE scripted run (device-resident
+    records, windows of 16): identical decisions, same final state.  Prints the decision histogram."""
+    script = pkg.scenarios.lifecycle_script(seed=20260001, n_landmarks=50, steps=1000)
+    kf = pkg.KalmanFilter(capacity_landmarks=96)  # (the reference's state simply grows; association noise adds a few landmarks to the world's 50)
+    x, P = np.zeros(3), np.zeros((3, 3))
+    hist = {oc.NEW: 0, oc.OLD: 0, oc.IGNORE: 0}
+    decs = []
+    for i, st in enumerate(script):
+        rot_deg = st["w"] * 180.0 / 3.141592654
+        kf.doPropagation(st["dt"], st["v"] * 1000.0, rot_deg)
+        v, w = (st["v"] * 1000.0) / 1000.0, rot_deg * 3.141592654 / 180.0  # kalmanfilter.cpp:19,26
+        x, P = oc.propagate(x, P, v, w, oc.make_Q(v), st["dt"])
+        for fx, fy in st["feats_mm"]:
+            z, R = oc.make_measurement(fx, fy)
+            kf.doUpdate(z.reshape(2, 1), R)
+            x, P, dec, mat, mah = oc.update(x, P, z.reshape(2, 1), R)
+            g = kf.last_decisions[0]
+            assert (g[0], g[1]) == (dec[0], mat[0]), (i, g, dec, mat, mah)
+            hist[dec[0]] += 1
+            decs.append((dec[0], mat[0]))
+        assert kf.Num_Landmarks == (x.size - 3) // 2
+        assert abs(kf.X - x[0]) < 1e-9 and abs(kf.Y - x[1]) < 1e-9 and abs(kf.Phi - x[2]) < 1e-9
+        if i % 100 == 99:
+            xg, Pg = kf.state()
+            assert_state_close(xg, Pg, x, P, "step %d" % (i + 1))
+            assert_bitwise_symmetric(Pg)
+    xg, Pg = kf.state()
+    assert_state_close(xg, Pg, x, P, "final")
+    assert kf.Num_Landmarks >= 40 and hist[oc.OLD] >= 2000 and hist[oc.NEW] == kf.Num_Landmarks, hist
+    print("config 1: 1000 steps, %d measurements, New %d Old %d Ignore %d, %d landmarks, digest oracle %s gpu %s"
+          % (len(decs), hist[oc.NEW], hist[oc.OLD], hist[oc.IGNORE], kf.Num_Landmarks, state_digest(x, P), state_digest(xg, Pg)))
+    # the same run as one scripted call
+    M = 4
+    ctrl = np.zeros((1000, 1, 3))
+    z = np.zeros((1000, M, 1, 2))
+    R = np.zeros((1000, M, 1, 4))
+    R[..., 0] = R[..., 3] = 1.0
+    valid = np.zeros((1000, M, 1), dtype=np.uint8)
+    for s_, st in enumerate(script):
+        rot_deg = st["w"] * 180.0 / 3.141592654
+        ctrl[s_, 0] = ((st["v"] * 1000.0) / 1000.0, rot_deg * 3.141592654 / 180.0, st["dt"])
+        for m, (fx, fy) in enumerate(st["feats_mm"]):
+            zz, RR = oc.make_measurement(fx, fy)
+            z[s_, m, 0], R[s_, m, 0], valid[s_, m, 0] = zz, RR.ravel(order="F"), 1
+    f = pkg.FilterBatch(1, 96, log_capacity=4096)
+    f.script_load(ctrl, z, R, valid=valid)
+    f.script_run(0, 1000)
+    f.sync()
+    assert [(d[0], d[1]) for d in f.decisions(0, len(decs))] == decs
+    xs, Ps = f.get_state()
+    assert_state_close(xs, Ps, x, P, "scripted")
+    assert_bitwise_symmetric(Ps)
+    f.close()
+
+
 def test_config3_benchmarked_configuration_vs_oracle(pkg, oc, pipeline_mode):
     """N = 4096 (dense P 8195 x 8195), window 16, the pipeline mode under test: the configuration BENCH_rNN times.
     Oracle check after step 1 and after step 5 (20 measurements: one full window folded by a dense pass that, in
