@@ -217,3 +217,17 @@ def simulated_drive(seed=20260012, steps=120, dt=0.25, v=0.3, noise_mm=6.0, max_
         out.append(dict(dt=dt, v_mm_s=1000.0 * v_meas, rot_deg_s=w_meas * 180.0 / 3.141592654,
                         scan=(r.astype(np.float64), r * np.cos(ang), r * np.sin(ang)), truth=pose.copy()))
     return out
+
+
+def state_digest(x, P):
+    """sha256 over the state rounded to 9 significant digits: what two implementations within the parity tolerance normally
+    share (a value that sits on a rounding boundary can still split them: the digest is a fingerprint, the tolerance is the test)."""
+    import hashlib
+
+    def rnd(a):
+        a = np.asarray(a, dtype=np.float64)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            mag = np.where(a == 0, 0.0, np.floor(np.log10(np.abs(a))))
+        return np.where(a == 0, 0.0, np.round(a / 10.0 ** mag, 8) * 10.0 ** mag)
+
+    return hashlib.sha256(np.ascontiguousarray(rnd(x)).tobytes() + np.ascontiguousarray(rnd(P)).tobytes()).hexdigest()[:16]

@@ -24,6 +24,17 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+def ekf_environment():
+    """Every EKF_* variable this process sees goes into the JSON line; a debug hook (EKF_DEBUG_*: skipped dense passes, dropped
+    completion marks -- only the debug variant of the library knows them, but the line must not depend on which library was
+    loaded) or a diagnostic library (EKFSLAM_LIB) makes the run invalid: refuse."""
+    seen = {k: v for k, v in sorted(os.environ.items()) if k.startswith("EKF")}
+    bad = [k for k in seen if k.startswith("EKF_DEBUG_") or k == "EKFSLAM_LIB"]
+    if bad:
+        raise SystemExit("bench.py refuses to run with %s set (debug hooks / diagnostic library builds are not the measured binary)" % ", ".join(bad))
+    return seen
+
+
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X datasheet fp64 matrix; v_mfma_f64_16x16x4_f64 measured 68 TFLOP/s (scripts/micro)
 
@@ -117,6 +128,167 @@ def config5_legs(pkg, mc, torch, dist, coll_device, rank, world, dev_id, M, max_
     return out
 
 
+def roofline_record(pkg, f, workload, B, N, K, M, window, launches, flush_ms, alone_launches, alone_ms, dev_ms, elapsed):
+    """The dominant kernel = the dense pass k_flush_rb.  Algorithmic bytes per launch: every stored P_LL element (upper-triangle
+    64x64 tiles; one triangle authoritative = SURVEY.md 8d's scheme C, 8 n^2 per pass) read once and written once, whatever
+    number of measurements the pass folds; duration = hipEvents riding on each dispatch packet inside the timed region."""
+    nT = (2 * N + 63) // 64
+    tiles = nT * (nT + 1) // 2
+    windows = -(-K * M // window)
+    groups = max(1, round(launches / windows)) if launches else 1  # (phase groups of a batch launch one pass per group and window)
+    filters_per_launch = max(1, B // groups)
+    bytes_per_launch = filters_per_launch * tiles * 4096 * 8 * 2
+    slots_per_launch = min(window, K * M)
+    flops_per_launch = filters_per_launch * tiles * ((slots_per_launch + 1) // 2) * 16 * 2048  # 16 v_mfma_f64_16x16x4_f64 per tile and PAIR of measurements
+    r = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+         "kernel": "k_flush_rb", "byte_model": "scheme C (one triangle authoritative): tiles * 32 KiB read + written per pass, %d measurements folded per pass" % slots_per_launch,
+         "bytes_per_launch": bytes_per_launch, "launches": int(launches), "avg_launch_us": None, "measurements_per_launch": slots_per_launch,
+         "mfma": {"achieved": None, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None, "flops_per_launch": flops_per_launch}}
+    if launches:
+        avg_s = flush_ms / 1e3 / launches
+        r["avg_launch_us"] = avg_s * 1e6
+        r["achieved"] = bytes_per_launch / avg_s / 1e9
+        r["frac"] = r["achieved"] / HBM_PEAK_GBS
+        r["mfma"]["achieved"] = flops_per_launch / avg_s / 1e12
+        r["mfma"]["frac"] = r["mfma"]["achieved"] / FP64_MFMA_PEAK_TFLOPS
+        r["share_of_step_time"] = flush_ms / (dev_ms if dev_ms > 0 else 1.0)
+        r["concurrent_with"] = "k_chain of the next window (overlap)" if f.overlap else None
+        # every pass of the timed region against the whole timed region: what the headline cannot hide (the sequential chain
+        # kernels, launch gaps, fill and drain all count as time in which HBM should have been busy)
+        r["end_to_end_hbm_frac"] = launches * bytes_per_launch / elapsed / 1e9 / HBM_PEAK_GBS
+    if alone_launches:
+        a_s = alone_ms / 1e3 / alone_launches
+        r["alone"] = {"avg_launch_us": a_s * 1e6, "achieved": bytes_per_launch / a_s / 1e9, "frac": bytes_per_launch / a_s / 1e9 / HBM_PEAK_GBS,
+                      "launches": int(alone_launches), "note": "same pass, nothing else on the GPU, outside the timed region"}
+    # PMC-derived HBM bytes per launch: NOT measured by this run -- replayed from the committed rocprofv3 --pmc passes of this very
+    # command (scripts/profile_r0x.sh -> profiles/traffic_*.json); null when no committed pass matches the configuration
+    for tname in ("traffic_%s.json" % workload, "traffic_%s_inplace.json" % workload):
+        tfile = os.path.join(ROOT, "profiles", tname)
+        if os.path.exists(tfile):
+            tj = json.load(open(tfile))
+            if tj.get("max_pending") == window and tj.get("overlap", int(f.overlap)) == int(f.overlap) and tj.get("filters_per_gpu", B) == B:
+                r["traffic"] = tj.get("hbm_bytes_per_launch")
+                r["traffic_source"] = "replayed from profiles/%s (separate rocprofv3 --pmc passes), not measured in this run" % tname
+                break
+    return r
+
+
+def measure(pkg, mc, torch, dist, coll_device, rank, world, dev_id, workload, K, W, M, max_pending, graph, flush_profile, check=True, alone=True, latency=False):
+    """One workload, timed as the contract says (timed_steps); returns its record."""
+    import numpy as np
+    N, B, _, _, seed, extent, min_sep = WORKLOADS[workload]
+    lo, hi = mc.shard_range(B * world, rank, world)
+    # (4 windows of untimed tail: dense passes measured one at a time, nothing beside them; latency: one step per call)
+    extra = 64 if latency else 0
+    f, scripts = make_filters(pkg, mc, workload, lo, hi, W + K + extra, M, dev_id, max_pending, (K + W + extra) * M, tail_windows=4 if alone else 0)
+    window = f.window  # the library may shorten the window to fit its on-chip buffer
+    win_steps = -(-window // M)
+    f.flush_profile(flush_profile)
+    elapsed, dev_ms, gathered = timed_steps(f, mc, torch, dist, coll_device, W, K, graph)
+    f.sync()
+    launches, flush_ms = f.flush_profile_read()
+    if check:
+        for b in range(B if B <= 4 else 4):
+            dec = f.decisions(b, K * M)
+            want = [3 + 2 * int(t) for t in scripts[b]["target"][W:W + K].ravel()]
+            assert len(dec) == K * M and all(d[0] == pkg.ekfslam.OLD for d in dec), "filter %d left the Old branch" % b
+            assert [d[1] for d in dec] == want, "filter %d matched an unintended landmark" % b
+        st = f.stats()
+        assert all(s["n_old"] == K * M and s["n_new"] == 0 and s["n_ignore"] == 0 for s in st)
+    lat = None
+    if latency:
+        # per-step latency (SURVEY.md 8d, config 2): one scripted step per call, host clock from the call to the moment the pose of
+        # that step is readable (kernel launch + completion, no state copy); the window's dense pass falls on every fourth step
+        ts = []
+        for s_ in range(W + K, W + K + extra):
+            t0 = time.perf_counter()
+            f.script_run(s_, 1)
+            f.poses()
+            ts.append((time.perf_counter() - t0) * 1e6)
+        ts = np.sort(np.array(ts[8:]))
+        lat = {"unit": "us per step (1 Propagate + %d Updates, one call per step, pose read back)" % M, "samples": int(ts.size),
+               "p10": float(np.percentile(ts, 10)), "p50": float(np.percentile(ts, 50)), "p90": float(np.percentile(ts, 90)), "max": float(ts[-1])}
+        f.flush()
+        f.sync()
+        f.flush_profile_read()
+    alone_launches, alone_ms = 0, 0.0
+    if flush_profile and alone:
+        base = W + K + extra
+        for r in range(4):
+            # a whole window, then its pipeline-style pass (buffer to buffer, on the pass's own stream) with the chain kernel
+            # already finished and nothing following
+            f.script_run(base + r * win_steps, win_steps)
+            f.sync()
+            f.close_window()
+            f.sync()
+        alone_launches, alone_ms = f.flush_profile_read()
+    roof = roofline_record(pkg, f, workload, B, N, K, M, window, launches, flush_ms, alone_launches, alone_ms, dev_ms, elapsed)
+    rep = mc.consistency_report(gathered, K * M, K)
+    overlap = int(f.overlap)
+    f.close()
+    return {"workload": workload, "N": N, "B": B, "K": K, "W": W, "M": M, "window": window, "overlap": overlap, "elapsed": elapsed, "dev_ms": dev_ms,
+            "value": B * world * K / elapsed, "roofline": roof, "latency": lat, "report": rep, "seed": seed, "extent": extent, "min_sep": min_sep}
+
+
+def config1_leg(pkg, dev_id):
+    """BASELINE.json config 1 as stated: one robot, N = 50 landmarks, 1000 steps of synthetic odometry + range/bearing
+    measurements (seed 20260001) from x = 0_3, P = 0 (kalmanfilter.cpp:4-12): the GPU as one scripted run, the faithful-dense
+    CPU path (the reference's dense passes, one thread) beside it, decision histogram, final-state digests."""
+    import numpy as np
+    from oracle import oracle_c as oc
+    steps, Mx = 1000, 4
+    script = pkg.scenarios.lifecycle_script(seed=20260001, n_landmarks=50, steps=steps)
+    ctrl = np.zeros((steps, 1, 3))
+    z = np.zeros((steps, Mx, 1, 2))
+    R = np.zeros((steps, Mx, 1, 4))
+    R[..., 0] = R[..., 3] = 1.0
+    valid = np.zeros((steps, Mx, 1), dtype=np.uint8)
+    for s_, st in enumerate(script):
+        ctrl[s_, 0] = (st["v"], st["w"], st["dt"])
+        for m, (fx, fy) in enumerate(st["feats_mm"]):
+            zz, RR = pkg.scenarios.measurement_from_feature_mm(fx, fy)
+            z[s_, m, 0], R[s_, m, 0], valid[s_, m, 0] = zz, RR.ravel(order="F"), 1
+    n_meas = int(valid.sum())
+    gpu_s = []
+    for rep in range(3):  # (the first run pays for first-touch costs)
+        f = pkg.FilterBatch(1, 96, device=dev_id, log_capacity=4096)
+        f.script_load(ctrl, z, R, valid=valid)
+        f.sync()
+        t0 = time.perf_counter()
+        f.script_run(0, steps)
+        f.flush()
+        f.sync()
+        gpu_s.append(time.perf_counter() - t0)
+        if rep == 2:
+            dec = f.decisions(0, n_meas)
+            xg, Pg = f.get_state()
+        f.close()
+    oc.build()
+    x, P = np.zeros(3), np.zeros((3, 3))
+    hist = {oc.NEW: 0, oc.OLD: 0, oc.IGNORE: 0}
+    decs = []
+    t0 = time.perf_counter()
+    for st in script:
+        x, P = oc.propagate(x, P, st["v"], st["w"], oc.make_Q(st["v"]), st["dt"], faithful=True)
+        for fx, fy in st["feats_mm"]:
+            zz, RR = oc.make_measurement(fx, fy)
+            x, P, d, mt, _ = oc.update(x, P, zz.reshape(2, 1), RR, faithful=True)
+            hist[d[0]] += 1
+            decs.append((d[0], mt[0]))
+    cpu_t = time.perf_counter() - t0
+    same = [(d[0], d[1]) for d in dec] == decs
+    scale = float(np.abs(P).max())
+    return {"config": "BASELINE.json config 1: 1 robot, N=50 landmarks, synthetic odom + range/bearing, 1000 steps from x=0, P=0 (seed 20260001)",
+            "steps": steps, "measurements": n_meas, "decisions": {"new": hist[oc.NEW], "old": hist[oc.OLD], "ignore": hist[oc.IGNORE]},
+            "landmarks_final": int((x.size - 3) // 2), "gpu_steps_per_s": steps / min(gpu_s), "gpu_ms_per_step": min(gpu_s) / steps * 1e3,
+            "cpu_baseline": {"value": steps / cpu_t, "unit": "steps/s", "cores": 1, "kind": "port",
+                             "sample": "all 1000 steps, faithful-dense oracle (the reference's dense passes, 1 thread), %.2f s" % cpu_t},
+            "decisions_identical": bool(same), "max_rel_err_x": float(np.abs(xg - x).max() / max(1.0, np.abs(x).max())),
+            "max_err_P_over_maxP": float(np.abs(Pg - P).max() / scale),
+            "state_digest": {"oracle": pkg.scenarios.state_digest(x, P), "gpu": pkg.scenarios.state_digest(xg, Pg),
+                             "note": "sha256 over x and P rounded to 9 significant digits"}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -127,11 +299,13 @@ def main():
     ap.add_argument("--max-pending", type=int, default=16, help="measurements folded per dense pass over P_LL (1 = a dense pass per measurement, as the reference does)")
     ap.add_argument("--graph", type=int, default=0, help="replay steps through HIP graphs (one k_chain launch already covers several steps; plain launches keep the per-launch dense-pass events)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary records (configs 1, 2, 4 and M = 1) that ride on the default line")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the real thing) or gloo (rehearsal of the multi-rank path on a one-GPU box)")
     ap.add_argument("--device", type=int, default=None, help="force a device id (rehearsal only; default LOCAL_RANK)")
     ap.add_argument("--no-flush-profile", action="store_true", help="do not bracket the dense pass with hipEvents")
     ap.add_argument("--no-config5", action="store_true", help="with --gpus N > 1: skip the config-5 legs (256 filters/GPU weak, 2048 filters strong)")
     args = ap.parse_args()
+    ekf_env = ekf_environment()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -164,96 +338,54 @@ def main():
             dist.init_process_group(args.dist_backend)
     coll_device = torch.device("cuda", dev_id) if args.dist_backend == "nccl" else torch.device("cpu")
 
-    # ---- inputs: built on the host, then moved to HBM (untimed) ------------------------------------
-    lo, hi = mc.shard_range(B * world, rank, world)
-    # (4 windows of untimed tail: dense passes measured one at a time, nothing beside them)
-    f, scripts = make_filters(pkg, mc, args.workload, lo, hi, W + K, M, dev_id, args.max_pending, (K + W) * M, tail_windows=4)
-    args.max_pending = f.window  # the library may shorten the window to fit its on-chip buffer
-    win_steps = -(-f.window // M)   # steps that fill one window
-    f.flush_profile(not args.no_flush_profile)
-
-    # ---- warm-up (untimed), then the timed region: exactly K steps -----------------------------------------
-    elapsed, dev_ms, gathered = timed_steps(f, mc, torch, dist, coll_device, W, K, bool(args.graph))
-
-    # ---- checks outside the timed region --------------------------------------------------------------
-    f.sync()
-    launches, flush_ms = f.flush_profile_read()
-    for b in range(B if B <= 4 else 4):
-        dec = f.decisions(b, K * M)
-        want = [3 + 2 * int(t) for t in scripts[b]["target"][W:W + K].ravel()]
-        assert len(dec) == K * M and all(d[0] == pkg.ekfslam.OLD for d in dec), "filter %d left the Old branch" % b
-        assert [d[1] for d in dec] == want, "filter %d matched an unintended landmark" % b
-    st = f.stats()
-    assert all(s["n_old"] == K * M and s["n_new"] == 0 and s["n_ignore"] == 0 for s in st)
-    # the same dense pass with the GPU to itself (in overlap mode the timed passes share HBM with the chain kernels)
-    alone_launches, alone_ms = 0, 0.0
-    if not args.no_flush_profile:
-        for r in range(4):
-            # a whole window, then its pipeline-style pass (buffer to buffer, on the pass's own stream) with the chain kernel
-            # already finished and nothing following
-            f.script_run(W + K + r * win_steps, win_steps)
-            f.sync()
-            f.close_window()
-            f.sync()
-        alone_launches, alone_ms = f.flush_profile_read()
+    # ---- the headline: inputs built on the host and moved to HBM (untimed), warm-up (untimed), exactly K timed steps -------
+    head = measure(pkg, mc, torch, dist, coll_device, rank, world, dev_id, args.workload, K, W, M, args.max_pending, bool(args.graph), not args.no_flush_profile)
 
     config5 = None
     if world > 1 and not args.no_config5:
-        f.close()
         config5 = config5_legs(pkg, mc, torch, dist, coll_device, rank, world, dev_id, M, args.max_pending)
+
+    # ---- secondary records on the same line (one GPU only): the other BASELINE.json configurations a single GPU holds, each with
+    # its own roofline, so that the driver's one command puts a number behind every one of them
+    secondary = None
+    if world == 1 and not args.no_secondary and args.workload == "n4096":
+        secondary = {}
+        def leg(name, fn):
+            try:
+                secondary[name] = fn()
+            except Exception as e:  # a secondary record must not cost the headline
+                secondary[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+        def summarise(r, unit="steps/s"):
+            out = {"workload": "%s: %d filter(s), N=%d, M=%d, window %d, overlap %d, %d timed steps after %d warm-up" % (r["workload"], r["B"], r["N"], r["M"], r["window"], r["overlap"], r["K"], r["W"]),
+                   "value": r["value"], "unit": unit, "ms_per_step": r["elapsed"] / r["K"] * 1e3, "device_ms_per_step": r["dev_ms"] / r["K"],
+                   "per_update_us": r["elapsed"] / (r["K"] * r["M"]) * 1e6, "roofline": r["roofline"]}
+            if r["latency"]:
+                out["per_step_latency"] = r["latency"]
+            return out
+        leg("config2_n1024", lambda: summarise(measure(pkg, mc, torch, None, coll_device, 0, 1, dev_id, "n1024", 200, 10, M, args.max_pending, False, True, latency=True)))
+        leg("config4_batch256", lambda: summarise(measure(pkg, mc, torch, None, coll_device, 0, 1, dev_id, "batch256", 200, 10, M, args.max_pending, False, True, alone=False), "filter-steps/s"))
+        leg("config3_M1", lambda: summarise(measure(pkg, mc, torch, None, coll_device, 0, 1, dev_id, "n4096", 512, 32, 1, args.max_pending, False, True, alone=False)))
+        leg("config3_512_steps", lambda: summarise(measure(pkg, mc, torch, None, coll_device, 0, 1, dev_id, "n4096", 512, 32, M, args.max_pending, False, True, alone=False)))
+        leg("config1_n50", lambda: config1_leg(pkg, dev_id))
 
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
         return
 
-    total_filter_steps = B * world * K
-    value = total_filter_steps / elapsed
-    nT = (2 * N + 63) // 64
-    tiles = nT * (nT + 1) // 2
-    # dominant kernel = the dense pass k_flush.  Algorithmic bytes per launch: every stored P_LL element
-    # (upper-triangle 64x64 tiles) read once and written once, whatever number of measurements it folds.
-    bytes_per_launch = B * tiles * 4096 * 8 * 2
-    slots_per_launch = min(args.max_pending, K * M)
-    flops_per_launch = B * tiles * ((slots_per_launch + 1) // 2) * 16 * 2048  # 16 v_mfma_f64_16x16x4_f64 per tile and PAIR of measurements
-    roofline = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
-                "kernel": "k_flush_rb", "bytes_per_launch": bytes_per_launch, "launches": int(launches), "avg_launch_us": None,
-                "measurements_per_launch": slots_per_launch,
-                "mfma": {"achieved": None, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None, "flops_per_launch": flops_per_launch}}
-    if launches:
-        avg_s = flush_ms / 1e3 / launches
-        roofline["avg_launch_us"] = avg_s * 1e6
-        roofline["achieved"] = bytes_per_launch / avg_s / 1e9
-        roofline["frac"] = roofline["achieved"] / HBM_PEAK_GBS
-        roofline["mfma"]["achieved"] = flops_per_launch / avg_s / 1e12
-        roofline["mfma"]["frac"] = roofline["mfma"]["achieved"] / FP64_MFMA_PEAK_TFLOPS
-        roofline["share_of_step_time"] = flush_ms / (dev_ms if dev_ms > 0 else 1.0)
-        roofline["concurrent_with"] = "k_chain of the next window (overlap)" if f.overlap else None
-    if alone_launches:
-        a_s = alone_ms / 1e3 / alone_launches
-        roofline["alone"] = {"avg_launch_us": a_s * 1e6, "achieved": bytes_per_launch / a_s / 1e9, "frac": bytes_per_launch / a_s / 1e9 / HBM_PEAK_GBS,
-                             "launches": int(alone_launches), "note": "same pass, nothing else on the GPU, outside the timed region"}
-    # PMC-derived HBM bytes per launch (separate rocprofv3 --pmc passes of this very command: scripts/profile_r02.sh, profiles/)
-    for tname in ("traffic_%s.json" % args.workload, "traffic_%s_inplace.json" % args.workload):
-        tfile = os.path.join(ROOT, "profiles", tname)
-        if os.path.exists(tfile):
-            tj = json.load(open(tfile))
-            if tj.get("max_pending") == args.max_pending and tj.get("overlap", int(f.overlap)) == int(f.overlap) and tj.get("filters_per_gpu", B) == B:
-                roofline["traffic"] = tj.get("hbm_bytes_per_launch")
-                break
-
     cpu = cpu_strong = None
     if world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(pkg, N, M, seed, extent, min_sep)
         cpu_strong = cpu_baseline_structured(pkg, N, M, seed, extent, min_sep)
 
-    rep = mc.consistency_report(gathered, K * M, K)
+    rep = head["report"]
     # the steady workload feeds 0.5-sigma measurement noise and a noise-free truth (margins
     # for the gate), so NIS/NEES below their dof are expected here; the chi-square verdict is for config 1 style runs
     mc_stats = {k: (None if v is None else {"mean": v["mean"], "dof": v["dof"], "filters": v["filters"]}) for k, v in rep.items()}
+    elapsed, dev_ms, window = head["elapsed"], head["dev_ms"], head["window"]
     line = {
         "metric": "EKF steps/sec (propagate+full update) at N landmarks",
-        "value": value,
+        "value": head["value"],
         "unit": "steps/s",
         "n_gpus": world,
         "steps": K,
@@ -265,15 +397,18 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": "%s: %d filter(s)/GPU, N=%d landmarks (n=%d, dense P %.1f MB fp64), M=%d Old updates/step, max_pending=%d, overlap=%d, graph=%d"
-                               % (args.workload, B, N, 3 + 2 * N, (3 + 2 * N) ** 2 * 8 / 1e6, M, args.max_pending, int(f.overlap), args.graph),
-                   "N": N, "filters_per_gpu": B, "M": M, "max_pending": args.max_pending, "overlap": int(f.overlap)},
+                               % (args.workload, B, N, 3 + 2 * N, (3 + 2 * N) ** 2 * 8 / 1e6, M, window, head["overlap"], args.graph),
+                   "N": N, "filters_per_gpu": B, "M": M, "max_pending": window, "overlap": head["overlap"]},
         "device_ms_per_step": dev_ms / K,
-        "roofline": roofline,
+        "roofline": head["roofline"],
         "cpu_baseline": cpu,
         "cpu_baseline_structured": cpu_strong,
         "per_update_us": elapsed / (K * M) * 1e6,
         "mc_stats": mc_stats,
         "config5": config5,
+        "secondary": secondary,
+        "multi_gpu_note": "no multi-GPU scaling curve has been measured by the builder (one-GPU boxes only); --gpus N shards filters with one RCCL all-gather",
+        "ekf_environment": ekf_env,
     }
     print(json.dumps(line))
     if dist is not None:
@@ -291,16 +426,20 @@ def cpu_baseline(pkg, N, M, seed, extent, min_sep):
     x, P = pkg.scenarios.injected_state(N, seed=seed, extent=extent)
     sc = pkg.scenarios.steady_script(x, steps=sample_steps, M=M, seed=seed + 7919, min_separation=min_sep)
     oc.build()
-    t0 = time.perf_counter()
+    per_step = []
     for s in range(sample_steps):
+        t0 = time.perf_counter()
         v, w, dt = sc["ctrl"][s]
         x, P = oc.propagate(x, P, v, w, oc.make_Q(v), dt, faithful=True)
         for m in range(M):
             x, P, dec, _, _ = oc.update(x, P, sc["z"][s, m].reshape(2, 1), sc["R"][s, m].reshape(2, 2, order="F"), faithful=True)
             assert dec == [oc.OLD]
-    t = time.perf_counter() - t0
+        per_step.append(time.perf_counter() - t0)
+    t = sum(per_step)
+    ps = np.array(per_step)
     return {"value": sample_steps / t, "unit": "steps/s", "cores": 1, "kind": "port",
             "sample": "%d step(s) of the same workload (1 Propagate + %d Old Updates each) at N=%d, faithful-dense oracle, %.1f s" % (sample_steps, M, N, t),
+            "seconds_per_step": {"median": float(np.median(ps)), "p10": float(np.percentile(ps, 10)), "p90": float(np.percentile(ps, 90))},
             "host_cpus": os.cpu_count()}
 
 

@@ -66,17 +66,6 @@ def bench_inputs(pkg, workload, steps, g=0):
     return N, x0, P0, sc
 
 
-def state_digest(x, P):
-    """sha256 over the state rounded to 9 significant digits (what two implementations within the parity tolerance share)."""
-    import hashlib
-    def rnd(a):
-        a = np.asarray(a, dtype=np.float64)
-        with np.errstate(divide="ignore", invalid="ignore"):
-            mag = np.where(a == 0, 0.0, np.floor(np.log10(np.abs(a))))
-        return np.where(a == 0, 0.0, np.round(a / 10.0 ** mag, 8) * 10.0 ** mag)
-    return hashlib.sha256(np.ascontiguousarray(rnd(x)).tobytes() + np.ascontiguousarray(rnd(P)).tobytes()).hexdigest()[:16]
-
-
 def test_config1_as_stated_1000_steps(pkg, oc):
     """BASELINE.json config 1 exactly as stated: one robot, N = 50 landmarks, 1000 steps of synthetic
     odometry + range/bearing measurements (seed 20260001) from the reference's initial condition x = 0_3, P = 0
@@ -112,7 +101,7 @@ def test_config1_as_stated_1000_steps(pkg, oc):
     assert_state_close(xg, Pg, x, P, "final")
     assert kf.Num_Landmarks >= 40 and hist[oc.OLD] >= 2000 and hist[oc.NEW] == kf.Num_Landmarks, hist
     print("config 1: 1000 steps, %d measurements, New %d Old %d Ignore %d, %d landmarks, digest oracle %s gpu %s"
-          % (len(decs), hist[oc.NEW], hist[oc.OLD], hist[oc.IGNORE], kf.Num_Landmarks, state_digest(x, P), state_digest(xg, Pg)))
+          % (len(decs), hist[oc.NEW], hist[oc.OLD], hist[oc.IGNORE], kf.Num_Landmarks, pkg.scenarios.state_digest(x, P), pkg.scenarios.state_digest(xg, Pg)))
     # the same run as one scripted call
     M = 4
     ctrl = np.zeros((1000, 1, 3))
