@@ -38,7 +38,7 @@ extern "C" int feat_destroy(feat_handle h) {
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
     hipFree(h->d_npts), hipFree(h->d_in), hipFree(h->d_tab);
-    hipFree(h->dv.n_corners), hipFree(h->dv.corners), hipFree(h->dv.dropped);
+    hipFree(h->dv.n_corners), hipFree(h->dv.corners), hipFree(h->dv.dropped), hipFree(h->dv.ticks);
     hipFree(h->dv.grid), hipFree(h->dv.peaks), hipFree(h->dv.n_lines), hipFree(h->dv.n_segs), hipFree(h->dv.lines), hipFree(h->dv.segs);
     if (h->e0) hipEventDestroy(h->e0);
     if (h->e1) hipEventDestroy(h->e1);
@@ -59,6 +59,7 @@ static int feat_create_impl(feat_batch *h) {
     FEAT_TRY(hipMalloc((void **)&h->dv.n_corners, S * sizeof(int)));
     FEAT_TRY(hipMalloc((void **)&h->dv.corners, S * h->max_corners * 2 * sizeof(double)));
     FEAT_TRY(hipMalloc((void **)&h->dv.dropped, S * sizeof(int)));
+    FEAT_TRY(hipMalloc((void **)&h->dv.ticks, S * 2 * sizeof(long long)));
     if (h->keep) {
         FEAT_TRY(hipMalloc((void **)&h->dv.grid, S * FEAT_THETA_SIZE * FEAT_RADIUS_SIZE));
         FEAT_TRY(hipMalloc((void **)&h->dv.peaks, S * FEAT_NUM_PEAKS * sizeof(int)));
@@ -149,6 +150,20 @@ extern "C" int feat_get_intermediates(feat_handle h, int scan, unsigned char *gr
     if (n_segs) *n_segs = ns;
     if (lines && nl > 0) FEAT_TRY(hipMemcpy(lines, h->dv.lines + s * FEAT_NUM_PEAKS * 3, (size_t)nl * 3 * sizeof(double), hipMemcpyDeviceToHost));
     if (segs && ns > 0) FEAT_TRY(hipMemcpy(segs, h->dv.segs + s * FEAT_MAX_SEGS * 7, (size_t)ns * 7 * sizeof(double), hipMemcpyDeviceToHost));
+    return EKF_OK;
+}
+
+extern "C" int feat_last_tail_share(feat_handle h, double *share_out) {
+    if (!h || !share_out) return ekf_set_last_error(EKF_ERR_BAD_ARG, "null argument");
+    *share_out = 0.0;
+    if (h->last_scans <= 0) return EKF_OK;
+    FEAT_TRY(hipSetDevice(h->device));
+    std::string buf((size_t)h->last_scans * 2 * sizeof(long long), '\0');
+    long long *t = (long long *)&buf[0];
+    FEAT_TRY(hipMemcpy(t, h->dv.ticks, buf.size(), hipMemcpyDeviceToHost));
+    double all = 0, tail = 0;
+    for (int s = 0; s < h->last_scans; s++) all += (double)t[2 * s], tail += (double)t[2 * s + 1];
+    *share_out = all > 0 ? tail / all : 0.0;
     return EKF_OK;
 }
 

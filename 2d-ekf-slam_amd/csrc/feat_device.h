@@ -35,4 +35,5 @@ struct FeatDev {
     int *peaks;                     // [S][200]
     int *n_lines, *n_segs;          // [S]
     double *lines, *segs;           // [S][200][3], [S][FEAT_MAX_SEGS][7]
+    long long *ticks;               // [S][2]: 100 MHz ticks of the scan's whole workgroup and of its tail (lines, segments, corners)
 };

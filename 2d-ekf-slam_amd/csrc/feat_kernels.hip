@@ -8,8 +8,8 @@
 // that beat the current lowest peak found by ballot and inserted in cell order, the 200 peak positions spread over the
 // wave's lanes (four per lane) with the "first lowest" rule as a DPP min-reduction of (value, position) keys.  The result
 // is the reference's peaks[] array entry for entry (which cell sits at which of the 200 positions decides how peaks group
-// into lines).  The small sequential tail (grouping, segments, corners: a few thousand operations per scan) runs on one
-// lane out of LDS; throughput comes from the number of scans in flight (3 workgroups per CU).
+// into lines).  The tail (grouping, merging, segments, corners) keeps the reference's order-dependent results but not its
+// loops: every stage gives a lane one group / line / segment to own and walks the ordered index uniformly (see "the tail").
 // Integer results (votes, peaks, groups) are bit-exact; the double results use the same expressions in the same order
 // with contraction off, the only difference to a host being the device's sin / cos (rounded to float as the reference does).
 #include <hip/hip_runtime.h>
@@ -34,210 +34,275 @@ __device__ __forceinline__ int wave_min_i32(int x) {
     return __builtin_amdgcn_readlane(x, 63);
 }
 
-struct FeatGroup {  // houghtransform.h:40-49
-    int maxRadius, minRadius, maxTheta, minTheta, radius, theta, weight, numPoints;
-};
-struct FeatSeg {  // featuredetector.h:45-52 (next: index into the pool, -1 = end)
-    double radius, theta, startX, startY, endX, endY;
-    int numPoints, next;
-};
-
+// LDS of one scan.  The tail's tables are structure-of-arrays so that a lane can own a group / a line / a segment pair and
+// reach any other one by index; integer fields that several lanes fold into (the merge of groups) are LDS atomics.
 struct FeatLds {
     unsigned row[2][FEAT_ROW_PAD];  // the theta row being scanned and the one being voted
     int pk_idx[FEAT_NUM_PEAKS], pk_val[FEAT_NUM_PEAKS];
-    FeatGroup groups[FEAT_NUM_PEAKS];
-    signed char merge[FEAT_NUM_PEAKS];
+    // peak groups (houghtransform.h:40-49), one per index
+    int g_maxR[FEAT_NUM_PEAKS], g_minR[FEAT_NUM_PEAKS], g_maxT[FEAT_NUM_PEAKS], g_minT[FEAT_NUM_PEAKS];
+    int g_rad[FEAT_NUM_PEAKS], g_th[FEAT_NUM_PEAKS], g_w[FEAT_NUM_PEAKS], g_n[FEAT_NUM_PEAKS];
+    int merge[FEAT_NUM_PEAKS];      // (values as the reference's `char mergeMatrix[size]` holds them: sign-extended 8 bits)
+    int n_groups, n_lines;
     double lines[FEAT_NUM_PEAKS][3];  // radius, theta, weight
-    float sn[FEAT_NUM_PEAKS], cs[FEAT_NUM_PEAKS];
-    int head[FEAT_NUM_PEAKS];
-    FeatSeg pool[FEAT_MAX_POINTS];
+    float sn[FEAT_NUM_PEAKS], cs[FEAT_NUM_PEAKS];  // of the lines, later of the segments
+    // segments: a pool of list nodes (featuredetector.h:45-52), one list per line, newest first
+    short assign[FEAT_MAX_POINTS];    // the line a reading belongs to, -1 = none
+    double p_sx[FEAT_MAX_POINTS], p_sy[FEAT_MAX_POINTS], p_ex[FEAT_MAX_POINTS], p_ey[FEAT_MAX_POINTS];
+    short p_np[FEAT_MAX_POINTS], p_next[FEAT_MAX_POINTS];
+    int n_pool;
+    short head[FEAT_NUM_PEAKS];
     double segs[FEAT_MAX_SEGS][7];
     int dropped;
 };
 
-// ---- the sequential tail, one lane ------------------------------------------------------------------------------------
-__device__ int feat_lines(FeatLds &L) {  // houghtransform.cpp:56-236
+// ---- the tail: peaks -> lines -> segments -> corners, by wave 0 ------------------------------------------------------------
+// The reference's loops carry order dependences (first fit, last writer wins, lists that grow at the head, push_back order),
+// but each of them is over ONE index; the other index is free.  So every stage gives a lane one object to own and walks the
+// ordered index in a uniform loop:
+//   grouping   (houghtransform.cpp:66-118)   peaks in order; lanes = groups; "the first group that fits" = lowest set bit of a ballot
+//   merge table (:170-195)                    groups i in order; lanes = groups j; "the last i < j that fits" = last writer in that loop
+//   merging     (:199-216)                    every merged group finds its root by itself and folds into it with integer LDS atomics
+//                                             (sums, min, max of ints: any order gives the reference's result)
+//   lines       (:219-236)                    lanes = groups; output position = number of roots with a smaller index (ballot prefix)
+//   closest line (featuredetector.cpp:107-121) one reading per thread of the whole workgroup (readings are independent there)
+//   segment lists (:124-190)                  readings in order; lanes = lines (lists of different lines never meet)
+//   good segments (:196-213)                  lanes = lines; output position = prefix sum over the lines before
+//   corners     (:224-289)                    segment i in order; lanes = segments j > i; ordered compaction by ballot prefix
+// Integer results are exact; doubles use the reference's expressions in its order with contraction off.
+
+// lanes below `lane` in a 64-bit ballot mask
+__device__ __forceinline__ int prefix_count(unsigned long long mask, int lane) { return __builtin_popcountll(mask & ((1ull << lane) - 1ull)); }
+
+__device__ void feat_lines(FeatLds &L, int lane) {  // houghtransform.cpp:56-236
 #pragma clang fp contract(off)
+    // group g lives in lane g % 64, register slot g / 64
+    int maxR[4], minR[4], maxT[4], minT[4], rad[4], th[4], w[4], np_[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) maxR[k] = minR[k] = maxT[k] = minT[k] = rad[k] = th[k] = w[k] = np_[k] = 0;
     int ng = 0;
     for (int i = 0; i < FEAT_NUM_PEAKS; i++) {
-        const int curRadius = L.pk_idx[i] % FEAT_RADIUS_SIZE, curTheta = L.pk_idx[i] / FEAT_RADIUS_SIZE, curWeight = L.pk_val[i];
-        if (curRadius <= 0) continue;
+        const int cell = f_uni(L.pk_idx[i]);
+        const int cr = cell % FEAT_RADIUS_SIZE, ct = cell / FEAT_RADIUS_SIZE, cw = f_uni(L.pk_val[i]);
+        if (cr <= 0) continue;
         bool merged = false;
-        for (int j = 0; j < ng; j++) {
-            FeatGroup &g = L.groups[j];
-            const int dTmax = abs(g.maxTheta - curTheta), dTmin = abs(g.minTheta - curTheta);
-            const int dRmax = abs(g.maxRadius - curRadius), dRmin = abs(g.minRadius - curRadius);
-            const bool tInside = (curTheta < g.maxTheta) && (curTheta > g.minTheta);
-            const bool rInside = (curRadius < g.maxRadius) && (curRadius > g.minRadius);
-            const bool inTheta = (dTmax < FEAT_MERGE_THETA) || (dTmin < FEAT_MERGE_THETA) || tInside;
-            const bool inRadius = (dRmax < FEAT_MERGE_RADIUS) || (dRmin < FEAT_MERGE_RADIUS) || rInside;
-            if (inTheta && inRadius) {
-                g.maxRadius = max(curRadius, g.maxRadius), g.minRadius = min(curRadius, g.minRadius);
-                g.maxTheta = max(curTheta, g.maxTheta), g.minTheta = min(curTheta, g.minTheta);
-                g.radius += curRadius * curWeight, g.theta += curTheta * curWeight, g.weight += curWeight, g.numPoints++;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (merged || k * 64 >= ng) continue;  // (uniform)
+            const bool in_t = (abs(maxT[k] - ct) < FEAT_MERGE_THETA) || (abs(minT[k] - ct) < FEAT_MERGE_THETA) || ((ct < maxT[k]) && (ct > minT[k]));
+            const bool in_r = (abs(maxR[k] - cr) < FEAT_MERGE_RADIUS) || (abs(minR[k] - cr) < FEAT_MERGE_RADIUS) || ((cr < maxR[k]) && (cr > minR[k]));
+            const unsigned long long fits = __ballot((lane + 64 * k) < ng && in_t && in_r);
+            if (fits) {  // the group with the lowest index takes the peak (:91-103)
+                if (lane == __builtin_ctzll(fits)) {
+                    maxR[k] = max(cr, maxR[k]), minR[k] = min(cr, minR[k]), maxT[k] = max(ct, maxT[k]), minT[k] = min(ct, minT[k]);
+                    rad[k] += cr * cw, th[k] += ct * cw, w[k] += cw, np_[k]++;
+                }
                 merged = true;
-                break;
             }
         }
-        if (!merged) {
-            FeatGroup g;
-            g.maxRadius = curRadius, g.maxTheta = curTheta, g.weight = curWeight, g.numPoints = 1;
-            g.minRadius = g.maxRadius, g.minTheta = g.maxTheta;
-            g.radius = g.minRadius * g.weight, g.theta = g.minTheta * g.weight;
-            L.groups[ng++] = g;
+        if (!merged && ng < FEAT_NUM_PEAKS) {  // a group of its own (:107-117)
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (k == (ng >> 6) && lane == (ng & 63)) maxR[k] = minR[k] = cr, maxT[k] = minT[k] = ct, w[k] = cw, np_[k] = 1, rad[k] = cr * cw, th[k] = ct * cw;
+            ng++;
         }
     }
     const int size = ng;
-    for (int i = 0; i < size; i++) {  // :122-134
-        FeatGroup &g = L.groups[i];
-        if (g.radius < FEAT_ADDITION * g.weight) {
-            g.radius = 2 * FEAT_ADDITION * g.weight - g.radius;
-            g.maxRadius = 2 * FEAT_ADDITION - g.maxRadius, g.minRadius = 2 * FEAT_ADDITION - g.minRadius;
-            g.theta -= FEAT_THETA_SIZE * g.weight;
-            g.maxTheta -= FEAT_THETA_SIZE, g.minTheta -= FEAT_THETA_SIZE;
+    // every group on the positive-radius side (:122-134), then into LDS where any lane can read it
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int g = lane + 64 * k;
+        if (g < size) {
+            if (rad[k] < FEAT_ADDITION * w[k]) {
+                rad[k] = 2 * FEAT_ADDITION * w[k] - rad[k];
+                maxR[k] = 2 * FEAT_ADDITION - maxR[k], minR[k] = 2 * FEAT_ADDITION - minR[k];
+                th[k] -= FEAT_THETA_SIZE * w[k];
+                maxT[k] -= FEAT_THETA_SIZE, minT[k] -= FEAT_THETA_SIZE;
+            }
+            L.g_maxR[g] = maxR[k], L.g_minR[g] = minR[k], L.g_maxT[g] = maxT[k], L.g_minT[g] = minT[k];
+            L.g_rad[g] = rad[k], L.g_th[g] = th[k], L.g_w[g] = w[k], L.g_n[g] = np_[k];
         }
     }
-    for (int i = 0; i < size; i++) L.merge[i] = -1;
-    for (int i = 0; i < size; i++) {  // :170-195
-        const FeatGroup m = L.groups[i];
-        for (int j = i + 1; j < size; j++) {
-            const FeatGroup &g = L.groups[j];
-            const int dTmax = abs(g.maxTheta - m.minTheta), dTmin = abs(g.minTheta - m.maxTheta);
-            const int dRmax = abs(g.maxRadius - m.minRadius), dRmin = abs(g.minRadius - m.maxRadius);
-            const bool tO = (m.maxTheta > g.minTheta) && (m.minTheta < g.maxTheta), rO = (m.maxRadius > g.minRadius) && (m.minRadius < g.maxRadius);
-            const bool inTheta = (dTmax < FEAT_MERGE_THETA) || (dTmin < FEAT_MERGE_THETA) || tO;
-            const bool inRadius = (dRmax < FEAT_MERGE_RADIUS) || (dRmin < FEAT_MERGE_RADIUS) || rO;
-            if (inTheta && inRadius) L.merge[j] = (signed char)i;  // (`char mergeMatrix[size]`, :165)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // which group each group merges into: the LAST i < j close enough, as the loops of :170-195 leave it (values before any merge)
+    int mg[4] = {-1, -1, -1, -1};
+    for (int i = 0; i < size; i++) {
+        const int iMaxT = f_uni(L.g_maxT[i]), iMinT = f_uni(L.g_minT[i]), iMaxR = f_uni(L.g_maxR[i]), iMinR = f_uni(L.g_minR[i]);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int j = lane + 64 * k;
+            const bool in_t = (abs(maxT[k] - iMinT) < FEAT_MERGE_THETA) || (abs(minT[k] - iMaxT) < FEAT_MERGE_THETA) || ((iMaxT > minT[k]) && (iMinT < maxT[k]));
+            const bool in_r = (abs(maxR[k] - iMinR) < FEAT_MERGE_RADIUS) || (abs(minR[k] - iMaxR) < FEAT_MERGE_RADIUS) || ((iMaxR > minR[k]) && (iMinR < maxR[k]));
+            if (j > i && j < size && in_t && in_r) mg[k] = (int)(signed char)i;  // (`char mergeMatrix[size]`, :165)
         }
     }
-    for (int i = 0; i < size; i++) {  // :199-216
-        if (L.merge[i] == -1) continue;
-        int j = i;
-        while (j >= 0 && L.merge[j] != -1) j = L.merge[j];
-        if (j < 0) continue;  // more than 127 groups: undefined in the reference
-        const FeatGroup m = L.groups[i];
-        FeatGroup &g = L.groups[j];
-        g.maxRadius = max(m.maxRadius, g.maxRadius), g.minRadius = min(m.minRadius, g.minRadius);
-        g.maxTheta = max(m.maxTheta, g.maxTheta), g.minTheta = min(m.minTheta, g.minTheta);
-        g.radius += m.radius, g.theta += m.theta, g.weight += m.weight, g.numPoints += m.numPoints;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        if (lane + 64 * k < size) L.merge[lane + 64 * k] = mg[k];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // every merged group folds into the root of its chain (:199-216): the roots are never merged themselves, the merged ones are
+    // never folded into, so the reference's in-order loop and these atomics produce the same integers
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int g = lane + 64 * k;
+        if (g < size && mg[k] != -1) {
+            int j = g;
+            while (j >= 0 && L.merge[j] != -1) j = L.merge[j];
+            if (j >= 0) {  // (more than 127 groups: undefined in the reference)
+                atomicMax(&L.g_maxR[j], maxR[k]), atomicMin(&L.g_minR[j], minR[k]), atomicMax(&L.g_maxT[j], maxT[k]), atomicMin(&L.g_minT[j], minT[k]);
+                atomicAdd(&L.g_rad[j], rad[k]), atomicAdd(&L.g_th[j], th[k]), atomicAdd(&L.g_w[j], w[k]), atomicAdd(&L.g_n[j], np_[k]);
+            }
+        }
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // roots become lines, in index order (:219-236)
     int nl = 0;
-    for (int i = 0; i < size; i++) {  // :219-236
-        if (L.merge[i] != -1) continue;
-        const FeatGroup &g = L.groups[i];
-        double theta = g.theta / (double)g.weight;
-        theta *= 3.141592654 / FEAT_THETA_SIZE;
-        double radius = g.radius / (double)g.weight;
-        radius -= FEAT_ADDITION;
-        radius *= FEAT_DISTANCE;
-        L.lines[nl][0] = radius, L.lines[nl][1] = theta, L.lines[nl][2] = g.weight / (double)g.numPoints;
-        nl++;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int g = lane + 64 * k;
+        const bool root = g < size && mg[k] == -1;
+        const unsigned long long roots = __ballot(root);
+        if (root) {
+            const int o = nl + prefix_count(roots, lane);
+            const int gw = L.g_w[g];
+            double theta = L.g_th[g] / (double)gw;
+            theta *= 3.141592654 / FEAT_THETA_SIZE;
+            double radius = L.g_rad[g] / (double)gw;
+            radius -= FEAT_ADDITION;
+            radius *= FEAT_DISTANCE;
+            L.lines[o][0] = radius, L.lines[o][1] = theta, L.lines[o][2] = gw / (double)L.g_n[g];
+            L.sn[o] = (float)sin(theta), L.cs[o] = (float)cos(theta);  // (fitLineSegments' float tables, featuredetector.cpp:86-90)
+            L.head[o] = -1;
+        }
+        nl += __builtin_popcountll(roots);
     }
-    return nl;
+    if (lane == 0) L.n_groups = size, L.n_lines = nl, L.n_pool = 0;
 }
 
-__device__ int feat_segments(FeatLds &L, int n, const double *range, const double *lx, const double *ly, int nlines) {  // featuredetector.cpp:74-220
+// the line closest to reading r (featuredetector.cpp:99-121): strict '<' from line 0, so the first of equally close lines wins
+__device__ __forceinline__ void feat_assign(FeatLds &L, int r, double range, double locX, double locY, int nl) {
 #pragma clang fp contract(off)
-    for (int i = 0; i < nlines; i++) {
-        const double theta = L.lines[i][1];
-        L.sn[i] = (float)sin(theta), L.cs[i] = (float)cos(theta);
-        L.head[i] = -1;
-    }
-    int npool = 0;
-    for (int r = 0; r < n; r++) {
-        if (range[r] > FEAT_MAX_DIST) continue;
+    int mindex = -1;
+    if (!(range > FEAT_MAX_DIST)) {
         double minDiff = 1000000.0;
-        const double locX = lx[r], locY = ly[r];
-        int mindex = 0;
-        for (int l = 0; l < nlines; l++) {
+        for (int l = 0; l < nl; l++) {
             const double curRad = locX * (double)L.cs[l] + locY * (double)L.sn[l];
             const double curDiff = fabs(L.lines[l][0] - curRad);
             if (curDiff < minDiff) minDiff = curDiff, mindex = l;
         }
-        if (minDiff > FEAT_POINT_DIST) continue;
-        int s = L.head[mindex];
-        if (fabsf(L.sn[mindex]) > fabsf(L.cs[mindex])) {
-            while (s != -1) {
-                FeatSeg &g = L.pool[s];
-                if ((locX <= g.startX) && (locX >= g.endX)) {
-                    g.numPoints++;
-                    break;
-                } else if ((locX > g.startX) && (fabs(locX - g.startX) <= FEAT_POINT_DIST)) {
-                    g.startX = locX, g.startY = locY, g.numPoints++;
-                    break;
-                } else if ((locX < g.endX) && (fabs(locX - g.endX) <= FEAT_POINT_DIST)) {
-                    g.endX = locX, g.endY = locY, g.numPoints++;
-                    break;
-                } else s = g.next;
-            }
-        } else {
-            while (s != -1) {
-                FeatSeg &g = L.pool[s];
-                if ((locY <= g.startY) && (locY >= g.endY)) {
-                    g.numPoints++;
-                    break;
-                } else if ((locY > g.startY) && (fabs(locY - g.startY) <= FEAT_POINT_DIST)) {
-                    g.startX = locX, g.startY = locY, g.numPoints++;
-                    break;
-                } else if ((locY < g.endY) && (fabs(locY - g.endY) <= FEAT_POINT_DIST)) {
-                    g.endX = locX, g.endY = locY, g.numPoints++;
-                    break;
-                } else s = g.next;
-            }
-        }
-        if (s == -1 && npool < FEAT_MAX_POINTS) {
-            FeatSeg &g = L.pool[npool];
-            g.theta = L.lines[mindex][1], g.radius = L.lines[mindex][0];
-            g.numPoints = 1;
-            g.startX = locX, g.startY = locY, g.endX = locX, g.endY = locY;
-            g.next = L.head[mindex];
-            L.head[mindex] = npool++;
-        }
+        if (minDiff > FEAT_POINT_DIST) mindex = -1;
     }
-    int count = 0;
-    for (int i = 0; i < nlines; i++)
-        for (int s = L.head[i]; s != -1; s = L.pool[s].next)
-            if (L.pool[s].numPoints > FEAT_MIN_POINTS) {
-                if (count < FEAT_MAX_SEGS) {
-                    const FeatSeg &g = L.pool[s];
-                    double *o = L.segs[count];
-                    o[0] = g.radius, o[1] = g.theta, o[2] = g.startX, o[3] = g.startY, o[4] = g.endX, o[5] = g.endY, o[6] = g.numPoints;
-                }
-                count++;
-            }
-    return count;
+    L.assign[r] = (short)mindex;
 }
 
-__device__ int feat_corners(FeatLds &L, int nseg, double *corners, int max_corners) {  // featuredetector.cpp:224-289
+__device__ int feat_segments(FeatLds &L, int lane, int n, const double *lx, const double *ly, int nl) {  // featuredetector.cpp:124-213
+#pragma clang fp contract(off)
+    int total = 0;
+    for (int base = 0; base < nl; base += 64) {  // 64 lines at a time, a lane per line
+        const int l = base + lane;
+        const bool mine = l < nl;
+        const bool horizontalish = mine && fabsf(L.sn[mine ? l : 0]) > fabsf(L.cs[mine ? l : 0]);
+        int head = -1, good = 0;
+        for (int r = 0; r < n; r++) {  // readings in scan order
+            if (!mine || L.assign[r] != l) continue;
+            const double locX = lx[r], locY = ly[r];
+            const double key = horizontalish ? locX : locY;  // the coordinate the segment is ordered along (:127 / :158)
+            int sg = head;
+            while (sg != -1) {
+                const double ks = horizontalish ? L.p_sx[sg] : L.p_sy[sg], ke = horizontalish ? L.p_ex[sg] : L.p_ey[sg];
+                if ((key <= ks) && (key >= ke)) {  // inside
+                    L.p_np[sg]++;
+                    break;
+                } else if ((key > ks) && (fabs(key - ks) <= FEAT_POINT_DIST)) {  // extends the start end
+                    L.p_sx[sg] = locX, L.p_sy[sg] = locY, L.p_np[sg]++;
+                    break;
+                } else if ((key < ke) && (fabs(key - ke) <= FEAT_POINT_DIST)) {  // extends the end end
+                    L.p_ex[sg] = locX, L.p_ey[sg] = locY, L.p_np[sg]++;
+                    break;
+                }
+                sg = L.p_next[sg];
+            }
+            if (sg == -1) {  // a new segment at the head of the line's list (:179-189)
+                const int nw = atomicAdd(&L.n_pool, 1);  // (which node a lane gets does not matter: lists are per line)
+                if (nw < FEAT_MAX_POINTS) {
+                    L.p_sx[nw] = locX, L.p_sy[nw] = locY, L.p_ex[nw] = locX, L.p_ey[nw] = locY;
+                    L.p_np[nw] = 1, L.p_next[nw] = (short)head;
+                    head = nw;
+                }
+            }
+        }
+        if (mine) {
+            for (int sg = head; sg != -1; sg = L.p_next[sg]) good += L.p_np[sg] > FEAT_MIN_POINTS ? 1 : 0;
+            L.head[l] = (short)head;
+        }
+        // output positions: the good segments of line l follow those of the lines before it (:196-213)
+        int incl = good;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += o;
+        }
+        int o = total + incl - good;
+        if (mine)
+            for (int sg = head; sg != -1; sg = L.p_next[sg])
+                if (L.p_np[sg] > FEAT_MIN_POINTS) {
+                    if (o < FEAT_MAX_SEGS) {
+                        double *out = L.segs[o];
+                        out[0] = L.lines[l][0], out[1] = L.lines[l][1], out[2] = L.p_sx[sg], out[3] = L.p_sy[sg], out[4] = L.p_ex[sg], out[5] = L.p_ey[sg], out[6] = L.p_np[sg];
+                    }
+                    o++;
+                }
+        total += __shfl(incl, 63, 64);
+    }
+    return total;
+}
+
+__device__ int feat_corners(FeatLds &L, int lane, int nseg, double *corners, int max_corners) {  // featuredetector.cpp:224-289
 #pragma clang fp contract(off)
     const double CORNER_THETA = 22.0 * 3.141592654 / 180.0;
-    for (int i = 0; i < nseg; i++) L.sn[i] = (float)sin(L.segs[i][1]), L.cs[i] = (float)cos(L.segs[i][1]);
+    for (int i = lane; i < nseg; i += 64) L.sn[i] = (float)sin(L.segs[i][1]), L.cs[i] = (float)cos(L.segs[i][1]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     int count = 0;
-    for (int i = 0; i < nseg; i++) {
-        const double *s1 = L.segs[i];
-        for (int j = i + 1; j < nseg; j++) {
-            const double *s2 = L.segs[j];
-            double thetaDiff = fabs(s1[1] - s2[1]);
-            if (thetaDiff > 3.141592654) thetaDiff = fabs(thetaDiff - 6.283185307);
-            if (thetaDiff > 1.570796327) thetaDiff = fabs(thetaDiff - 3.141592654);
-            if (thetaDiff < CORNER_THETA) continue;
-            const float p1 = L.cs[i] * L.sn[j], p2 = L.sn[i] * L.cs[j];  // float products, float difference (:251)
-            const double det = (double)(p1 - p2);
-            const double x = (s1[0] * (double)L.sn[j] - s2[0] * (double)L.sn[i]) / det;
-            const double y = (s2[0] * (double)L.cs[i] - s1[0] * (double)L.cs[j]) / det;
-            double dx, dy;
-            dx = s1[2] - x, dy = s1[3] - y;
-            const bool start1 = (dx * dx + dy * dy) < FEAT_CORNER_DIST;
-            dx = s1[4] - x, dy = s1[5] - y;
-            const bool end1 = (dx * dx + dy * dy) < FEAT_CORNER_DIST;
-            dx = s2[2] - x, dy = s2[3] - y;
-            const bool start2 = (dx * dx + dy * dy) < FEAT_CORNER_DIST;
-            dx = s2[4] - x, dy = s2[5] - y;
-            const bool end2 = (dx * dx + dy * dy) < FEAT_CORNER_DIST;
-            if ((start1 || end1) && (start2 || end2) && ((x * x + y * y) > FEAT_MIN_DIST)) {
-                if (count < max_corners) corners[count * 2] = x, corners[count * 2 + 1] = y;
-                count++;
+    for (int i = 0; i + 1 < nseg; i++) {
+        const double r1 = L.segs[i][0], t1 = L.segs[i][1], sx1 = L.segs[i][2], sy1 = L.segs[i][3], ex1 = L.segs[i][4], ey1 = L.segs[i][5];
+        const float sn1 = L.sn[i], cs1 = L.cs[i];
+        for (int jb = i + 1; jb < nseg; jb += 64) {  // partners j > i, 64 at a time, in order
+            const int j = jb + lane;
+            bool hit = false;
+            double x = 0, y = 0;
+            if (j < nseg) {
+                const double *s2 = L.segs[j];
+                double thetaDiff = fabs(t1 - s2[1]);
+                if (thetaDiff > 3.141592654) thetaDiff = fabs(thetaDiff - 6.283185307);
+                if (thetaDiff > 1.570796327) thetaDiff = fabs(thetaDiff - 3.141592654);
+                if (!(thetaDiff < CORNER_THETA)) {
+                    const float sn2 = L.sn[j], cs2 = L.cs[j];
+                    const float p1 = cs1 * sn2, p2 = sn1 * cs2;  // float products, float difference (:251)
+                    const double det = (double)(p1 - p2);
+                    x = (r1 * (double)sn2 - s2[0] * (double)sn1) / det;
+                    y = (s2[0] * (double)cs1 - r1 * (double)cs2) / det;
+                    double dx, dy;
+                    dx = sx1 - x, dy = sy1 - y;
+                    const bool start1 = (dx * dx + dy * dy) < FEAT_CORNER_DIST;
+                    dx = ex1 - x, dy = ey1 - y;
+                    const bool end1 = (dx * dx + dy * dy) < FEAT_CORNER_DIST;
+                    dx = s2[2] - x, dy = s2[3] - y;
+                    const bool start2 = (dx * dx + dy * dy) < FEAT_CORNER_DIST;
+                    dx = s2[4] - x, dy = s2[5] - y;
+                    const bool end2 = (dx * dx + dy * dy) < FEAT_CORNER_DIST;
+                    hit = (start1 || end1) && (start2 || end2) && ((x * x + y * y) > FEAT_MIN_DIST);
+                }
             }
+            const unsigned long long hits = __ballot(hit);
+            if (hit) {
+                const int o = count + prefix_count(hits, lane);
+                if (o < max_corners) corners[o * 2] = x, corners[o * 2 + 1] = y;
+            }
+            count += __builtin_popcountll(hits);
         }
     }
     return count;
@@ -250,6 +315,8 @@ __global__ __launch_bounds__(256) void k_features(FeatDev dv) {
     const bool w0 = f_uni(tid < 64) != 0;
     const int n = min(dv.npts[s], dv.P);
     const double *range = dv.range + (size_t)s * dv.P, *lx = dv.lx + (size_t)s * dv.P, *ly = dv.ly + (size_t)s * dv.P;
+    long long t_start = 0;
+    if (tid == 0 && dv.ticks) t_start = (long long)wall_clock64();
     for (int i = tid; i < 2 * FEAT_ROW_PAD; i += 256) (&L.row[0][0])[i] = 0;
     if (tid == 0) L.dropped = 0;
     __syncthreads();
@@ -336,19 +403,31 @@ __global__ __launch_bounds__(256) void k_features(FeatDev dv) {
         }
     }
     __syncthreads();
-    if (tid == 0) {
-        const int nl = feat_lines(L);
-        int ns = feat_segments(L, n, range, lx, ly, nl);
-        if (ns > FEAT_MAX_SEGS) ns = FEAT_MAX_SEGS;
-        const int nc = feat_corners(L, ns, dv.corners + (size_t)s * dv.max_corners * 2, dv.max_corners);
-        dv.n_corners[s] = nc;
-        if (dv.dropped) dv.dropped[s] = L.dropped;
-        if (dv.n_lines) {
-            dv.n_lines[s] = nl, dv.n_segs[s] = ns;
-            for (int i = 0; i < nl; i++)
-                for (int c = 0; c < 3; c++) dv.lines[((size_t)s * FEAT_NUM_PEAKS + i) * 3 + c] = L.lines[i][c];
-            for (int i = 0; i < ns; i++)
-                for (int c = 0; c < 7; c++) dv.segs[((size_t)s * FEAT_MAX_SEGS + i) * 7 + c] = L.segs[i][c];
+    long long t_tail = 0;
+    if (tid == 0 && dv.ticks) t_tail = (long long)wall_clock64();
+    if (w0) feat_lines(L, lane);
+    __syncthreads();
+    const int nl = L.n_lines;
+    for (int r = tid; r < n; r += 256) feat_assign(L, r, range[r], lx[r], ly[r], nl);
+    __syncthreads();
+    if (w0) {
+        const int ns_all = feat_segments(L, lane, n, lx, ly, nl);
+        const int ns = ns_all > FEAT_MAX_SEGS ? FEAT_MAX_SEGS : ns_all;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (dv.n_lines) {  // (before the corners reuse the float tables)
+            if (lane == 0) dv.n_lines[s] = nl, dv.n_segs[s] = ns;
+            for (int i = lane; i < nl * 3; i += 64) dv.lines[(size_t)s * FEAT_NUM_PEAKS * 3 + i] = (&L.lines[0][0])[i];
+            for (int i = lane; i < ns * 7; i += 64) dv.segs[(size_t)s * FEAT_MAX_SEGS * 7 + i] = (&L.segs[0][0])[i];
+        }
+        const int nc = feat_corners(L, lane, ns, dv.corners + (size_t)s * dv.max_corners * 2, dv.max_corners);
+        if (lane == 0) {
+            dv.n_corners[s] = nc;
+            if (dv.dropped) dv.dropped[s] = L.dropped;
+            if (dv.ticks) {
+                const long long t_end = (long long)wall_clock64();
+                dv.ticks[2 * (size_t)s] = t_end - t_start, dv.ticks[2 * (size_t)s + 1] = t_end - t_tail;
+            }
         }
     }
 }

@@ -8,7 +8,7 @@ import numpy as np
 from . import ekfslam
 
 THETA_SIZE, RADIUS_SIZE, NUM_PEAKS, MAX_SEGS, MAX_POINTS = 180, 1601, 200, 128, 384
-FEAT_ABI_SYMBOLS = ["feat_create", "feat_destroy", "feat_extract", "feat_get_intermediates", "feat_last_kernel_ms"]
+FEAT_ABI_SYMBOLS = ["feat_create", "feat_destroy", "feat_extract", "feat_get_intermediates", "feat_last_kernel_ms", "feat_last_tail_share"]
 
 _dp = ctypes.POINTER(ctypes.c_double)
 _ip = ctypes.POINTER(ctypes.c_int)
@@ -26,6 +26,7 @@ def _lib():
         L.feat_extract.argtypes = [_H, ctypes.c_int, _ip, _dp, _dp, _dp, _ip, _dp]
         L.feat_get_intermediates.argtypes = [_H, ctypes.c_int, _up, _ip, _ip, _dp, _ip, _dp, _ip]
         L.feat_last_kernel_ms.argtypes = [_H, _dp]
+        L.feat_last_tail_share.argtypes = [_H, _dp]
         _bound = True
     return L
 
@@ -81,3 +82,9 @@ class FeatureExtractor:
         ms = ctypes.c_double(0)
         ekfslam._chk(self.L.feat_last_kernel_ms(self.h, ctypes.byref(ms)))
         return ms.value
+
+    def tail_share(self):
+        """Share of a scan's workgroup time behind the peak selection (grouping, merging, segments, corners) in the last extract."""
+        v = ctypes.c_double(0)
+        ekfslam._chk(self.L.feat_last_tail_share(self.h, ctypes.byref(v)))
+        return v.value

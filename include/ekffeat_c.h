@@ -50,6 +50,10 @@ int feat_get_intermediates(feat_handle h, int scan, unsigned char *grid, int *pe
 /* Device time of the last feat_extract's kernel in milliseconds (hipEvents around the launch). */
 int feat_last_kernel_ms(feat_handle h, double *ms_out);
 
+/* Share of a scan's workgroup time that the last feat_extract spent behind the peak selection -- grouping, merging, segments,
+ * corners -- averaged over its scans (wall-clock ticks taken inside the kernel). */
+int feat_last_tail_share(feat_handle h, double *share_out);
+
 #ifdef __cplusplus
 }
 #endif
