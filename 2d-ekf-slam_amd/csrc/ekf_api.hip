@@ -1359,6 +1359,19 @@ extern "C" int ekf_get_stats(ekf_handle h, ekf_stats *out) {
     return EKF_OK;
 }
 
+extern "C" int ekf_stats_means_device(ekf_handle h, double *out_device) {
+    if (!h || !out_device) return set_error(EKF_ERR_BAD_ARG, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, out_device) != hipSuccess || (attr.type != hipMemoryTypeDevice && attr.type != hipMemoryTypeManaged)) {
+        (void)hipGetLastError();
+        return set_error(EKF_ERR_BAD_ARG, "ekf_stats_means_device wants device memory");
+    }
+    hipLaunchKernelGGL(k_stats_means, dim3(cdiv(h->dv.B, 256)), dim3(256), 0, h->s_chain, (const ekf_stats *)h->dv.stats, h->dv.B, out_device);
+    HIP_TRY(stream_wait(h->s_chain));
+    return check_launch();
+}
+
 extern "C" int ekf_reset_stats(ekf_handle h) {
     if (!h) return set_error(EKF_ERR_BAD_ARG, "null handle");
     HIP_TRY(hipSetDevice(h->device));

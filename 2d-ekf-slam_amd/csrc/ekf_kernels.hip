@@ -1662,6 +1662,16 @@ __global__ void k_mark(int *flag, int value) {
     if (threadIdx.x == 0) __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// per-filter (mean NIS, mean NEES) into device memory: the send buffer of the multi-GPU all-gather
+__global__ void k_stats_means(const ekf_stats *st, int B, double *out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const ekf_stats s = st[b];
+    const double nan = __longlong_as_double(0x7ff8000000000000LL);
+    out[2 * b] = s.nis_count > 0 ? s.nis_sum / (double)s.nis_count : nan;
+    out[2 * b + 1] = s.nees_count > 0 ? s.nees_sum / (double)s.nees_count : nan;
+}
+
 // Holds a stream for `ticks` of the 100 MHz wall clock: the phase shift between the groups of a batch of one-workgroup filters.
 __global__ void k_delay(long long ticks) {
     if (threadIdx.x == 0) {

@@ -22,7 +22,7 @@ ABI_SYMBOLS = [
     "ekf_batch_update_compass", "ekf_batch_get_pose", "ekf_batch_num_landmarks", "ekf_get_state", "ekf_set_state",
     "ekf_broadcast_state", "ekf_script_load", "ekf_script_run", "ekf_sync", "ekf_flush", "ekf_close_window", "ekf_timer_start",
     "ekf_timer_stop", "ekf_flush_profile", "ekf_flush_profile_read", "ekf_get_decisions", "ekf_get_stats",
-    "ekf_reset_stats", "ekf_record_truth", "ekf_stream", "ekf_device_bytes",
+    "ekf_reset_stats", "ekf_stats_means_device", "ekf_record_truth", "ekf_stream", "ekf_device_bytes",
 ]
 
 
@@ -105,6 +105,7 @@ def load():
     L.ekf_get_decisions.argtypes = [_H, ctypes.c_int, ctypes.POINTER(EkfDecision), ctypes.c_int]
     L.ekf_get_stats.argtypes = [_H, ctypes.POINTER(EkfStats)]
     L.ekf_reset_stats.argtypes = [_H]
+    L.ekf_stats_means_device.argtypes = [_H, ctypes.c_void_p]
     L.ekf_record_truth.argtypes = [_H, _dp]
     L.ekf_stream.argtypes = [_H]
     L.ekf_stream.restype = ctypes.c_void_p
@@ -304,6 +305,11 @@ class FilterBatch:
 
     def reset_stats(self):
         _chk(self.L.ekf_reset_stats(self.h))
+
+    def stats_means_into(self, device_ptr):
+        """(mean NIS, mean NEES) per filter, [batch][2] doubles, written by the device into device memory at `device_ptr`
+        (e.g. torch_tensor.data_ptr()): the send buffer of the multi-GPU all-gather, no host bounce."""
+        _chk(self.L.ekf_stats_means_device(self.h, ctypes.c_void_p(int(device_ptr))))
 
     def record_truth(self, truth):
         t = _f64(truth).reshape(self.batch, 3)

@@ -43,23 +43,55 @@ def summarise(stats):
     return out
 
 
-def gather_stats(local, device=None):
-    """All-gather [n_local, 2] summaries into [world * n_local, 2], ordered by global filter index.
-    Every rank must pass the same n_local (pad with NaN rows otherwise).  Without an initialised
-    process group this is the identity."""
+def gather_stats(local, device=None, total_filters=None):
+    """All-gather per-filter summaries [n_local, 2] into [total, 2], ordered by global filter index.
+
+    `local` is a NumPy array (host) or a torch tensor -- a tensor already on the collective's device goes into the all-gather
+    as it is (gather_device_stats: no host bounce).  Ranks of an uneven partition (shard_range with total % world != 0) hold
+    different numbers of rows: pass `total_filters`; every rank then pads its block with NaN rows to the largest block, the
+    equal-size all-gather runs, and the padding is dropped again.  Without an initialised process group: the identity."""
     import torch
     import torch.distributed as dist
 
-    local = np.ascontiguousarray(local, dtype=np.float64)
+    is_tensor = isinstance(local, torch.Tensor)
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return local.copy()
-    world = dist.get_world_size()
-    t = torch.from_numpy(local)
-    if device is not None:
+        return local.detach().cpu().numpy().copy() if is_tensor else np.ascontiguousarray(local, dtype=np.float64).copy()
+    world, rank = dist.get_world_size(), dist.get_rank()
+    t = local if is_tensor else torch.from_numpy(np.ascontiguousarray(local, dtype=np.float64))
+    if device is not None and t.device != torch.device(device):
         t = t.to(device)
-    out = torch.empty((world * local.shape[0], local.shape[1]), dtype=torch.float64, device=t.device)
+    rows = t.shape[0]
+    if total_filters is not None:
+        rows = max(hi - lo for lo, hi in (shard_range(total_filters, r, world) for r in range(world)))
+        lo, hi = shard_range(total_filters, rank, world)
+        assert hi - lo == t.shape[0], "this rank holds %d filters, shard_range says %d" % (t.shape[0], hi - lo)
+        if t.shape[0] < rows:
+            pad = torch.full((rows - t.shape[0], t.shape[1]), float("nan"), dtype=t.dtype, device=t.device)
+            t = torch.cat([t, pad], dim=0)
+    t = t.contiguous()
+    out = torch.empty((world * rows, t.shape[1]), dtype=torch.float64, device=t.device)
     dist.all_gather_into_tensor(out, t)
-    return out.cpu().numpy()
+    res = out.cpu().numpy()
+    if total_filters is not None:
+        keep = np.concatenate([np.arange(r * rows, r * rows + (hi - lo)) for r, (lo, hi) in enumerate(shard_range(total_filters, q, world) for q in range(world))])
+        res = res[keep]
+    return res
+
+
+def gather_device_stats(f, device, total_filters=None):
+    """The one collective of a multi-GPU run, straight from the device: the library writes every filter's (mean NIS, mean NEES)
+    into a tensor on `device` (ekf_stats_means_device), which is the all-gather's send buffer.  On a CPU device (gloo
+    rehearsals) the summary goes through the host mirror as before."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return summarise(f.stats_array())  # one rank: nothing to gather, the counters come from the host-mapped mirror (no copy, no launch)
+    if torch.device(device).type == "cuda":
+        t = torch.empty((f.batch, 2), dtype=torch.float64, device=device)
+        f.stats_means_into(t.data_ptr())
+        return gather_stats(t, device=device, total_filters=total_filters)
+    return gather_stats(summarise(f.stats_array()), device=device, total_filters=total_filters)
 
 
 def consistency_report(summary, nis_samples_per_filter, nees_samples_per_filter, alpha=0.05):

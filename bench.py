@@ -79,7 +79,7 @@ def timed_steps(f, mc, torch, dist, coll_device, W, K, graph):
     f.script_run(0, W, use_graph=graph)
     f.flush()
     f.timer_stop()
-    mc.gather_stats(mc.summarise(f.stats_array()), device=coll_device)
+    mc.gather_device_stats(f, coll_device)
     f.sync()
     f.reset_stats()
     f.flush_profile_read()
@@ -93,8 +93,7 @@ def timed_steps(f, mc, torch, dist, coll_device, W, K, graph):
     t1 = time.perf_counter()
     dev_ms = f.timer_stop()  # hipEvents on the handle's own stream
     t2 = time.perf_counter()
-    summary = mc.summarise(f.stats_array())
-    gathered = mc.gather_stats(summary, device=coll_device)  # the one collective (RCCL all-gather)
+    gathered = mc.gather_device_stats(f, coll_device)  # the one collective (RCCL all-gather), fed from the device's own summary buffer
     t3 = time.perf_counter()
     torch.cuda.synchronize()
     if dist is not None:

@@ -30,6 +30,7 @@
 #include "../include/ekfslam_c.h"
 
 #define INF 999999999999 /* kalmanfilter.h:17 */
+#define PI 3.141592653589793238462643383279502884197169399375105820974944592307816406286 /* kalmanfilter.h:18 (unused by the filter itself, which writes 3.141592654) */
 
 class KalmanFilter {
 public:

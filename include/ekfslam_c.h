@@ -179,6 +179,10 @@ int ekf_flush_profile_read(ekf_handle h, long long *launches_out, double *total_
 int ekf_get_decisions(ekf_handle h, int index, ekf_decision *out, int count);
 int ekf_get_stats(ekf_handle h, ekf_stats *out /*[batch]*/);
 int ekf_reset_stats(ekf_handle h);
+/* Per-filter means of the counters, [batch][2] = (mean NIS, mean NEES), NaN without samples, written by a kernel on the
+ * handle's stream straight into DEVICE memory at out_device (synchronises): the send buffer of the one collective of a
+ * multi-GPU run (RCCL all-gather of [filters_per_gpu][2] doubles) without a trip through the host. */
+int ekf_stats_means_device(ekf_handle h, double *out_device /*[batch][2], device memory*/);
 /* One NEES sample against a ground-truth pose, truth [batch][3]. */
 int ekf_record_truth(ekf_handle h, const double *truth);
 /* The HIP stream (hipStream_t) the handle launches on, for callers that want to order their own work. */

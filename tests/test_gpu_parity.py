@@ -1215,3 +1215,36 @@ def test_batch_of_multi_workgroup_filters_uneven_masks_200_windows(pkg, oc, monk
         assert_state_close(xg, Pg, xo, Po, "seed %d filter %d" % (seed, b))
         assert_bitwise_symmetric(Pg)
     f.close()
+
+
+def test_stats_means_on_the_device_equal_the_host_summary(pkg):
+    """ekf_stats_means_device: the send buffer of the multi-GPU all-gather is written by the device (mean NIS, mean NEES per
+    filter, NaN without samples) -- same numbers as the host-side summary of the counters."""
+    B, N, M, steps = 5, 40, 2, 12
+    f = pkg.FilterBatch(B, N, log_capacity=256)
+    scripts = []
+    for b in range(B):
+        x0, P0 = pkg.scenarios.injected_state(N, seed=40 + b, extent=8.0)
+        f.set_state(x0, P0, index=b)
+        scripts.append(pkg.scenarios.steady_script(x0, steps=steps, M=M, seed=50 + b, min_separation=0.8))
+    valid = np.ones((steps, M, B), dtype=np.uint8)
+    valid[:, :, 3] = 0  # a filter without a single NIS sample
+    f.script_load(np.stack([s["ctrl"] for s in scripts], axis=1), np.stack([s["z"] for s in scripts], axis=2), np.stack([s["R"] for s in scripts], axis=2),
+                  valid=valid, truth=np.stack([s["truth"] for s in scripts], axis=1))
+    f.script_run(0, steps)
+    f.sync()
+    # (device memory from the HIP runtime the library itself uses: importing torch after it would bring a second runtime)
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    ptr = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(ptr), ctypes.c_size_t(B * 2 * 8)) == 0
+    f.stats_means_into(ptr.value)
+    host = pkg.montecarlo.summarise(f.stats_array())
+    dev = np.zeros((B, 2))
+    assert hip.hipMemcpy(dev.ctypes.data_as(ctypes.c_void_p), ptr, ctypes.c_size_t(B * 2 * 8), 2) == 0  # hipMemcpyDeviceToHost
+    hip.hipFree(ptr)
+    assert np.isnan(dev[3, 0]) and np.isnan(host[3, 0]) and np.isfinite(dev[3, 1])
+    assert np.array_equal(np.isnan(dev), np.isnan(host)) and np.allclose(dev[np.isfinite(dev)], host[np.isfinite(host)], rtol=1e-15, atol=0)
+    with pytest.raises(pkg.ekfslam.EkfError):
+        f.stats_means_into(np.zeros((B, 2)).ctypes.data)  # host memory is refused
+    f.close()

@@ -59,7 +59,7 @@ def _worker(rank, world, port, total, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     lo, hi = mc.shard_range(total, rank, world)
     local = np.stack([np.arange(lo, hi, dtype=np.float64), 100.0 + np.arange(lo, hi)], axis=1)  # rows tagged by global index
-    out = mc.gather_stats(local)
+    out = mc.gather_stats(local, total_filters=total)
     if rank == 0:
         q.put(out)
     dist.barrier()
@@ -81,6 +81,26 @@ def test_gather_stats_two_ranks_gloo(pkg):
         p.join(timeout=120)
         assert p.exitcode == 0
     assert out.shape == (total, 2)
+    assert np.array_equal(out[:, 0], np.arange(total)) and np.array_equal(out[:, 1], 100.0 + np.arange(total))
+
+
+def test_gather_stats_uneven_shards_three_ranks_gloo(pkg):
+    """8 filters over 3 ranks (3 + 3 + 2): the short block is NaN-padded for the equal-size all-gather and the padding is
+    dropped again; rows come back in global filter order."""
+    import torch.multiprocessing as mp
+
+    world, total = 3, 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    assert out.shape == (total, 2) and np.isfinite(out).all()
     assert np.array_equal(out[:, 0], np.arange(total)) and np.array_equal(out[:, 1], 100.0 + np.arange(total))
 
 
