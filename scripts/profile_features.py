@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """k_features on 4096 simulated scans (64 distinct sweeps, repeated), three calls: the command rocprofv3 wraps for
-profiles/r02_features_kernel_stats.csv.  Prints the library's own hipEvent time per call beside it."""
+profiles/r0x_features_kernel_stats.csv.  Prints the library's own hipEvent time per call beside it."""
 import os
 import sys
 
@@ -14,5 +14,5 @@ fx = pkg.FeatureExtractor(len(scans), max_points=181, max_corners=16)
 for r in range(3):
     corners, n = fx.extract(scans)
     ms = fx.kernel_ms()
-    print("call %d: %d scans, %d corners, %.3f ms on the device = %.0f scans/s" % (r, len(scans), int(sum(n)), ms, len(scans) / ms * 1e3), flush=True)
+    print("call %d: %d scans, %d corners, %.3f ms on the device = %.0f scans/s, tail share %.3f" % (r, len(scans), int(sum(n)), ms, len(scans) / ms * 1e3, fx.tail_share()), flush=True)
 fx.close()

@@ -11,7 +11,7 @@ dst = "profiles"
 os.makedirs(dst, exist_ok=True)
 ks = glob.glob(os.path.join(src, "trace/*/*_kernel_stats.csv"))[0]
 shutil.copy(ks, os.path.join(dst, tag + "_kernel_stats.csv"))
-summary = {"command": "rocprofv3 --kernel-trace --stats | --pmc FETCH_SIZE | --pmc WRITE_SIZE | --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE  -- python3 bench.py %s   (scripts/profile_r02.sh; EKF_OVERLAP=%s)" % (args, os.environ.get("EKF_OVERLAP", "unset")),
+summary = {"command": "rocprofv3 --kernel-trace --stats | --pmc FETCH_SIZE | --pmc WRITE_SIZE | --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE  -- python3 bench.py %s   (scripts/profile_r0x.sh; EKF_OVERLAP=%s)" % (args, os.environ.get("EKF_OVERLAP", "unset")),
            "kernels": {}, "bench_lines": {}}
 for row in csv.DictReader(open(ks)):
     summary["kernels"][row["Name"].split("(")[0]] = {"calls": int(row["Calls"]), "avg_us": float(row["AverageNs"]) / 1e3, "pct": float(row["Percentage"])}
