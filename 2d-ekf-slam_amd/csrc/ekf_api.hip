@@ -1240,6 +1240,13 @@ extern "C" int ekf_sync(ekf_handle h) {
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(stream_wait(h->s_chain));
     if (h->overlap) HIP_TRY(stream_wait(h->s_flush));
+    // The mirror's status is written by the LAST segment of a chain launch; a wait that ran out elsewhere (the arrival wait of a
+    // launch without an exchange) reaches it only with the next launch.  A full synchronise reads the device's own words as well.
+    h->h_int.resize(h->dv.B);
+    HIP_TRY(hipMemcpy(h->h_int.data(), h->dv.status, sizeof(int) * h->dv.B, hipMemcpyDeviceToHost));
+    for (int b = 0; b < h->dv.B; b++)
+        if (h->h_int[b] == EKF_ERR_TIMEOUT) h->mirror_h[b].status = EKF_ERR_TIMEOUT;
+    for (int b = 0; b < h->dv.B; b++) h->h_int[b] = h->mirror_h[b].n_lm;
     return sticky_status(h, true);
 }
 

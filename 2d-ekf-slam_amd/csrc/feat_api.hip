@@ -149,7 +149,8 @@ extern "C" int feat_get_intermediates(feat_handle h, int scan, unsigned char *gr
     if (n_lines) *n_lines = nl;
     if (n_segs) *n_segs = ns;
     if (lines && nl > 0) FEAT_TRY(hipMemcpy(lines, h->dv.lines + s * FEAT_NUM_PEAKS * 3, (size_t)nl * 3 * sizeof(double), hipMemcpyDeviceToHost));
-    if (segs && ns > 0) FEAT_TRY(hipMemcpy(segs, h->dv.segs + s * FEAT_MAX_SEGS * 7, (size_t)ns * 7 * sizeof(double), hipMemcpyDeviceToHost));
+    const int ns_stored = ns < FEAT_MAX_SEGS ? ns : FEAT_MAX_SEGS;
+    if (segs && ns_stored > 0) FEAT_TRY(hipMemcpy(segs, h->dv.segs + s * FEAT_MAX_SEGS * 7, (size_t)ns_stored * 7 * sizeof(double), hipMemcpyDeviceToHost));
     return EKF_OK;
 }
 

@@ -416,7 +416,7 @@ __global__ __launch_bounds__(256) void k_features(FeatDev dv) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (dv.n_lines) {  // (before the corners reuse the float tables)
-            if (lane == 0) dv.n_lines[s] = nl, dv.n_segs[s] = ns;
+            if (lane == 0) dv.n_lines[s] = nl, dv.n_segs[s] = ns_all;  // (the count FOUND: more than EKF_FEAT_MAX_SEGS means the list was cut, as for corners)
             for (int i = lane; i < nl * 3; i += 64) dv.lines[(size_t)s * FEAT_NUM_PEAKS * 3 + i] = (&L.lines[0][0])[i];
             for (int i = lane; i < ns * 7; i += 64) dv.segs[(size_t)s * FEAT_MAX_SEGS * 7 + i] = (&L.segs[0][0])[i];
         }

@@ -76,7 +76,8 @@ class FeatureExtractor:
         nl, ns, dropped = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
         ekfslam._chk(self.L.feat_get_intermediates(self.h, scan, grid.ctypes.data_as(_up), peaks.ctypes.data_as(_ip), ctypes.byref(nl),
                                                    lines.ctypes.data_as(_dp), ctypes.byref(ns), segs.ctypes.data_as(_dp), ctypes.byref(dropped)))
-        return dict(grid=grid, peaks=peaks, lines=lines[:nl.value].copy(), segs=segs[:ns.value].copy(), dropped=dropped.value)
+        return dict(grid=grid, peaks=peaks, lines=lines[:nl.value].copy(), segs=segs[:min(ns.value, MAX_SEGS)].copy(), dropped=dropped.value,
+                    segs_found=ns.value)  # (segs_found > MAX_SEGS: the list was cut)
 
     def kernel_ms(self):
         ms = ctypes.c_double(0)

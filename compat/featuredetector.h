@@ -31,6 +31,7 @@ typedef struct Feature {  // featuredetector.h:16-19
 class FeatureDetector {
 public:
     double NO_COMPASS = 100.0;  // featuredetector.h:25
+    int Corners_Dropped = 0;    // (addition) corners of the last scan beyond this class's capacity of 64, 0 in any sane scan
 
     // the reference's public tuning constants, featuredetector.h:27-36 (values only: the kernels carry their own copies,
     // 2d-ekf-slam_amd/csrc/feat_device.h; slam.cpp reads none of them)
@@ -73,6 +74,7 @@ public:
         corners.resize(2 * kMaxCorners);
         check(feat_extract(fh, 1, &n, rng.data(), lx.data(), ly.data(), &nc, corners.data()));  // :37-56
         const int numf = nc < kMaxCorners ? nc : kMaxCorners;
+        Corners_Dropped = nc - numf;  // (the reference's vector is unbounded; more than kMaxCorners corners in one scan are cut, and said so here)
         for (int i = 0; i < numf; i++) {  // :275-280
             Feature f;
             f.x = corners[2 * i], f.y = corners[2 * i + 1];

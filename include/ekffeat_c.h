@@ -42,7 +42,9 @@ int feat_extract(feat_handle h, int n_scans, const int *n_points, const double *
 
 /* Intermediate results of scan `scan` of the last feat_extract (any pointer may be NULL):
  * grid [180][1601] votes (HoughTransform::houghGrid), peaks [200] cell indices (getPeaks' array, position for position),
- * lines [n][3] = radius, theta, weight (houghLine), segs [n][7] = radius, theta, startX, startY, endX, endY, numPoints.
+ * lines [n][3] = radius, theta, weight (houghLine), segs [n][7] = radius, theta, startX, startY, endX, endY, numPoints;
+ * *n_segs = segments FOUND (the reference's vector is unbounded): more than EKF_FEAT_MAX_SEGS means only that many were
+ * stored and paired into corners -- the same convention as n_corners_out / max_corners of feat_extract.
  * dropped_votes = votes whose radius bin fell outside its theta row (the reference writes outside the row there). */
 int feat_get_intermediates(feat_handle h, int scan, unsigned char *grid, int *peaks, int *n_lines, double *lines, int *n_segs, double *segs,
                            int *dropped_votes);

@@ -1235,7 +1235,7 @@ def test_stats_means_on_the_device_equal_the_host_summary(pkg):
     f.sync()
     # (device memory from the HIP runtime the library itself uses: importing torch after it would bring a second runtime)
     import ctypes
-    hip = ctypes.CDLL("libamdhip64.so")
+    hip = ctypes.CDLL("/opt/rocm/lib/libamdhip64.so")  # (by path: torch, if some earlier test imported it, carries a runtime of its own under the same name)
     ptr = ctypes.c_void_p()
     assert hip.hipMalloc(ctypes.byref(ptr), ctypes.c_size_t(B * 2 * 8)) == 0
     f.stats_means_into(ptr.value)
