@@ -1248,3 +1248,34 @@ def test_stats_means_on_the_device_equal_the_host_summary(pkg):
     with pytest.raises(pkg.ekfslam.EkfError):
         f.stats_means_into(np.zeros((B, 2)).ctypes.data)  # host memory is refused
     f.close()
+
+
+def test_phase_groups_give_the_same_results(pkg, monkeypatch):
+    """EKF_SOLO_GROUPS (an experiment, default off): a batch of one-workgroup filters cut into phase groups, each with a stream
+    of its own carrying chain launch, dense pass, chain launch, ... for its filters only.  Filters are independent, so every
+    filter's decisions and state must be what the ungrouped run gives, bit for bit; state reads, flushes and immediate-mode
+    calls between two grouped runs see one stream as before (fork from and join into the handle's stream)."""
+    B, N, M, steps = 40, 60, 4, 36
+    outs = []
+    for groups in ("1", "2", "3"):
+        monkeypatch.setenv("EKF_SOLO_GROUPS", groups)
+        monkeypatch.setenv("EKF_OVERLAP", "0")
+        f = pkg.FilterBatch(B, N, max_pending=8, log_capacity=steps * M + 8)
+        scripts = []
+        for b in range(B):
+            x0, P0 = pkg.scenarios.injected_state(N, seed=900 + b, extent=9.0)
+            f.set_state(x0, P0, index=b)
+            scripts.append(pkg.scenarios.steady_script(x0, steps=steps, M=M, seed=950 + b, min_separation=0.8))
+        f.script_load(np.stack([s["ctrl"] for s in scripts], axis=1), np.stack([s["z"] for s in scripts], axis=2), np.stack([s["R"] for s in scripts], axis=2))
+        f.script_run(0, 20)                       # 80 measurements: ten windows -> the grouped path
+        mid = f.get_state(7)
+        f.propagate(np.full(B, 0.2), np.full(B, 0.05), np.full(B, 0.1))   # an immediate-mode call in between
+        f.script_run(20, steps - 20)
+        f.sync()
+        outs.append((mid, [f.get_state(b) for b in (0, 13, 27, B - 1)], [f.decisions(b, steps * M) for b in (0, 27)], f.stats()))
+        f.close()
+    for o in outs[1:]:
+        assert o[3] == outs[0][3] and o[2] == outs[0][2]
+        assert np.array_equal(o[0][0], outs[0][0][0]) and np.array_equal(o[0][1], outs[0][0][1])
+        for (xa, Pa), (xb, Pb) in zip(o[1], outs[0][1]):
+            assert np.array_equal(xa, xb) and np.array_equal(Pa, Pb)
