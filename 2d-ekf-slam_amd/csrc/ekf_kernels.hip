@@ -1414,7 +1414,11 @@ finish:  // (also the way out when a bounded wait ran out: the sticky status say
 #define TILE_ST(p, v) (*(double2_t *)(p) = (v))
 #endif
 
-template <int NP>
+// DIAG: a diagonal tile (I == J).  Only its 16x16 chains on or above the diagonal (column block >= row block) hold entries anybody
+// reads -- an entry of P_LL is addressed as (row of the older landmark, column of the younger), the 2x2 blocks on the diagonal live
+// in D -- so the six chains below are dead storage: not loaded, not multiplied, not stored (8 % of the tile traffic of a map of
+// 256 landmarks, whose 36 tiles include 8 diagonal ones; 0.6 % at N = 4096).
+template <int NP, bool DIAG>
 __device__ __forceinline__ void flush_tile_rb(const double *tp, double *tq, const double *FA, const double *FB, unsigned lo, unsigned live, int zero_slot, size_t slot_stride) {
         // the common case (windows up to 16): three row-blocks of the tile in flight, the fourth is requested
         // into the registers of the first once that has been stored
@@ -1439,6 +1443,7 @@ __device__ __forceinline__ void flush_tile_rb(const double *tp, double *tq, cons
         for (int r = 0; r < 3; r++)
 #pragma unroll
             for (int cc = 0; cc < 4; cc++) {
+                if (DIAG && cc < r) continue;
                 const int ch = r * 4 + cc;
                 double2_t l2 = TILE_LD(tp + ch * 256);
                 double2_t h2 = TILE_LD(tp + ch * 256 + 128);
@@ -1451,7 +1456,10 @@ __device__ __forceinline__ void flush_tile_rb(const double *tp, double *tq, cons
 #pragma unroll
             for (int p = 0; p < NP; p++)
 #pragma unroll
-                for (int cc = 0; cc < 4; cc++) blk[k][cc] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[rc & 1][p], bq[p][cc], blk[k][cc], 0, 0, 0);
+                for (int cc = 0; cc < 4; cc++) {
+                    if (DIAG && cc < rc) continue;
+                    blk[k][cc] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[rc & 1][p], bq[p][cc], blk[k][cc], 0, 0, 0);
+                }
             __builtin_amdgcn_sched_barrier(0);
             if (rc + 2 < 4) {
 #pragma unroll
@@ -1459,6 +1467,7 @@ __device__ __forceinline__ void flush_tile_rb(const double *tp, double *tq, cons
             }
 #pragma unroll
             for (int cc = 0; cc < 4; cc++) {
+                if (DIAG && cc < rc) continue;
                 const int ch = rc * 4 + cc;
                 TILE_ST(tq + ch * 256, ((double2_t){blk[k][cc].x, blk[k][cc].y}));
                 TILE_ST(tq + ch * 256 + 128, ((double2_t){blk[k][cc].z, blk[k][cc].w}));
@@ -1466,6 +1475,7 @@ __device__ __forceinline__ void flush_tile_rb(const double *tp, double *tq, cons
             if (rc == 0) {
 #pragma unroll
                 for (int cc = 0; cc < 4; cc++) {
+                    if (DIAG && cc < 3) continue;
                     const int ch = 12 + cc;
                     double2_t l2 = TILE_LD(tp + ch * 256);
                     double2_t h2 = TILE_LD(tp + ch * 256 + 128);
@@ -1540,9 +1550,15 @@ __global__ __launch_bounds__(256, 2) void k_flush_rb(EkfDev dv, int nT_hi, int s
     const int npl = __builtin_popcount(live);
 
     if (npl <= 8) {  // windows up to 16
-        if (npl <= 2) flush_tile_rb<2>(tp, tq, FA, FB, lo, live, zero_slot, slot_stride);
-        else if (npl <= 4) flush_tile_rb<4>(tp, tq, FA, FB, lo, live, zero_slot, slot_stride);
-        else flush_tile_rb<8>(tp, tq, FA, FB, lo, live, zero_slot, slot_stride);
+        if (uni(I) == uni(J)) {  // (a diagonal tile: its chains below the diagonal are dead storage)
+            if (npl <= 2) flush_tile_rb<2, true>(tp, tq, FA, FB, lo, live, zero_slot, slot_stride);
+            else if (npl <= 4) flush_tile_rb<4, true>(tp, tq, FA, FB, lo, live, zero_slot, slot_stride);
+            else flush_tile_rb<8, true>(tp, tq, FA, FB, lo, live, zero_slot, slot_stride);
+            return;
+        }
+        if (npl <= 2) flush_tile_rb<2, false>(tp, tq, FA, FB, lo, live, zero_slot, slot_stride);
+        else if (npl <= 4) flush_tile_rb<4, false>(tp, tq, FA, FB, lo, live, zero_slot, slot_stride);
+        else flush_tile_rb<8, false>(tp, tq, FA, FB, lo, live, zero_slot, slot_stride);
         return;
     }
     // windows above 16: slot-major walk (whole tile loaded, all pairs, then stored), two pairs per iteration

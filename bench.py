@@ -136,11 +136,14 @@ def roofline_record(pkg, f, workload, B, N, K, M, window, launches, flush_ms, al
     windows = -(-K * M // window)
     groups = max(1, round(launches / windows)) if launches else 1  # (phase groups of a batch launch one pass per group and window)
     filters_per_launch = max(1, B // groups)
-    bytes_per_launch = filters_per_launch * tiles * 4096 * 8 * 2
+    # (a tile is 16 chains of 16 x 16; the six chains below the diagonal of a DIAGONAL tile are dead storage nobody reads, and the pass
+    # neither loads, multiplies nor stores them: they are not algorithmic bytes)
+    chains = tiles * 16 - nT * 6
+    bytes_per_launch = filters_per_launch * chains * 256 * 8 * 2
     slots_per_launch = min(window, K * M)
-    flops_per_launch = filters_per_launch * tiles * ((slots_per_launch + 1) // 2) * 16 * 2048  # 16 v_mfma_f64_16x16x4_f64 per tile and PAIR of measurements
+    flops_per_launch = filters_per_launch * chains * ((slots_per_launch + 1) // 2) * 2048  # one v_mfma_f64_16x16x4_f64 per chain and PAIR of measurements
     r = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
-         "kernel": "k_flush_rb", "byte_model": "scheme C (one triangle authoritative): tiles * 32 KiB read + written per pass, %d measurements folded per pass" % slots_per_launch,
+         "kernel": "k_flush_rb", "byte_model": "scheme C (one triangle authoritative): every live 16x16 chain of the upper-triangle tiles (2 KiB) read + written per pass -- %d tiles = %d chains, the %d dead chains below the diagonals of the diagonal tiles left out; %d measurements folded per pass" % (tiles, chains, nT * 6, slots_per_launch),
          "bytes_per_launch": bytes_per_launch, "launches": int(launches), "avg_launch_us": None, "measurements_per_launch": slots_per_launch,
          "mfma": {"achieved": None, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None, "flops_per_launch": flops_per_launch}}
     if launches:
