@@ -43,18 +43,19 @@ def summarise(stats):
     return out
 
 
-def gather_stats(local, device=None, total_filters=None):
+def gather_stats(local, device=None, total_filters=None, force_collective=False):
     """All-gather per-filter summaries [n_local, 2] into [total, 2], ordered by global filter index.
 
     `local` is a NumPy array (host) or a torch tensor -- a tensor already on the collective's device goes into the all-gather
     as it is (gather_device_stats: no host bounce).  Ranks of an uneven partition (shard_range with total % world != 0) hold
     different numbers of rows: pass `total_filters`; every rank then pads its block with NaN rows to the largest block, the
-    equal-size all-gather runs, and the padding is dropped again.  Without an initialised process group: the identity."""
+    equal-size all-gather runs, and the padding is dropped again.  Without an initialised process group: the identity; a group of
+    one rank skips the collective too unless `force_collective` asks for it (the one-GPU test of the RCCL leg)."""
     import torch
     import torch.distributed as dist
 
     is_tensor = isinstance(local, torch.Tensor)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force_collective):
         return local.detach().cpu().numpy().copy() if is_tensor else np.ascontiguousarray(local, dtype=np.float64).copy()
     world, rank = dist.get_world_size(), dist.get_rank()
     t = local if is_tensor else torch.from_numpy(np.ascontiguousarray(local, dtype=np.float64))
@@ -78,20 +79,20 @@ def gather_stats(local, device=None, total_filters=None):
     return res
 
 
-def gather_device_stats(f, device, total_filters=None):
+def gather_device_stats(f, device, total_filters=None, force_collective=False):
     """The one collective of a multi-GPU run, straight from the device: the library writes every filter's (mean NIS, mean NEES)
     into a tensor on `device` (ekf_stats_means_device), which is the all-gather's send buffer.  On a CPU device (gloo
     rehearsals) the summary goes through the host mirror as before."""
     import torch
     import torch.distributed as dist
 
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force_collective):
         return summarise(f.stats_array())  # one rank: nothing to gather, the counters come from the host-mapped mirror (no copy, no launch)
     if torch.device(device).type == "cuda":
         t = torch.empty((f.batch, 2), dtype=torch.float64, device=device)
         f.stats_means_into(t.data_ptr())
-        return gather_stats(t, device=device, total_filters=total_filters)
-    return gather_stats(summarise(f.stats_array()), device=device, total_filters=total_filters)
+        return gather_stats(t, device=device, total_filters=total_filters, force_collective=force_collective)
+    return gather_stats(summarise(f.stats_array()), device=device, total_filters=total_filters, force_collective=force_collective)
 
 
 def consistency_report(summary, nis_samples_per_filter, nees_samples_per_filter, alpha=0.05):

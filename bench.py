@@ -109,11 +109,13 @@ def timed_steps(f, mc, torch, dist, coll_device, W, K, graph):
     return elapsed, dev_ms, gathered
 
 
-def config5_legs(pkg, mc, torch, dist, coll_device, rank, world, dev_id, M, max_pending):
+def config5_legs(pkg, mc, torch, dist, coll_device, rank, world, dev_id, M, max_pending, steps=None):
     """BASELINE.json config 5: independent filters at N = 256 sharded over the ranks, RCCL all-gather of NIS / NEES inside
     the timed region.  Weak: 256 filters per GPU.  Strong: 2048 filters in all (more than 256 per GPU go out as several
     chain launches per window)."""
     _, per_gpu, K, W, _, _, _ = WORKLOADS["batch256"]
+    if steps is not None:
+        K = steps
     out = {"world_size": world, "N": 256, "M": M, "steps": K, "warmup": W}
     for leg, total in (("weak", per_gpu * world), ("strong", 2048)):
         lo, hi = mc.shard_range(total, rank, world)
@@ -164,15 +166,57 @@ def roofline_record(pkg, f, workload, B, N, K, M, window, launches, flush_ms, al
                       "launches": int(alone_launches), "note": "same pass, nothing else on the GPU, outside the timed region"}
     # PMC-derived HBM bytes per launch: NOT measured by this run -- replayed from the committed rocprofv3 --pmc passes of this very
     # command (scripts/profile_r0x.sh -> profiles/traffic_*.json); null when no committed pass matches the configuration
+    have = kernel_source_digest()
     for tname in ("traffic_%s.json" % workload, "traffic_%s_inplace.json" % workload):
         tfile = os.path.join(ROOT, "profiles", tname)
         if os.path.exists(tfile):
             tj = json.load(open(tfile))
             if tj.get("max_pending") == window and tj.get("overlap", int(f.overlap)) == int(f.overlap) and tj.get("filters_per_gpu", B) == B:
+                if tj.get("kernel_source_sha16") != have:
+                    # a counter pass of OTHER kernel sources says nothing about this binary: null, not a stale number
+                    r["traffic_source"] = "profiles/%s was collected on kernel sources %s, this run's are %s: stale, not replayed" % (tname, tj.get("kernel_source_sha16"), have)
+                    continue
                 r["traffic"] = tj.get("hbm_bytes_per_launch")
-                r["traffic_source"] = "replayed from profiles/%s (separate rocprofv3 --pmc passes), not measured in this run" % tname
+                r["traffic_source"] = "replayed from profiles/%s (separate rocprofv3 --pmc passes of these kernel sources, %s), not measured in this run" % (tname, have)
                 break
     return r
+
+
+def kernel_source_digest():
+    """sha256 (first 16 hex digits) over the device sources of the library: profiles/traffic_*.json carry the digest of the sources
+    their counter passes ran on (scripts/summarize_profile.py), and a replayed number must come from the same ones."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "2d-ekf-slam_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")) or name == "Makefile":
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def host_cpu_record():
+    """CPU model, frequency governor and the pinning the CPU legs ran under."""
+    rec = {"host_cpus": os.cpu_count(), "model": None, "governor": None, "affinity_cpus": None, "pinning": None}
+    try:
+        for l in open("/proc/cpuinfo"):
+            if l.startswith("model name"):
+                rec["model"] = l.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    try:
+        rec["governor"] = open("/sys/devices/system/cpu/cpu0/cpufreq/scaling_governor").read().strip()
+    except OSError:
+        rec["governor"] = "not exposed"
+    try:
+        aff = sorted(os.sched_getaffinity(0))
+        rec["affinity_cpus"] = len(aff)
+    except (AttributeError, OSError):
+        aff = None
+    rec["pinning"] = {"OMP_PROC_BIND": os.environ.get("OMP_PROC_BIND"), "OMP_PLACES": os.environ.get("OMP_PLACES"), "OMP_NUM_THREADS": os.environ.get("OMP_NUM_THREADS"),
+                      "taskset": "none (the process's affinity mask as inherited: %s CPUs)" % (len(aff) if aff else "?")}
+    return rec
 
 
 def measure(pkg, mc, torch, dist, coll_device, rank, world, dev_id, workload, K, W, M, max_pending, graph, flush_profile, check=True, alone=True, latency=False):
@@ -181,7 +225,7 @@ def measure(pkg, mc, torch, dist, coll_device, rank, world, dev_id, workload, K,
     N, B, _, _, seed, extent, min_sep = WORKLOADS[workload]
     lo, hi = mc.shard_range(B * world, rank, world)
     # (4 windows of untimed tail: dense passes measured one at a time, nothing beside them; latency: one step per call)
-    extra = 64 if latency else 0
+    extra = 264 if latency else 0
     f, scripts = make_filters(pkg, mc, workload, lo, hi, W + K + extra, M, dev_id, max_pending, (K + W + extra) * M, tail_windows=4 if alone else 0)
     window = f.window  # the library may shorten the window to fit its on-chip buffer
     win_steps = -(-window // M)
@@ -207,9 +251,13 @@ def measure(pkg, mc, torch, dist, coll_device, rank, world, dev_id, workload, K,
             f.script_run(s_, 1)
             f.poses()
             ts.append((time.perf_counter() - t0) * 1e6)
-        ts = np.sort(np.array(ts[8:]))
+        raw = np.array(ts)
+        ts = np.sort(raw[8:])
         lat = {"unit": "us per step (1 Propagate + %d Updates, one call per step, pose read back)" % M, "samples": int(ts.size),
-               "p10": float(np.percentile(ts, 10)), "p50": float(np.percentile(ts, 50)), "p90": float(np.percentile(ts, 90)), "max": float(ts[-1])}
+               "p10": float(np.percentile(ts, 10)), "p50": float(np.percentile(ts, 50)), "p90": float(np.percentile(ts, 90)),
+               "p99": float(np.percentile(ts, 99)), "max": float(ts[-1]), "over_1ms": int((ts > 1000.0).sum()),
+               "first_8_calls_us": [float(t) for t in raw[:8]],
+               "note": "the first 8 calls (first per-step launches after the scripted run: host-side first-use costs) are listed, not ranked"}
         f.flush()
         f.sync()
         f.flush_profile_read()
@@ -291,6 +339,91 @@ def config1_leg(pkg, dev_id):
                              "note": "sha256 over x and P rounded to 9 significant digits"}}
 
 
+def secondary_in_a_child(args, dev_id):
+    """The secondary records (configs 1, 2, 4, M = 1, 512 steps) are measured by a CHILD process after the headline and the CPU
+    baselines are in hand: a GPU fault, a hang or a blown time budget in one of them then costs that record, never the line."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--secondary-only", "--device", str(dev_id), "--M", str(args.M), "--max-pending", str(args.max_pending)]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    try:
+        p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=args.secondary_budget)
+    except subprocess.TimeoutExpired:
+        return {"error": "the secondary legs exceeded their %.0f s budget and were stopped" % args.secondary_budget}
+    for l in reversed(p.stdout.splitlines()):
+        if l.startswith('{"secondary"'):
+            return json.loads(l)["secondary"]
+    return {"error": "the secondary legs ended with rc %d: %s" % (p.returncode, p.stderr[-400:])}
+
+
+def dry_run(args, rank, world, ekf_env):
+    """--dry-run: what a multi-rank run does AROUND the GPU work -- rendezvous, shard_range of both config-5 legs, the equal-size
+    all-gather with NaN padding, the max-over-ranks reduction, one line from rank 0 -- on synthetic rows tagged by global filter
+    index.  No device, no library: `value` is null and the line says "dry_run"."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    mc = ge.load_package().montecarlo
+    if args.dist_backend == "nccl":
+        raise SystemExit("--dry-run is a CPU rehearsal: use --dist-backend gloo")
+    if world > 1:
+        dist.init_process_group(args.dist_backend)
+    per_gpu = WORKLOADS["batch256"][1]
+    c5 = {"world_size": world}
+    for leg, total in (("weak", per_gpu * world), ("strong", 2048)):
+        lo, hi = mc.shard_range(total, rank, world)
+        local = np.stack([np.arange(lo, hi, dtype=np.float64), 1e6 + np.arange(lo, hi)], axis=1)
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        out = mc.gather_stats(local, total_filters=total)
+        el = time.perf_counter() - t0
+        if world > 1:
+            te = torch.tensor([el], dtype=torch.float64)
+            dist.all_reduce(te, op=dist.ReduceOp.MAX)
+            el = float(te.item())
+        ok = out.shape == (total, 2) and np.array_equal(out[:, 0], np.arange(total)) and np.array_equal(out[:, 1], 1e6 + np.arange(total))
+        if not ok:
+            raise SystemExit("rank %d: the gathered rows of the %s leg are not in global filter order" % (rank, leg))
+        c5[leg] = {"filters_total": total, "filters_per_gpu": hi - lo, "value": None, "gathered_rows": int(out.shape[0]), "gather_ms": el * 1e3}
+    if rank == 0:
+        print(json.dumps({"metric": "EKF steps/sec (propagate+full update) at N landmarks", "value": None, "unit": "steps/s", "n_gpus": world,
+                          "steps": 0, "warmup": 0, "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "dtype": "f64", "data": "synthetic", "dry_run": True, "config": {"workload": "dry run: no GPU work"},
+                          "config5": c5, "ekf_environment": ekf_env}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher around it: start the N ranks as children through torch.distributed.run (the very
+    command the driver uses), let rank 0's single JSON line through on stdout, return non-zero if any rank failed."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (dmabuf IPC: RCCL between processes needs it on this driver)
+    env.setdefault("OMP_NUM_THREADS", "16")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
+    for l in p.stdout.splitlines():
+        if l not in lines:
+            print(l, file=sys.stderr)
+    if p.returncode != 0:
+        print("bench.py: the %d-rank launch failed (rc %d)" % (n, p.returncode), file=sys.stderr)
+        return p.returncode or 1
+    if len(lines) != 1:
+        print("bench.py: expected one JSON line from rank 0, got %d" % len(lines), file=sys.stderr)
+        return 1
+    print(lines[0])
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -306,6 +439,10 @@ def main():
     ap.add_argument("--device", type=int, default=None, help="force a device id (rehearsal only; default LOCAL_RANK)")
     ap.add_argument("--no-flush-profile", action="store_true", help="do not bracket the dense pass with hipEvents")
     ap.add_argument("--no-config5", action="store_true", help="with --gpus N > 1: skip the config-5 legs (256 filters/GPU weak, 2048 filters strong)")
+    ap.add_argument("--config5-steps", type=int, default=None, help="timed steps of the config-5 legs (default: the batch256 workload's 200)")
+    ap.add_argument("--secondary-only", action="store_true", help="(internal) run only the secondary records and print them: bench.py starts itself this way as a child, so that a fault or a hang in a secondary leg cannot cost the headline")
+    ap.add_argument("--secondary-budget", type=float, default=420.0, help="wall-clock limit in seconds of the child that measures the secondary records")
+    ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous / shard / all-gather plumbing only, no GPU work: every rank gathers synthetic per-filter rows of its config-5 shards (CPU rehearsal, gloo)")
     args = ap.parse_args()
     ekf_env = ekf_environment()
 
@@ -313,9 +450,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
+        if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
+            # plain `python bench.py --gpus N`: this process becomes the launcher.  Nothing here has touched the GPU yet (no torch.cuda,
+            # no HIP library), and the ranks are CHILD processes -- never an exec of a process that holds the device
+            raise SystemExit(self_launch(args.gpus))
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+
+    if args.dry_run:
+        return dry_run(args, rank, world, ekf_env)
 
     import numpy as np
     import torch  # imported before the HIP library so that one HIP runtime (torch's) serves both
@@ -341,16 +483,16 @@ def main():
     coll_device = torch.device("cuda", dev_id) if args.dist_backend == "nccl" else torch.device("cpu")
 
     # ---- the headline: inputs built on the host and moved to HBM (untimed), warm-up (untimed), exactly K timed steps -------
-    head = measure(pkg, mc, torch, dist, coll_device, rank, world, dev_id, args.workload, K, W, M, args.max_pending, bool(args.graph), not args.no_flush_profile)
+    head = None if args.secondary_only else measure(pkg, mc, torch, dist, coll_device, rank, world, dev_id, args.workload, K, W, M, args.max_pending, bool(args.graph), not args.no_flush_profile)
 
     config5 = None
     if world > 1 and not args.no_config5:
-        config5 = config5_legs(pkg, mc, torch, dist, coll_device, rank, world, dev_id, M, args.max_pending)
+        config5 = config5_legs(pkg, mc, torch, dist, coll_device, rank, world, dev_id, M, args.max_pending, args.config5_steps)
 
     # ---- secondary records on the same line (one GPU only): the other BASELINE.json configurations a single GPU holds, each with
     # its own roofline, so that the driver's one command puts a number behind every one of them
     secondary = None
-    if world == 1 and not args.no_secondary and args.workload == "n4096":
+    if args.secondary_only:
         secondary = {}
         def leg(name, fn):
             try:
@@ -369,6 +511,8 @@ def main():
         leg("config3_M1", lambda: summarise(measure(pkg, mc, torch, None, coll_device, 0, 1, dev_id, "n4096", 512, 32, 1, args.max_pending, False, True, alone=False)))
         leg("config3_512_steps", lambda: summarise(measure(pkg, mc, torch, None, coll_device, 0, 1, dev_id, "n4096", 512, 32, M, args.max_pending, False, True, alone=False)))
         leg("config1_n50", lambda: config1_leg(pkg, dev_id))
+        print(json.dumps({"secondary": secondary}))
+        return
 
     if rank != 0:
         if dist is not None:
@@ -379,6 +523,9 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(pkg, N, M, seed, extent, min_sep)
         cpu_strong = cpu_baseline_structured(pkg, N, M, seed, extent, min_sep)
+
+    if world == 1 and not args.no_secondary and args.workload == "n4096":
+        secondary = secondary_in_a_child(args, dev_id)
 
     rep = head["report"]
     # the steady workload feeds 0.5-sigma measurement noise and a noise-free truth (margins
@@ -442,7 +589,7 @@ def cpu_baseline(pkg, N, M, seed, extent, min_sep):
     return {"value": sample_steps / t, "unit": "steps/s", "cores": 1, "kind": "port",
             "sample": "%d step(s) of the same workload (1 Propagate + %d Old Updates each) at N=%d, faithful-dense oracle, %.1f s" % (sample_steps, M, N, t),
             "seconds_per_step": {"median": float(np.median(ps)), "p10": float(np.percentile(ps, 10)), "p90": float(np.percentile(ps, 90))},
-            "host_cpus": os.cpu_count()}
+            "host_cpus": os.cpu_count(), "host": host_cpu_record(), "compiler_flags": "gcc -O3 -march=x86-64-v3 -ffp-contract=off (oracle/Makefile; the reference's Makefile:2 has no -O at all)"}
 
 
 def cpu_baseline_structured(pkg, N, M, seed, extent, min_sep):

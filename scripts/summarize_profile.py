@@ -45,7 +45,9 @@ if "FETCH_SIZE_mean_per_dispatch" in fl and "WRITE_SIZE_mean_per_dispatch" in fl
     summary["traffic"] = {"fetch_size_kb": f_kb, "write_size_kb": w_kb, "tile_read_bytes": tile_read, "operand_read_bytes": operand,
                           "hbm_bytes_per_launch": tile_read + operand + w_kb * 1024.0, "algorithmic_bytes_per_launch": line["roofline"]["bytes_per_launch"]}
     wl = cfg["workload"].split(":")[0]
-    tj = {"workload": wl, "max_pending": cfg["max_pending"], "overlap": cfg["overlap"], "filters_per_gpu": cfg["filters_per_gpu"],
+    sys.path.insert(0, os.getcwd())
+    import bench
+    tj = {"kernel_source_sha16": bench.kernel_source_digest(), "workload": wl, "max_pending": cfg["max_pending"], "overlap": cfg["overlap"], "filters_per_gpu": cfg["filters_per_gpu"],
           "hbm_bytes_per_launch": summary["traffic"]["hbm_bytes_per_launch"], "tile_read_bytes": tile_read, "operand_read_bytes": operand,
           "write_bytes": w_kb * 1024.0, "algorithmic_bytes_per_launch": line["roofline"]["bytes_per_launch"],
           "source": "profiles/%s_summary.json: WRITE_SIZE exact; FETCH_SIZE halves the 16 B/lane tile stream (MI355X_MICROARCH.md; calibrated on the 1-measurement window in round 1)" % tag}

@@ -1,0 +1,143 @@
+"""`python bench.py --gpus N` must start by itself (the driver calls it that way for N = 1 and through torch.distributed.run for
+N > 1; both forms have to work), and the one collective of a multi-GPU run -- the all-gather of per-filter (mean NIS, mean NEES),
+SURVEY.md 8e -- must have run through RCCL at least once before an 8-GPU node sees it: a one-rank nccl group on the one GPU of
+the box drives gather_device_stats through all_gather_into_tensor."""
+import json
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run_bench(argv, timeout):
+    env = dict(os.environ)
+    for k in [k for k in env if k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT") or k.startswith("EKF")]:
+        env.pop(k)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=timeout)
+    return p
+
+
+def _one_line(p):
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, (p.stdout, p.stderr[-2000:])
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_launches_its_own_ranks_dry_run(world):
+    """No torchrun around it, no GPU: the parent spawns the ranks as children, rank 0's single line comes through, config 5's
+    shards (weak: 256 per rank; strong: 2048 in all, uneven at 3 ranks) are gathered in global filter order."""
+    p = _run_bench(["--gpus", str(world), "--dist-backend", "gloo", "--dry-run"], 600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = _one_line(p)
+    assert line["dry_run"] is True and line["value"] is None and line["n_gpus"] == world
+    c5 = line["config5"]
+    assert c5["world_size"] == world
+    assert c5["weak"]["filters_total"] == 256 * world and c5["weak"]["gathered_rows"] == 256 * world and c5["weak"]["filters_per_gpu"] == 256
+    assert c5["strong"]["filters_total"] == 2048 and c5["strong"]["gathered_rows"] == 2048
+
+
+def test_bench_launcher_reports_a_failed_rank():
+    """A rank that dies (here: every rank refuses nccl in a dry run) makes the launcher return non-zero and print no result line."""
+    p = _run_bench(["--gpus", "2", "--dist-backend", "nccl", "--dry-run"], 600)
+    assert p.returncode != 0
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--dist-backend", "gloo"], cwd=ROOT, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode != 0 and "does not match WORLD_SIZE" in p.stderr
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_share_the_one_gpu(pipeline_mode):
+    """The real thing minus the second GPU: `python bench.py --gpus 2` (self-launched), both ranks on device 0, gloo for the
+    collective -- headline, config-5 weak and strong legs, one line."""
+    if pipeline_mode != "inplace":
+        pytest.skip("once is enough: the launcher does not depend on the pipeline mode")
+    p = _run_bench(["--gpus", "2", "--dist-backend", "gloo", "--device", "0", "--workload", "n1024", "--steps", "16", "--warmup", "4",
+                    "--config5-steps", "16"], 900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = _one_line(p)
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["scaling"] == "weak"
+    c5 = line["config5"]
+    assert c5["world_size"] == 2
+    for leg, total in (("weak", 512), ("strong", 2048)):
+        assert c5[leg]["filters_total"] == total and c5[leg]["gathered_rows"] == total and c5[leg]["value"] > 0
+
+
+_NCCL_CHILD = textwrap.dedent("""
+    import json, os, sys
+    sys.path.insert(0, %r)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(%d), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    pkg = ge.load_package()
+    mc = pkg.montecarlo
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    B, N, steps, M = 12, 256, 24, 4
+    f = pkg.FilterBatch(B, N, device=0)
+    scripts = []
+    for b in range(B):
+        x0, P0 = pkg.scenarios.injected_state(N, seed=20260004 + b, extent=12.5)
+        f.set_state(x0, P0, index=b)
+        scripts.append(pkg.scenarios.steady_script(x0, steps=steps, M=M, seed=20268000 + b, min_separation=1.0))
+    f.script_load(np.stack([s["ctrl"] for s in scripts], axis=1), np.stack([s["z"] for s in scripts], axis=2),
+                  np.stack([s["R"] for s in scripts], axis=2), truth=np.stack([s["truth"] for s in scripts], axis=1))
+    f.script_run(0, steps)
+    f.flush()
+    f.sync()
+    host = mc.summarise(f.stats_array())
+    short = mc.gather_device_stats(f, dev)                                  # world 1: the short cut through the host mirror
+    rccl = mc.gather_device_stats(f, dev, force_collective=True)            # ekf_stats_means_device -> all_gather_into_tensor (RCCL)
+    rccl_padded = mc.gather_device_stats(f, dev, total_filters=B, force_collective=True)
+    # and an all-reduce on the same communicator, as bench.py's max-over-ranks does
+    te = torch.tensor([1.25], dtype=torch.float64, device=dev)
+    dist.all_reduce(te, op=dist.ReduceOp.MAX)
+    dist.barrier()
+    f.close()
+    dist.destroy_process_group()
+    print("RESULT " + json.dumps({"host": host.tolist(), "short": short.tolist(), "rccl": rccl.tolist(), "padded": rccl_padded.tolist(),
+                                  "allreduce": float(te.item()), "backend": "nccl"}))
+""")
+
+
+@pytest.mark.gpu
+def test_rccl_all_gather_of_device_written_stats_one_rank(pipeline_mode):
+    """A fresh child initialises a ONE-rank nccl (= RCCL) group on the box's GPU and sends the device-written summary buffer
+    (ekf_stats_means_device) through all_gather_into_tensor; the result must equal the summary of the host mirror's counters."""
+    import socket
+
+    import numpy as np
+    if pipeline_mode != "inplace":
+        pytest.skip("once is enough: the collective does not depend on the pipeline mode")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = {k: v for k, v in os.environ.items() if not k.startswith("EKF")}
+    p = subprocess.run([sys.executable, "-c", _NCCL_CHILD % (ROOT, port)], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    res = [l for l in p.stdout.splitlines() if l.startswith("RESULT ")]
+    assert len(res) == 1, p.stdout
+    r = json.loads(res[0][7:])
+    host, rccl = np.array(r["host"]), np.array(r["rccl"])
+    assert host.shape == (12, 2) and np.isfinite(host).all() and (host > 0).all()
+    assert np.array_equal(np.array(r["short"]), host)
+    # (the device divides sum by count in fp64 exactly as summarise does)
+    assert np.array_equal(rccl, host), np.abs(rccl - host).max()
+    assert np.array_equal(np.array(r["padded"]), host)
+    assert r["allreduce"] == 1.25
