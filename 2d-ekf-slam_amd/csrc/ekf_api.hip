@@ -338,10 +338,12 @@ static int create_impl(ekf_batch *h, int batch, int capacity_landmarks, int devi
         if (g_max < 1) g_max = 1;
         long lpw_min = ((capacity_landmarks + g_max - 1) / g_max + 63) / 64 * 64;  // (the LDS cache is laid out in chunks of 64 landmarks)
         want_overlap = (lpw_min * maxp * 2 * 32 <= lds_budget) ? 1 : 0;
-        // ... and when a dense pass is long enough to be worth hiding (P_LL of the whole batch >= 128 MB, a pass of
-        // about 45 us): below that the chain kernels dominate and the second window's bookkeeping only costs
+        // ... and when there is a dense pass worth hiding.  Round 4 (scripts/r04_geometry.py): with several windows per chain launch
+        // the overlapped pipeline also saves the launch boundaries between chain kernel and pass, and wins from P_LL = 10 MB on
+        // (N = 768: 39.2 k against 35.3 k steps/s in place; N = 1024: 38.5 k against 35.3 k; N = 2048: 37.8 k against 32.3 k; N = 512,
+        // 4 MB: 37.6 k against 36.9 k -- a draw; the threshold is 8 MB).  The threshold was 128 MB in rounds 1-3, measured on one-window launches.
         size_t T = (2 * (size_t)capacity_landmarks + 63) / 64;
-        if ((size_t)batch * (T * (T + 1) / 2) * 4096 * sizeof(double) < ((size_t)128 << 20)) want_overlap = 0;
+        if ((size_t)batch * (T * (T + 1) / 2) * 4096 * sizeof(double) < ((size_t)8 << 20)) want_overlap = 0;
     }
     h->overlap = want_overlap != 0;
     h->params.overlap = h->overlap ? 1 : 0;
@@ -349,6 +351,16 @@ static int create_impl(ekf_batch *h, int batch, int capacity_landmarks, int devi
     int G = (capacity_landmarks + max_workers - 1) / max_workers;
     int G_lds = (int)((((long)capacity_landmarks + 63) / 64 * 64 * maxp * sets_in_lds * 32 + lds_budget - 1) / lds_budget);
     if (G_lds > G) G = G_lds;
+    // Round 4: about 64 landmarks -- ONE worker wave -- per workgroup is the fastest shape wherever the GPU has the CUs for it, up to
+    // 32 workgroups per filter (fewer waves to keep in step at every barrier; N = 512: 8 workgroups 36.9 k against 3 workgroups
+    // 34.4 k steps/s, N = 1024: 16 against 6: 35.3 k against 32.5 k in place, N = 2048: 32 against 16: 37.8 k against 36.3 k
+    // overlapped; at N = 4096 the rule gives the 32 workgroups of 128 landmarks the LDS budget asked for already, and 64
+    // workgroups of 64 were slower there: 29.7 k against 31.6 k, the dense pass loses too many CUs)
+    {
+        int G_pref = (capacity_landmarks + 63) / 64;
+        if (G_pref > 32) G_pref = 32;
+        if (G_pref > G) G = G_pref;
+    }
     if (G > EKF_CHAIN_MAX_WGS) G = EKF_CHAIN_MAX_WGS;
     if (G * batch > 256) G = 256 / batch;  // (batches of more than 256 filters: one workgroup per filter, several launches)
     if (G < 1) G = 1;
@@ -617,11 +629,16 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 // Low-latency waits: a blocking hipStreamSynchronize / hipEventSynchronize costs 20-50 us of wake-up latency, which is a
 // sizeable part of a run of a few hundred microseconds.  The host polls the stream / event for up to two milliseconds
 // (about a microsecond per query) and only then blocks.
-static hipError_t stream_wait(hipStream_t s) {
+// ... and a blocking wait in the runtime is never entered at all: once in a few dozen waits of several milliseconds the wake-up
+// came 4-10 ms late on the gpurun boxes (scripts/r04_stall_hunt.py: hipEventSynchronize returned 10-16 ms after the start of a
+// 6.9 ms region; the driver's box showed 54 ms once), which is what a robot loop must not see.  So: spin on the query for 2 ms
+// (short waits: no system call), then keep querying with 20 us naps (one core mostly asleep, wake-up bounded by the nap).
+template <typename Query>
+static hipError_t poll_wait(Query query) {
     timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);
     for (long spin = 0;; spin++) {
-        hipError_t e = hipStreamQuery(s);
+        hipError_t e = query();
         if (e != hipErrorNotReady) return e;
         if ((spin & 63) == 63) {
             clock_gettime(CLOCK_MONOTONIC, &t1);
@@ -629,22 +646,19 @@ static hipError_t stream_wait(hipStream_t s) {
         }
         __builtin_ia32_pause();
     }
-    return hipStreamSynchronize(s);
+    const timespec nap = {0, 20000};
+    for (;;) {
+        hipError_t e = query();
+        if (e != hipErrorNotReady) return e;
+        nanosleep(&nap, nullptr);
+    }
+}
+static hipError_t stream_wait(hipStream_t s) {
+    return poll_wait([s]() { return hipStreamQuery(s); });
 }
 
 static hipError_t event_wait(hipEvent_t ev) {
-    timespec t0, t1;
-    clock_gettime(CLOCK_MONOTONIC, &t0);
-    for (long spin = 0;; spin++) {
-        hipError_t e = hipEventQuery(ev);
-        if (e != hipErrorNotReady) return e;
-        if ((spin & 63) == 63) {
-            clock_gettime(CLOCK_MONOTONIC, &t1);
-            if ((t1.tv_sec - t0.tv_sec) * 1000000000L + (t1.tv_nsec - t0.tv_nsec) > 2000000L) break;
-        }
-        __builtin_ia32_pause();
-    }
-    return hipEventSynchronize(ev);
+    return poll_wait([ev]() { return hipEventQuery(ev); });
 }
 
 static int check_launch() {
@@ -826,9 +840,9 @@ static int close_set(ekf_batch *h, bool terminal = false, EnqueueList *defer = n
 static int settle(ekf_batch *h) {
     int rc = close_set(h, true);
     if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(h->s_chain));
+    HIP_TRY(stream_wait(h->s_chain));
     if (h->overlap) {
-        HIP_TRY(hipStreamSynchronize(h->s_flush));
+        HIP_TRY(stream_wait(h->s_flush));
         if (h->prev_pending > 0) {
             h->buf_in ^= 1;  // the last pass's output
             h->prev_pending = 0;
@@ -1042,7 +1056,7 @@ static int ring_reserve(ekf_batch *h, int count, double **rec, int *k_out) {
         h->ring_ev_valid[which] = true;
         which ^= 1;
         pos = which * half;
-        if (h->ring_ev_valid[which]) HIP_TRY(hipEventSynchronize(h->ring_ev[which]));  // its readers from one lap ago
+        if (h->ring_ev_valid[which]) HIP_TRY(event_wait(h->ring_ev[which]));  // its readers from one lap ago
     }
     *rec = h->ring_h + (size_t)pos * h->dv.B * 8;
     *k_out = pos;
@@ -1078,7 +1092,7 @@ static int refresh_bounds(ekf_batch *h, bool full = true) {
             __builtin_ia32_pause();
         }
     }
-    if (!done) HIP_TRY(hipStreamSynchronize(h->s_chain));
+    if (!done) HIP_TRY(stream_wait(h->s_chain));
     int mx = 0;
     for (int b = 0; b < h->dv.B; b++) {
         h->h_int[b] = h->mirror_h[b].n_lm;
@@ -1240,12 +1254,9 @@ extern "C" int ekf_sync(ekf_handle h) {
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(stream_wait(h->s_chain));
     if (h->overlap) HIP_TRY(stream_wait(h->s_flush));
-    // The mirror's status is written by the LAST segment of a chain launch; a wait that ran out elsewhere (the arrival wait of a
-    // launch without an exchange) reaches it only with the next launch.  A full synchronise reads the device's own words as well.
+    // Every bounded wait that runs out stores EKF_ERR_TIMEOUT into the host-mapped mirror itself, at once (and nothing but
+    // k_set_meta ever writes a zero there): the mirror is complete when the streams are idle -- no device-to-host copy here.
     h->h_int.resize(h->dv.B);
-    HIP_TRY(hipMemcpy(h->h_int.data(), h->dv.status, sizeof(int) * h->dv.B, hipMemcpyDeviceToHost));
-    for (int b = 0; b < h->dv.B; b++)
-        if (h->h_int[b] == EKF_ERR_TIMEOUT) h->mirror_h[b].status = EKF_ERR_TIMEOUT;
     for (int b = 0; b < h->dv.B; b++) h->h_int[b] = h->mirror_h[b].n_lm;
     return sticky_status(h, true);
 }
@@ -1298,7 +1309,7 @@ extern "C" int ekf_get_robot_cov(ekf_handle h, double P_RR_out[9]) {
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipMemcpy2DAsync(P_RR_out, 3 * sizeof(double), h->dv.R, (size_t)h->dv.xs * sizeof(double), 3 * sizeof(double), 3,
                              hipMemcpyDeviceToHost, h->s_chain));
-    HIP_TRY(hipStreamSynchronize(h->s_chain));
+    HIP_TRY(stream_wait(h->s_chain));
     return EKF_OK;
 }
 
@@ -1341,7 +1352,7 @@ extern "C" int ekf_get_decisions(ekf_handle h, int index, ekf_decision *out, int
     HIP_TRY(hipSetDevice(h->device));
     long long cnt;
     HIP_TRY(hipMemcpyAsync(&cnt, h->dv.log_count + index, sizeof cnt, hipMemcpyDeviceToHost, h->s_chain));
-    HIP_TRY(hipStreamSynchronize(h->s_chain));
+    HIP_TRY(stream_wait(h->s_chain));
     long long avail = cnt < h->dv.logcap ? cnt : h->dv.logcap;
     long long n = count < avail ? count : avail;
     std::vector<ekf_decision> ring(h->dv.logcap);
@@ -1406,7 +1417,7 @@ extern "C" int ekf_get_state(ekf_handle h, int index, double *x_out, double *P_o
     if (e == hipSuccess)
         e = hipMemcpy2DAsync(P_out, (size_t)ld * sizeof(double), stage, (size_t)n * sizeof(double), (size_t)n * sizeof(double), n,
                              hipMemcpyDeviceToHost, h->s_chain);
-    if (e == hipSuccess) e = hipStreamSynchronize(h->s_chain);
+    if (e == hipSuccess) e = stream_wait(h->s_chain);
     hipFree(stage);
     if (e != hipSuccess) return set_error(EKF_ERR_HIP, hipGetErrorString(e));
     return n;
@@ -1449,7 +1460,7 @@ extern "C" int ekf_set_state(ekf_handle h, int index, const double *x, const dou
         hipLaunchKernelGGL(k_import, dim3(cdiv(n, 256), n), dim3(256), 0, s, dv, index, h->buf_in, (const double *)xd, (const double *)stage, n, n);
         hipLaunchKernelGGL(k_set_meta, dim3(1), dim3(64), 0, s, dv, index, N);
         h->mirror_by_chain = false;
-        e = hipStreamSynchronize(s);
+        e = stream_wait(s);
     }
     hipFree(stage);
     if (e != hipSuccess) return set_error(EKF_ERR_HIP, hipGetErrorString(e));
@@ -1479,7 +1490,7 @@ extern "C" int ekf_broadcast_state(ekf_handle h) {
         HIP_TRY(hipMemcpyAsync(dv.status + b, dv.status, sizeof(int), hipMemcpyDeviceToDevice, s));
         HIP_TRY(hipMemcpyAsync(dv.log_count + b, dv.log_count, sizeof(long long), hipMemcpyDeviceToDevice, s));
     }
-    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(stream_wait(s));
     for (int b = 1; b < dv.B; b++) hipLaunchKernelGGL(k_set_meta, dim3(1), dim3(64), 0, s, dv, b, h->mirror_h[0].n_lm);  // also refreshes the host mirror
     h->mirror_by_chain = false;
     return refresh_bounds(h);
@@ -1492,7 +1503,7 @@ extern "C" int ekf_script_load(ekf_handle h, int steps, int M, const double *ctr
                                const unsigned char *valid, const double *truth) {
     if (!h || steps < 1 || M < 0 || !ctrl || (M > 0 && (!z || !R))) return set_error(EKF_ERR_BAD_ARG, "bad argument");
     HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(hipStreamSynchronize(h->s_chain));
+    HIP_TRY(stream_wait(h->s_chain));
     for (auto &g : h->graphs) hipGraphExecDestroy(g.exec);
     h->graphs.clear();
     if (h->script_d) {
@@ -1603,7 +1614,7 @@ extern "C" int ekf_script_run(ekf_handle h, int first_step, int n_steps, int use
             }
             int start_op = s * ops;
             HIP_TRY(hipMemcpyAsync(h->cursor_d, &start_op, sizeof(int), hipMemcpyHostToDevice, h->s_chain));
-            HIP_TRY(hipStreamSynchronize(h->s_chain));  // start_op is a stack variable
+            HIP_TRY(stream_wait(h->s_chain));  // start_op is a stack variable
             while (end - s >= S) {
                 HIP_TRY(hipGraphLaunch(ge->exec, h->s_chain));
                 s += S;
@@ -1627,7 +1638,7 @@ extern "C" int ekf_script_run(ekf_handle h, int first_step, int n_steps, int use
 extern "C" int ekf_debug_stamps(ekf_handle h, long long *out16, int reset) {
     if (!h || !out16) return EKF_ERR_BAD_ARG;
     HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(hipStreamSynchronize(h->s_chain));
+    HIP_TRY(stream_wait(h->s_chain));
     HIP_TRY(hipMemcpy(out16, h->dv.dbg, 32 * sizeof(long long), hipMemcpyDeviceToHost));
     if (reset) HIP_TRY(hipMemset(h->dv.dbg, 0, 32 * sizeof(long long)));
     return EKF_OK;
@@ -1662,8 +1673,8 @@ extern "C" int ekf_flush_profile(ekf_handle h, int enable) {
 extern "C" int ekf_flush_profile_read(ekf_handle h, long long *launches_out, double *total_ms_out) {
     if (!h) return set_error(EKF_ERR_BAD_ARG, "null handle");
     HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(hipStreamSynchronize(h->s_chain));
-    if (h->overlap) HIP_TRY(hipStreamSynchronize(h->s_flush));
+    HIP_TRY(stream_wait(h->s_chain));
+    if (h->overlap) HIP_TRY(stream_wait(h->s_flush));
     for (size_t i = 0; i + 1 < h->prof_used; i += 2) {
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, h->prof_pool[i], h->prof_pool[i + 1]));

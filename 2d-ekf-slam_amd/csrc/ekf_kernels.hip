@@ -479,11 +479,6 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
         p[0][0] = raw[0], p[1][1] = raw[3];
         p[0][1] = below ? raw[1] : raw[2], p[1][0] = below ? raw[2] : raw[1];
     };
-    auto load_old_inputs = [=](int lm, int lo, double p[2][2]) {
-        double raw[4];
-        request_old_inputs(lm, lo, raw);
-        orient_old_inputs(lm, lo, raw, p);
-    };
     // One landmark's two rows of a measurement's rank-2 slot: A rows (a00 a01 / a10 a11), B rows likewise.
     // Slots are stored in pairs (one k=4 MFMA operand): an even slot writes whole 32-byte rows and
     // zeroes its partner's half, an odd slot fills that half.
@@ -620,7 +615,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
         while ((int)(__hip_atomic_load(dv.pass_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - need_pass) < 0) {
             __builtin_amdgcn_s_sleep(8);
             if (++spins > dv.spin_limit) {  // bounded (2^24 polls, seconds): the launch then applies nothing more (the pass's output is not there)
-                dv.status[b] = EKF_ERR_TIMEOUT;
+                dv.status[b] = EKF_ERR_TIMEOUT, dv.mirror[b].status = EKF_ERR_TIMEOUT;  // (the mirror as well, at once: ekf_sync reads nothing else)
                 L.abort = 1;
                 break;
             }
@@ -951,7 +946,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                         }
                         if (__all(ok)) break;
                         if (++spins > (1L << 22)) {  // bounded: a workgroup that is not running must not hang the GPU
-                            if (lane == 0) dv.status[b] = EKF_ERR_TIMEOUT, L.abort = 1;
+                            if (lane == 0) dv.status[b] = EKF_ERR_TIMEOUT, dv.mirror[b].status = EKF_ERR_TIMEOUT, L.abort = 1;
                             break;
                         }
                         __builtin_amdgcn_s_sleep(1);
@@ -1009,6 +1004,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                 }
             }
 
+            STAMP(3);  // gate and bookkeeping
             if (hdr == HDR_OLD) {
                 ahead_prop = uni((int)L.ap_tab[op]);
                 // ---- Old, Update.cpp:181-189.  Workers: request the matched landmark's slot rows (into LDS) and their
@@ -1028,7 +1024,11 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                     const bool slot_thread = tid < nvs;
                     double c4[4] = {0, 0, 0, 0};
                     if (G > 1) {
-                        const bool cur_thread = slot_thread && tid >= n_prev, w_thread = (tid >= 64 && tid < 80);  // (virtual slots: at most 2 * 32 threads)
+                      if (!worker) {
+                        // the winner data too is read by the control wave (lanes 0..15: one value each, two more granules): a worker wave has its
+                        // P_LL entries in flight, loads return in order, and the sixteen worker threads that used to read the winner data
+                        // therefore waited for their HBM loads first -- and the whole workgroup with them at the barrier below
+                        const bool cur_thread = slot_thread && tid >= n_prev, w_thread = tid < 16;  // (virtual slots: at most 2 * 32 threads)
                         if (slot_thread && !cur_thread && L.sm[tid].type != SLOT_DEAD) {
                             const size_t off_p = (size_t)(set ^ 1) * dv.f_stride;
                             const double *F = (L.sm[tid].type == SLOT_NEW ? FAb : FBb) + CK(off_p + pair_offset(rows_, 2 * w_lo, tid >> 1), lim_F - 7) + (tid & 1) * 2;
@@ -1036,28 +1036,33 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                         }
                         const unsigned long long *wrec = (const unsigned long long *)(part + ((size_t)((epoch - 1) & 1) * dv.gmax + src) * EKF_REC_DOUBLES);
                         const unsigned long long tag = (unsigned long long)(unsigned)(ebase + epoch) << 32;
-                        const unsigned long long *gp = cur_thread ? wrec + 2 * (16 + (tid - n_prev) * 4) : wrec + 2 * (tid - 64);
-                        const int ng = cur_thread ? 8 : (w_thread ? 2 : 0);
-                        unsigned long long g[8];
+                        const unsigned long long *gp = wrec + 2 * (16 + (cur_thread ? tid - n_prev : 0) * 4), *gw = wrec + 2 * (tid & 15);
+                        const int ng = cur_thread ? 8 : 0, nwg = w_thread ? 2 : 0;
+                        unsigned long long g[10];
                         long spins = 0;
                         for (;;) {
                             unsigned long long bad = 0;
 #pragma unroll
-                            for (int i = 0; i < 8; i++) {
+                            for (int i = 0; i < 10; i++) {
                                 g[i] = tag;
-                                if (i < ng) g[i] = __hip_atomic_load(gp + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                if (i < 8 ? i < ng : i - 8 < nwg) g[i] = __hip_atomic_load(i < 8 ? gp + i : gw + (i - 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                 bad |= g[i] ^ tag;
                             }
                             if ((bad >> 32) == 0) break;
                             if (++spins > (1L << 22)) {  // bounded
-                                dv.status[b] = EKF_ERR_TIMEOUT;
+                                dv.status[b] = EKF_ERR_TIMEOUT, dv.mirror[b].status = EKF_ERR_TIMEOUT;
                                 L.abort = 1;
                                 break;
                             }
                         }
+#ifdef EKF_CHAIN_STAMPS
+                        asm volatile("" ::"v"(g[0]), "v"(g[9]));
+                        STAMP(12);  // the control wave's read of the winner's record
+#endif
                         if (cur_thread)
                             for (int j = 0; j < 4; j++) c4[j] = __longlong_as_double((long long)((g[2 * j + 1] << 32) | (g[2 * j] & 0xffffffffull)));
-                        if (w_thread) L.w[tid - 64] = __longlong_as_double((long long)((g[1] << 32) | (g[0] & 0xffffffffull)));
+                        if (w_thread) L.w[tid] = __longlong_as_double((long long)((g[9] << 32) | (g[8] & 0xffffffffull)));
+                      }
                     } else {
                         if (w_lo == best.lm)
                             for (int i = 0; i < 16; i++) L.w[i] = best.w[i];
@@ -1103,17 +1108,10 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                         if (lm == w_lo) {
                             p[0][0] = st.dxx, p[0][1] = st.dxy, p[1][0] = st.dxy, p[1][1] = st.dyy;
                         } else {
-                            if (prefetched) {
-                                orient_old_inputs(lm, w_lo, pf_raw, p);
-                            } else {
-                                load_old_inputs(lm, w_lo, p);
-                            }
-#ifdef EKF_CHAIN_STAMPS
-                            if (prefetched) {
-                                asm volatile("" ::"v"(p[0][0]), "v"(p[0][1]), "v"(p[1][0]), "v"(p[1][1]));  // (forces the wait for the loads)
-                                STAMP(8);
-                            }
-#endif
+                            // the entries of Bm (requested before the stage barrier for the register-resident landmark) are used LAST: the
+                            // fold of the unflushed slots needs LDS only and runs while they are still on their way
+                            double raw[4];
+                            if (!prefetched) request_old_inputs(lm, w_lo, raw);
                             // the unflushed slots are not in Bm yet: P[lm rows, lo cols] += (own cached rows) * M_slot
                             double pe[2][2] = {{0, 0}, {0, 0}};
                             if (n_own > 0) {  // (wave-uniform)
@@ -1132,6 +1130,20 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                                     pe[0][0] += c[0], pe[0][1] += c[2], pe[1][0] += c[1], pe[1][1] += c[3];
                                 }
                             }
+#ifdef EKF_CHAIN_STAMPS
+                            if (prefetched) {
+                                asm volatile("" ::"v"(pe[0][0]), "v"(pe[0][1]), "v"(pe[1][0]), "v"(pe[1][1]));
+                                STAMP(9);  // the fold
+                            }
+#endif
+                            if (prefetched) orient_old_inputs(lm, w_lo, pf_raw, p);
+                            else orient_old_inputs(lm, w_lo, raw, p);
+#ifdef EKF_CHAIN_STAMPS
+                            if (prefetched) {
+                                asm volatile("" ::"v"(p[0][0]), "v"(p[0][1]), "v"(p[1][0]), "v"(p[1][1]));  // (forces the wait for the loads)
+                                STAMP(8);  // what is left of the wait for the P_LL entries behind the fold
+                            }
+#endif
                             for (int a = 0; a < 2; a++)
                                 for (int e = 0; e < 2; e++) p[a][e] += pe[a][e];
                             if (helper_on) {  // the helper wave's share (it has had the same time for the same number of slots)
@@ -1140,12 +1152,6 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                                 const int ll = lm - own_lo;
                                 p[0][0] += L.hp[ll], p[0][1] += L.hp[128 + ll], p[1][0] += L.hp[256 + ll], p[1][1] += L.hp[384 + ll];
                             }
-#ifdef EKF_CHAIN_STAMPS
-                            if (prefetched) {
-                                asm volatile("" ::"v"(p[0][0]), "v"(p[0][1]), "v"(p[1][0]), "v"(p[1][1]));
-                                STAMP(9);
-                            }
-#endif
                         }
                         apply_old(lm, st, p, slot, h, RS.Prr, L.w);
                     };
@@ -1319,7 +1325,8 @@ finish:  // (also the way out when a bounded wait ran out: the sticky status say
 
 #ifdef EKF_CHAIN_STAMPS
     if ((tid == 0 || tid == 64) && g == 0 && b == 0)
-        for (int i = 0; i < (tid == 0 ? 8 : 13); i++) dv.dbg[(tid == 0 ? 0 : 16) + i] += stamp_acc[i], stamp_acc[i] = 0;
+        for (int i = 0; i < 13; i++)
+            if (tid != 0 || i < 8 || i == 12) dv.dbg[(tid == 0 ? 0 : 16) + i] += stamp_acc[i], stamp_acc[i] = 0;  // (the control lane's [12] lands in dbg[12])
 #endif
     if (tid == 0) {
         if (lead) {
@@ -1330,7 +1337,7 @@ finish:  // (also the way out when a bounded wait ran out: the sticky status say
                 while ((int)(__hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (arrive_base + G)) < 0) {
                     __builtin_amdgcn_s_sleep(2);
                     if (++spins > (1L << 22)) {  // bounded: a workgroup that never starts must not hang the GPU
-                        dv.status[b] = EKF_ERR_TIMEOUT;
+                        dv.status[b] = EKF_ERR_TIMEOUT, dv.mirror[b].status = EKF_ERR_TIMEOUT;
                         break;
                     }
                 }
@@ -1352,7 +1359,8 @@ finish:  // (also the way out when a bounded wait ran out: the sticky status say
                 dv.stats[b] = L.st;
                 mr->stats = L.st;
                 dv.log_count[b] = L.log_count;
-                mr->status = dv.status[b];
+                if (dv.status[b] != 0) mr->status = dv.status[b];  // (never a zero: a workgroup whose bounded wait ran out has written the mirror itself, and its
+                                                                    //  store to dv.status need not be visible here; k_set_meta clears both)
                 mr->log_count = L.log_count;
                 // everything above is in host memory before the sequence number is: a host thread spinning on seq reads a complete mirror
                 __atomic_thread_fence(__ATOMIC_RELEASE);

@@ -667,7 +667,7 @@ __global__ __launch_bounds__(256) void k_solo(EkfDev dv, const double *in, const
                 dv.stats[b] = L.st;
                 mr->stats = L.st;
                 dv.log_count[b] = L.log_count;
-                mr->status = dv.status[b];
+                if (dv.status[b] != 0) mr->status = dv.status[b];  // (k_set_meta clears both)
                 mr->log_count = L.log_count;
                 // everything above is in host memory before the sequence number is: a host thread spinning on seq reads a complete mirror
                 __atomic_thread_fence(__ATOMIC_RELEASE);

@@ -1,0 +1,63 @@
+"""Round 4: where do the sporadic 20-50 ms stalls come from (a 54 ms per-step latency maximum on the driver's box)?
+Fresh child processes; in each, scripted runs of ~7 ms timed call by call on the host, the device time of the same region from
+hipEvents beside it.  Prints every iteration whose host time exceeds its device time by more than 1 ms."""
+import json, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CHILD = r'''
+import os, sys, time, json
+sys.path.insert(0, %r)
+import numpy as np
+import __graft_entry__ as ge
+pkg = ge.load_package()
+N, steps, warm, M, reps = int(sys.argv[1]), int(sys.argv[2]), 8, 4, int(sys.argv[3])
+extent = 50.0 * (N / 4096.0) ** 0.5
+f = pkg.FilterBatch(1, N)
+x0, P0 = pkg.scenarios.injected_state(N, seed=3, extent=extent)
+sc = pkg.scenarios.steady_script(x0, steps=warm + steps * reps, M=M, seed=4)
+f.set_state(x0, P0)
+f.script_load(sc["ctrl"][:, None, :], sc["z"][:, :, None, :], sc["R"][:, :, None, :])
+f.script_run(0, warm); f.flush(); f.sync()
+out = []
+for r in range(reps):
+    t0 = time.perf_counter()
+    f.timer_start()
+    t1 = time.perf_counter()
+    f.script_run(warm + r * steps, steps)
+    t2 = time.perf_counter()
+    f.flush()
+    t3 = time.perf_counter()
+    dev = f.timer_stop()   # waits for the stream
+    t4 = time.perf_counter()
+    f.sync()
+    t5 = time.perf_counter()
+    out.append([(t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3, (t5 - t4) * 1e3, dev])
+print(json.dumps(out))
+''' % ROOT
+def main():
+    N, steps, reps, procs = (int(a) for a in (sys.argv[1:5] + [None] * 4)[:4]) if len(sys.argv) >= 5 else (896, 256, 12, 10)
+    worst = 0.0
+    n = slow = 0
+    devs = []
+    for p_ in range(procs):
+        env = dict(os.environ)
+        p = subprocess.run([sys.executable, "-c", CHILD, str(N), str(steps), str(reps)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+        try:
+            rows = json.loads(p.stdout.strip().splitlines()[-1])
+        except Exception as e:
+            print("process", p_, "failed", e, p.stderr[-300:]); continue
+        for r, (a, b, c, d, e, dev) in enumerate(rows):
+            host = a + b + c + d + e
+            n += 1
+            devs.append((dev, p_, r))
+            worst = max(worst, host - dev)
+            if host - dev > 1.0:
+                slow += 1
+                print("process %d rep %d: host %.2f ms vs device %.2f ms: timer_start %.2f, script_run %.2f, flush %.2f, timer_stop(wait) %.2f, sync %.2f" % (p_, r, host, dev, a, b, c, d, e), flush=True)
+    devs.sort()
+    med = devs[len(devs) // 2][0]
+    for dev, p_, r in devs:
+        if dev > 1.3 * med:
+            print("process %d rep %d: DEVICE time %.2f ms against a median of %.2f ms" % (p_, r, dev, med), flush=True)
+    print("device time per region: min %.2f median %.2f max %.2f ms" % (devs[0][0], med, devs[-1][0]))
+    print("N=%d: %d timed regions of %d steps in %d processes, %d with host - device > 1 ms, worst excess %.2f ms" % (N, n, steps, procs, slow, worst), flush=True)
+main()
