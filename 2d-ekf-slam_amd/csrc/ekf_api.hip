@@ -11,6 +11,7 @@
 #include <time.h>
 
 #include <string>
+#include <atomic>
 #include <mutex>
 #include <functional>
 #include <vector>
@@ -122,6 +123,7 @@ struct ekf_batch {
     long long prof_launches;
     double prof_ms;
     EkfMirror *mirror_h;  // host view of dv.mirror
+    ekf_params params_requested;
     // scratch
     std::vector<int> h_int;
 };
@@ -290,6 +292,7 @@ extern "C" int ekf_batch_create(ekf_handle *out, int batch, int capacity_landmar
 static int create_impl(ekf_batch *h, int batch, int capacity_landmarks, int device_id, const ekf_params *params, const hipDeviceProp_t &prop) {
     ekf_default_params(&h->params);
     if (params) h->params = *params;
+    h->params_requested = h->params;  // (ekf_reserve builds the larger handle from what the caller asked for, not from what this capacity allowed)
     if (h->params.max_pending < 1) h->params.max_pending = 1;
     if (h->params.max_pending > EKF_MAX_PENDING) h->params.max_pending = EKF_MAX_PENDING;
     if (h->params.log_capacity < 16) h->params.log_capacity = 16;
@@ -566,11 +569,26 @@ extern "C" int ekf_create(ekf_handle *out, int capacity_landmarks, int device_id
     return ekf_batch_create(out, 1, capacity_landmarks, device_id, params);
 }
 
+// Bounds-checking variant (make check: -DEKF_CHAIN_CHECK, libekfslam_hip_check.so): every data-dependent global index of k_chain
+// is range-checked on the device and the first violation of a handle is left in dv.dbg[8..11]; a handle that is destroyed with one
+// reports it on stderr and counts it here (tests/test_safety_builds.py runs part of the suite against that library and wants 0).
+static std::atomic<long> g_check_violations{0};
+extern "C" long ekf_debug_check_violations(void) { return g_check_violations.load(); }
+
 extern "C" int ekf_destroy(ekf_handle h) {
     if (!h) return EKF_OK;
     hipSetDevice(h->device);
     TRACE("destroy: sync");
     if (h->s_chain) hipStreamSynchronize(h->s_chain);
+#ifdef EKF_CHAIN_CHECK
+    if (h->dv.dbg) {
+        long long d[12] = {0};
+        if (hipMemcpy(d, h->dv.dbg, sizeof d, hipMemcpyDeviceToHost) == hipSuccess && d[8] != 0) {
+            g_check_violations++;
+            fprintf(stderr, "EKF_CHAIN_CHECK: index %lld outside [0, %lld) at ekf_kernels.hip:%lld (workgroup * 100000 + thread = %lld)\n", d[9], d[10], d[8], d[11]);
+        }
+    }
+#endif
     if (h->s_flush && h->s_flush != h->s_chain) {
         hipStreamSynchronize(h->s_flush);
         pool_give(h->device, h->flush_keep, h->s_flush);
@@ -1465,6 +1483,92 @@ extern "C" int ekf_set_state(ekf_handle h, int index, const double *x, const dou
     hipFree(stage);
     if (e != hipSuccess) return set_error(EKF_ERR_HIP, hipGetErrorString(e));
     if (N > h->n_lm_hi) h->n_lm_hi = N;
+    return refresh_bounds(h);
+}
+
+// Grow a handle's landmark capacity (the reference grows x and P with every New landmark, Update.cpp:158-177 /
+// kalmanfilter.cpp:78-84, and never fails).  A second set of device buffers of the larger capacity is built, every filter's state
+// moves over on the device (k_export into a dense staging matrix, k_import from it: the tile numbering depends on the capacity),
+// the counters, the decision log and a loaded script move with it, and the handle keeps its address.
+extern "C" int ekf_reserve(ekf_handle h, int capacity_landmarks) {
+    if (!h || capacity_landmarks < 1 || capacity_landmarks > 16000) return set_error(EKF_ERR_BAD_ARG, "bad handle / capacity");
+    if (capacity_landmarks <= h->dv.Ncap) return EKF_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    int rc = settle(h);  // every deferred slot folded, both streams idle
+    if (rc) return rc;
+    rc = refresh_bounds(h);  // h_int[b] = landmarks of filter b; a sticky EKF_ERR_TIMEOUT (invalid state) ends it here
+    if (rc == EKF_ERR_TIMEOUT) return rc;
+    const int B = h->dv.B;
+    std::vector<int> n_lm(h->h_int.begin(), h->h_int.begin() + B);
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, h->device));
+    // the old buffers are idle from here on and will not launch again: their CUs are free for the new handle's residency check
+    const int had_claimed = h->claimed_cus;
+    {
+        std::lock_guard<std::mutex> lk(g_res_mu);
+        g_cus_claimed[h->device] -= had_claimed;
+        h->claimed_cus = 0;
+    }
+    ekf_batch *nh = new ekf_batch();
+    nh->device = h->device;
+    rc = create_impl(nh, B, capacity_landmarks, h->device, &h->params_requested, prop);
+    if (rc != EKF_OK) {
+        std::string keep = g_last_error;
+        ekf_destroy(nh);
+        (void)hipGetLastError();
+        g_last_error = keep;
+        std::lock_guard<std::mutex> lk(g_res_mu);
+        g_cus_claimed[h->device] += had_claimed;
+        h->claimed_cus = had_claimed;
+        return rc;
+    }
+    hipError_t e = hipSuccess;
+    int n_max = 3;
+    for (int b = 0; b < B; b++) n_max = 3 + 2 * n_lm[b] > n_max ? 3 + 2 * n_lm[b] : n_max;
+    double *stage = nullptr;
+    e = hipMalloc((void **)&stage, ((size_t)n_max * n_max + n_max) * sizeof(double));
+    for (int b = 0; b < B && e == hipSuccess; b++) {
+        const int n = 3 + 2 * n_lm[b];
+        double *xd = stage + (size_t)n * n;
+        hipLaunchKernelGGL(k_export, dim3(cdiv(n, 256), n), dim3(256), 0, h->s_chain, h->dv, b, h->buf_in, xd, stage, n, n);
+        e = stream_wait(h->s_chain);
+        if (e != hipSuccess) break;
+        hipLaunchKernelGGL(k_import, dim3(cdiv(n, 256), n), dim3(256), 0, nh->s_chain, nh->dv, b, nh->buf_in, (const double *)xd, (const double *)stage, n, n);
+        e = stream_wait(nh->s_chain);
+    }
+    if (stage) hipFree(stage);
+    // counters, decision log (entries name state indices, which do not depend on the capacity), then the bookkeeping kernel
+    // (landmark counts, host mirror: pose, count, log position; it also clears the sticky capacity status -- there is room now)
+    const bool same_log = nh->dv.logcap == h->dv.logcap;
+    if (e == hipSuccess) e = hipMemcpyAsync(nh->dv.stats, h->dv.stats, sizeof(ekf_stats) * B, hipMemcpyDeviceToDevice, nh->s_chain);
+    if (e == hipSuccess && same_log) e = hipMemcpyAsync(nh->dv.log, h->dv.log, sizeof(ekf_decision) * (size_t)B * h->dv.logcap, hipMemcpyDeviceToDevice, nh->s_chain);
+    if (e == hipSuccess && same_log) e = hipMemcpyAsync(nh->dv.log_count, h->dv.log_count, sizeof(long long) * B, hipMemcpyDeviceToDevice, nh->s_chain);
+    if (e == hipSuccess) {
+        for (int b = 0; b < B; b++) hipLaunchKernelGGL(k_set_meta, dim3(1), dim3(64), 0, nh->s_chain, nh->dv, b, n_lm[b]);
+        e = stream_wait(nh->s_chain);
+    }
+    if (e != hipSuccess || check_launch() != EKF_OK) {
+        std::string keep = e != hipSuccess ? std::string(hipGetErrorString(e)) : g_last_error;
+        ekf_destroy(nh);
+        (void)hipGetLastError();
+        std::lock_guard<std::mutex> lk(g_res_mu);
+        g_cus_claimed[h->device] += had_claimed;
+        h->claimed_cus = had_claimed;
+        return set_error(EKF_ERR_HIP, keep.c_str());
+    }
+    for (int b = 0; b < B; b++) {  // the host mirror's newest decisions and counters (ekf_get_stats / the compat shim read them there)
+        memcpy(nh->mirror_h[b].last, h->mirror_h[b].last, sizeof nh->mirror_h[b].last);
+        nh->mirror_h[b].stats = h->mirror_h[b].stats;
+    }
+    nh->stats_in_mirror = h->stats_in_mirror;
+    nh->n_lm_hi = h->n_lm_hi;
+    nh->prof_flush = h->prof_flush;
+    // a loaded script is laid out per (operation, filter): independent of the capacity
+    std::swap(nh->script_d, h->script_d);
+    nh->script_steps = h->script_steps, nh->script_M = h->script_M, nh->script_has_truth = h->script_has_truth;
+    h->script_steps = 0;
+    std::swap(*h, *nh);  // the caller's handle now owns the larger buffers ...
+    ekf_destroy(nh);     // ... and the old ones go
     return refresh_bounds(h);
 }
 

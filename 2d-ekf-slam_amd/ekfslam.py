@@ -16,7 +16,7 @@ NEW, OLD, IGNORE = 1, 2, 3
 
 # every symbol include/ekfslam_c.h declares
 ABI_SYMBOLS = [
-    "ekf_last_error", "ekf_default_params", "ekf_create", "ekf_batch_create", "ekf_destroy", "ekf_batch_size",
+    "ekf_last_error", "ekf_default_params", "ekf_create", "ekf_batch_create", "ekf_destroy", "ekf_reserve", "ekf_batch_size",
     "ekf_capacity", "ekf_window", "ekf_overlap", "ekf_propagate", "ekf_propagate_q", "ekf_update", "ekf_update_compass", "ekf_get_pose",
     "ekf_num_landmarks", "ekf_get_robot_cov", "ekf_get_x", "ekf_batch_propagate", "ekf_batch_propagate_q", "ekf_batch_update",
     "ekf_batch_update_compass", "ekf_batch_get_pose", "ekf_batch_num_landmarks", "ekf_get_state", "ekf_set_state",
@@ -72,6 +72,7 @@ def load():
     L.ekf_create.argtypes = [ctypes.POINTER(_H), ctypes.c_int, ctypes.c_int, ctypes.POINTER(EkfParams)]
     L.ekf_batch_create.argtypes = [ctypes.POINTER(_H), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(EkfParams)]
     L.ekf_destroy.argtypes = [_H]
+    L.ekf_reserve.argtypes = [_H, ctypes.c_int]
     L.ekf_batch_size.argtypes = [_H]
     L.ekf_capacity.argtypes = [_H]
     L.ekf_window.argtypes = [_H]
@@ -148,6 +149,13 @@ class FilterBatch:
         self.batch = batch
         self.capacity = capacity_landmarks
         self.window = int(self.L.ekf_window(self.h))  # effective max_pending
+        self.overlap = bool(self.L.ekf_overlap(self.h))
+
+    def reserve(self, capacity_landmarks):
+        """Grow the landmark capacity (ekf_reserve: the state moves to larger device buffers, the handle stays)."""
+        _chk(self.L.ekf_reserve(self.h, int(capacity_landmarks)))
+        self.capacity = int(self.L.ekf_capacity(self.h))
+        self.window = int(self.L.ekf_window(self.h))
         self.overlap = bool(self.L.ekf_overlap(self.h))
 
     def close(self):
@@ -324,11 +332,12 @@ class KalmanFilter:
     members X, Y, Phi, Num_Landmarks and the same three methods, forwarding to the C ABI.  The ARIA
     velocity reads of doPropagation (kalmanfilter.cpp:17-20) become the v_mm_s / rotvel_deg_s arguments."""
 
-    def __init__(self, capacity_landmarks=1024, device=0, **params):
+    def __init__(self, capacity_landmarks=1024, device=0, print_decisions=False, **params):
         self._f = FilterBatch(1, capacity_landmarks, device, **params)
         self.X = self.Y = self.Phi = 0.0
         self.Num_Landmarks = 0
         self.last_decisions = []
+        self.Print_Decisions = print_decisions  # the reference's stdout tokens "New " / "Old " / "Ignore " (Update.cpp:154,183,191)
 
     def _mirror(self):
         pose = self._f.poses()[0]
@@ -347,7 +356,12 @@ class KalmanFilter:
         n_z = z.shape[1]
         Rm = np.asarray(R_chunk, dtype=np.float64).reshape(2, 2 * n_z)
         R = np.stack([Rm[:, 2 * j:2 * j + 2] for j in range(n_z)])
+        if self.Num_Landmarks + n_z > self._f.capacity:  # the reference's state grows without bound (Update.cpp:158-177): make room first
+            self._f.reserve(max(2 * self._f.capacity, self.Num_Landmarks + n_z))
         self.last_decisions = self._f.update(z.T.reshape(1, n_z, 2), R.reshape(1, n_z, 2, 2))[0]
+        if self.Print_Decisions:
+            import sys
+            sys.stdout.write("".join({NEW: "New ", OLD: "Old ", IGNORE: "Ignore "}[d[0]] for d in self.last_decisions))
         self._mirror()
 
     def doUpdateCompass(self, z, R):

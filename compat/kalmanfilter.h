@@ -7,11 +7,13 @@
 //   - the ARIA velocity reads under robot->lock() and their unit conversions (kalmanfilter.cpp:17-26)
 //   - the two per-step file writes (kalmanfilter.cpp:51,56-59), same formats, same index quirk
 //   - the public mirrors refreshed after every call (kalmanfilter.cpp:46-48,85-89)
-// What the reference does not have: an error channel.  A failing C-ABI call throws std::runtime_error.
+// What the reference does not have: an error channel.  A failing C-ABI call throws std::runtime_error (a full map is not a failure:
+// doUpdate grows the capacity, as the reference's state grows).
 #ifndef KALMANFILTER_H
 #define KALMANFILTER_H
 
 #include <fstream>
+#include <iostream>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -38,6 +40,9 @@ public:
     double Y = 0.0;
     double Phi = 0.0;
     int Num_Landmarks = 0;
+    // not in the reference: the reference's only diagnostics -- "New " / "Old " / "Ignore " on stdout, one token per measurement
+    // (Update.cpp:154,183,191; slam.cpp:169-171 prints "Update: " in front and Num_Landmarks behind) -- can be switched off
+    bool Print_Decisions = true;
 
     // capacity_landmarks / device_id are additions with defaults: `new KalmanFilter(&robot)` still works
     explicit KalmanFilter(ArRobot *robot, int capacity_landmarks = 4096, int device_id = 0) : robot(robot) {
@@ -70,9 +75,17 @@ public:
 
     void doUpdate(Eigen::MatrixXd z_chunk, Eigen::MatrixXd R_chunk) {
         int n_z = (int)(z_chunk.size() / 2);  // Update.cpp:27
+        // The reference's state grows with every New landmark and never runs out (Update.cpp:158-177, kalmanfilter.cpp:78-84); the
+        // device buffers are sized by a capacity, so make room BEFORE a chunk that could exceed it (each measurement adds at most
+        // one landmark): the capacity doubles, the state moves over on the device (ekf_reserve), nothing is dropped, nothing throws
+        const int cap = ekf_capacity(h);
+        if (Num_Landmarks + n_z > cap) check(ekf_reserve(h, 2 * cap > Num_Landmarks + n_z ? 2 * cap : Num_Landmarks + n_z));
         decisions.resize(n_z);
         // z_chunk.data() / R_chunk.data() are column-major, which is what the C ABI takes
         check(ekf_update(h, z_chunk.data(), R_chunk.data(), n_z, decisions.data()));  // Gamma 50 / 10: kalmanfilter.cpp:67-68
+        if (Print_Decisions)  // Update.cpp:154,183,191: the same tokens, in measurement order, no newline, no flush
+            for (const ekf_decision &d : decisions)
+                std::cout << (d.decision == EKF_DECISION_NEW ? "New " : d.decision == EKF_DECISION_OLD ? "Old " : "Ignore ");
         mirror();
     }
 

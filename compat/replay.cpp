@@ -53,16 +53,17 @@ static bool read_state(const char *path, std::vector<double> &x, std::vector<dou
 int main(int argc, char **argv) {
     std::vector<std::string> pos;
     const char *state_in = nullptr, *state_out = nullptr;
-    bool timing = false, detect = false;
+    bool timing = false, detect = false, quiet = false;  // --quiet: without slam.cpp's stdout chatter ("Compass: ...", "Update: New 12")
     for (int i = 1; i < argc; i++) {
         if (!std::strcmp(argv[i], "--state") && i + 1 < argc) state_in = argv[++i];
         else if (!std::strcmp(argv[i], "--dump-state") && i + 1 < argc) state_out = argv[++i];
         else if (!std::strcmp(argv[i], "--timing")) timing = true;
         else if (!std::strcmp(argv[i], "--detect")) detect = true;
+        else if (!std::strcmp(argv[i], "--quiet")) quiet = true;
         else pos.push_back(argv[i]);
     }
     if (pos.size() < 2) {
-        std::fprintf(stderr, "usage: %s <records.txt> <output-dir> [capacity_landmarks] [--state f] [--dump-state f] [--timing]\n", argv[0]);
+        std::fprintf(stderr, "usage: %s <records.txt> <output-dir> [capacity_landmarks] [--state f] [--dump-state f] [--timing] [--detect] [--quiet]\n", argv[0]);
         return 2;
     }
     std::ifstream in(pos[0]);
@@ -85,6 +86,8 @@ int main(int argc, char **argv) {
     try {
         FeatureDetector *f = detect ? new FeatureDetector(&sick) : nullptr;  // slam.cpp:110
         KalmanFilter *ekf = new KalmanFilter(&robot, cap);  // slam.cpp:127
+        if (quiet || timing) ekf->Print_Decisions = false;
+        const bool chatter = !(quiet || timing);
         if (state_in) {
             std::vector<double> x, P;
             if (!read_state(state_in, x, P)) return std::fprintf(stderr, "cannot read %s\n", state_in), 2;
@@ -122,11 +125,15 @@ int main(int argc, char **argv) {
                 double compass;
                 f->getFeatures(&fvec, &compass, ekf->Phi);
                 if (compass != f->NO_COMPASS) {  // :144-147
+                    if (chatter) std::cout << "Compass: " << compass << std::endl;  // :145
                     compassFile << compass << "\n";
                     ekf->doUpdateCompass(compass, 0.0005);
                 }
                 n = (int)fvec.size();
-            } else if (comp != "nan") ekf->doUpdateCompass(std::stod(comp), 0.0005);
+            } else if (comp != "nan") {
+                if (chatter) std::cout << "Compass: " << std::stod(comp) << std::endl;  // :145
+                ekf->doUpdateCompass(std::stod(comp), 0.0005);
+            }
             for (int i = 0; i < n; i++) {
                 double fxmm, fymm;
                 if (detect) fxmm = fvec[i].x, fymm = fvec[i].y;
@@ -147,7 +154,9 @@ int main(int argc, char **argv) {
                         }
                         R_chunk(r, c) = s;
                     }
-                ekf->doUpdate(z_chunk, R_chunk);  // :170
+                if (chatter) std::cout << "Update: ";  // :169
+                ekf->doUpdate(z_chunk, R_chunk);  // :170 (prints "New " / "Old " / "Ignore " as Update.cpp:154,183,191 do)
+                if (chatter) std::cout << ekf->Num_Landmarks << std::endl;  // :171
                 const ekf_decision &d = ekf->lastDecisions()[0];
                 decisionFile << d.decision << " " << d.matched << " " << d.mahal << "\n";
                 double newX = fx * std::cos(ekf->Phi) - fy * std::sin(ekf->Phi);  // :173-177
@@ -168,6 +177,7 @@ int main(int argc, char **argv) {
                 loopTime = 0.0;
             }
         }
+        std::cout.flush();
         std::printf("final %.17g %.17g %.17g %d\n", ekf->X, ekf->Y, ekf->Phi, ekf->Num_Landmarks);
         if (timing && !step_us.empty()) {
             std::vector<double> s(step_us.begin() + std::min<size_t>(step_us.size() / 5, 10), step_us.end());  // skip the warm-up iterations

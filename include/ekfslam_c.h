@@ -94,6 +94,13 @@ void ekf_default_params(ekf_params *p);
 int ekf_create(ekf_handle *out, int capacity_landmarks, int device_id, const ekf_params *params);
 int ekf_batch_create(ekf_handle *out, int batch, int capacity_landmarks, int device_id, const ekf_params *params);
 int ekf_destroy(ekf_handle h);
+/* Grow the landmark capacity of every filter of the handle to at least capacity_landmarks (no-op when it is there already).  The
+ * reference grows x and P by two rows and columns with every New landmark (Update.cpp:158-177, the O(n^2) copy of
+ * kalmanfilter.cpp:78-84) and never runs out; here all device memory is sized by the capacity, so growth is an explicit, rare
+ * step: device buffers of the larger capacity are allocated, the state moves over on the device, counters, decision log and a
+ * loaded script are kept, the handle stays valid.  Synchronises; clears a sticky EKF_ERR_CAPACITY.  EKF_ERR_STATE when the
+ * larger chain launch would not fit the GPU beside the other live handles (the handle is unchanged then). */
+int ekf_reserve(ekf_handle h, int capacity_landmarks);
 int ekf_batch_size(ekf_handle h);
 int ekf_capacity(ekf_handle h);
 /* The effective max_pending: the requested window, shortened when capacity_landmarks x window does not fit

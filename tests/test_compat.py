@@ -88,12 +88,14 @@ def test_replay_against_the_oracle_trajectory_and_reference_file_layout(replay_b
             feats = " ".join("%r %r" % (float(fx), float(fy)) for fx, fy in st["feats_mm"])
             f.write("%r %r %r %s %d %s\n" % (st["dt"], st["v"] * 1000.0, st["w"] * 180.0 / 3.141592654, comp, len(st["feats_mm"]), feats))
     dump = tmp_path / "final.bin"
-    out = subprocess.run([replay_bin, str(rec), str(tmp_path), "64", "--dump-state", str(dump)], capture_output=True, text=True)
+    # capacity 4 for a map that ends with 17 landmarks: the reference's state simply grows (Update.cpp:158-177), so the shim
+    # must grow its device buffers on the way (ekf_reserve, doubling) -- without a visible effect on any result
+    out = subprocess.run([replay_bin, str(rec), str(tmp_path), "4", "--dump-state", str(dump)], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
 
     # the oracle, driven the same way
     x, P = np.zeros(3), np.zeros((3, 3))
-    odom, cov, known, feats, decs, scan_pts = [], [], [], [], [], []
+    odom, cov, known, feats, decs, scan_pts, chatter = [], [], [], [], [], [], []
     cur_scan, loop_time = [], 0.0
     for s, st in enumerate(script):
         if s in scans:
@@ -105,11 +107,14 @@ def test_replay_against_the_oracle_trajectory_and_reference_file_layout(replay_b
         for i in range(1, n_lm):                                   # kalmanfilter.cpp:56-59: stride 1, from i = 1
             known.append((x[3 + i], x[4 + i]))
         if st["compass"] is not None:
+            chatter.append("Compass:")
             x, P = oc.compass(x, P, st["compass"], 0.0005)
         for fx, fy in st["feats_mm"]:
             z, R = oc.make_measurement(fx, fy)
             x, P, d, m, mh = oc.update(x, P, z.reshape(2, 1), R)
             decs.append((d[0], m[0], mh[0]))
+            # what slam.cpp:169-171 and Update.cpp:154,183,191 leave on stdout for this measurement
+            chatter.append("Update: %s %d" % ({oc.NEW: "New", oc.OLD: "Old", oc.IGNORE: "Ignore"}[d[0]], (x.size - 3) // 2))
             c, sn = np.cos(x[2]), np.sin(x[2])
             feats.append((z[0] * c - z[1] * sn + x[0], z[0] * sn + z[1] * c + x[1]))  # slam.cpp:173-177
         odom.append((x[0], x[1]))                                  # slam.cpp:181
@@ -140,8 +145,14 @@ def test_replay_against_the_oracle_trajectory_and_reference_file_layout(replay_b
     xg, Pg = read_state(str(dump))
     assert_state_close(xg, Pg, x, P, "replay final state")
     assert np.array_equal(Pg, Pg.T)
-    final = out.stdout.split()
-    assert int(final[4]) == (x.size - 3) // 2 and np.allclose([float(v) for v in final[1:4]], x[:3], **tol)
+    lines = out.stdout.strip().split("\n")
+    final = lines[-1].split()
+    assert final[0] == "final" and int(final[4]) == (x.size - 3) // 2 and np.allclose([float(v) for v in final[1:4]], x[:3], **tol)
+    assert (x.size - 3) // 2 > 16, "the map was meant to outgrow the initial capacity of 4 three times"
+    # the reference's only diagnostics, token for token: "Compass: <z>" (slam.cpp:145), "Update: " + "New " / "Old " / "Ignore "
+    # (Update.cpp:154,183,191) + Num_Landmarks (slam.cpp:169-171)
+    got = [l if l.startswith("Update:") else l.split()[0] for l in lines[:-1]]
+    assert got == chatter
     # what plot.py:10-31 does with the three files it opens (relative to the directory the program ran in)
     for rel in ("data/odom/odomRun.txt", "data/features/featuresRun.txt", "data/scan/scanRun.txt"):
         rows = [r for r in open(str(tmp_path / rel)).read().split("\n") if r != ""]
@@ -231,7 +242,7 @@ def test_replay_detect_runs_perception_and_filter_end_to_end_like_the_oracle(rep
             f.write("scan %d %s\n" % (r.size, " ".join("%r %r %r" % (float(a), float(b), float(c)) for a, b, c in zip(r, lx, ly))))
             f.write("%r %r %r nan 0\n" % (float(it["dt"]), float(it["v_mm_s"]), float(it["rot_deg_s"])))
     dump = tmp_path / "final.bin"
-    out = subprocess.run([replay_bin, str(rec), str(tmp_path), "64", "--detect", "--dump-state", str(dump)], capture_output=True, text=True)
+    out = subprocess.run([replay_bin, str(rec), str(tmp_path), "64", "--detect", "--quiet", "--dump-state", str(dump)], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
 
     x, P = np.zeros(3), np.zeros((3, 3))
