@@ -83,6 +83,7 @@ struct ekf_batch {
     int chain_wgs;        // k_chain workgroups per filter
     int chain_filters;    // filters per k_chain launch (all of the batch when its workgroups are resident together)
     int claimed_cus;      // CUs this handle's chain workgroups occupy when they run (residency registry, below)
+    int solo_cus = 0;     // one-workgroup handles: CUs their launches occupy while they run (they claim none: g_cus_solo)
     bool flush_masked;    // s_flush is a dedicated CU-masked queue
     size_t chain_lds;     // dynamic LDS of a k_chain launch: the own-row cache
     double *bm1_base;     // allocation behind dv.Bm[1] (overlap mode)
@@ -242,6 +243,10 @@ static hipError_t dev_alloc_zero(T **p, size_t count, size_t *total, hipStream_t
 // refused at creation.  Per process and device; other processes on the GPU are out of sight.
 static std::mutex g_res_mu;
 static int g_cus_claimed[64];
+// CUs the launches of one-workgroup ("solo") handles occupy while they run.  Those handles wait for nobody, so they need no
+// co-residency and claim nothing above -- but a 256-filter k_solo launch does fill the GPU, and a multi-segment chain launch of
+// ANOTHER handle, whose gated dense passes need free CUs, must know (launch_ops: persist).
+static int g_cus_solo[64];
 
 static int create_impl(ekf_batch *h, int batch, int capacity_landmarks, int device_id, const ekf_params *params, const hipDeviceProp_t &prop);
 
@@ -423,6 +428,9 @@ static int create_impl(ekf_batch *h, int batch, int capacity_landmarks, int devi
         }
         g_cus_claimed[device_id] += need;
         h->claimed_cus = need;
+        h->solo_cus = h->solo ? (h->chain_filters + per_cu - 1) / per_cu : 0;
+        if (h->solo_cus > prop.multiProcessorCount) h->solo_cus = prop.multiProcessorCount;
+        g_cus_solo[device_id] += h->solo_cus;
         h->ncu = prop.multiProcessorCount;
     }
     size_t B = batch;
@@ -624,9 +632,10 @@ extern "C" int ekf_destroy(ekf_handle h) {
     for (auto e : h->prof_pool) hipEventDestroy(e);
     TRACE("destroy: streams");
     if (h->s_chain) pool_give(h->device, -1, h->s_chain);
-    if (h->claimed_cus > 0) {
+    if (h->claimed_cus > 0 || h->solo_cus > 0) {
         std::lock_guard<std::mutex> lk(g_res_mu);
         g_cus_claimed[h->device] -= h->claimed_cus;
+        g_cus_solo[h->device] -= h->solo_cus;
     }
     delete h;
     (void)hipGetLastError();
@@ -892,13 +901,13 @@ static int launch_ops(ekf_batch *h, const double *in, const int *cursor, int k0,
     bool persist = h->persist && defer_last_close && cursor == nullptr && h->overlap && h->inkernel_wait && h->chain_filters == h->dv.B;
     if (persist) {
         std::lock_guard<std::mutex> lk(g_res_mu);
-        persist = g_cus_claimed[h->device] * 2 <= h->ncu;
+        persist = (g_cus_claimed[h->device] + g_cus_solo[h->device] - h->solo_cus) * 2 <= h->ncu;  // (everybody else's chain workgroups, solo launches included)
     }
     const bool solo = h->solo_kernel;  // one-workgroup filters run by k_solo
     if (h->solo && h->ngroups > 1 && cursor == nullptr) {
         long slots = h->pending;
         for (int q = 0; q < nops; q++) slots += consumes[q] ? 1 : 0;
-        if (slots >= 2L * h->dv.maxp) return launch_ops_grouped(h, in, k0, consumes, nops);  // the call closes at least two windows
+        if (slots >= 2L * h->dv.maxp) return launch_ops_grouped(h, in, k0, consumes, nops);  // the call closes at least two windows (scripted runs, and immediate-mode chunks that long)
     }
     ChainPlan plan;
     memset(&plan, 0, sizeof plan);
@@ -994,12 +1003,30 @@ static int launch_ops_grouped(ekf_batch *h, const double *in, int k0, const unsi
     hipError_t e;
     if ((e = hipEventRecord(h->ev_fork, h->s_chain)) != hipSuccess) return set_error(EKF_ERR_HIP, hipGetErrorString(e));
     for (int g = 1; g < ng; g++) {
-        if ((e = hipStreamWaitEvent(h->s_grp[g], h->ev_fork, 0)) != hipSuccess) return set_error(EKF_ERR_HIP, hipGetErrorString(e));
+        if ((e = hipStreamWaitEvent(h->s_grp[g], h->ev_fork, 0)) != hipSuccess) return set_error(EKF_ERR_HIP, hipGetErrorString(e));  // (nothing has been launched on a group stream yet)
         if (h->stagger_ticks > 0) hipLaunchKernelGGL(k_delay, dim3(1), dim3(64), 0, h->s_grp[g], (long long)g * h->stagger_ticks);
     }
     const bool interleave = h->batch_interleave;
+    // The group streams have been forked off s_chain: whatever happens from here on, they are joined back before this function
+    // returns -- later work on s_chain (ring reuse, memsets of ekf_set_state, the hipFree of a staging buffer) must not run beside
+    // chain and pass kernels still queued on a group stream.  An error on the way is remembered, the join still happens (where even
+    // the join's event calls fail the group stream is drained on the host).
+    int rc_pending = EKF_OK;
+    if (h->prof_flush) {  // (event creation can fail: do it in front of the first launch, not between a fork and its join)
+        long passes = 0, used_ = h->pending;
+        for (int q = 0; q < nops; q++)
+            if (consumes[q] && ++used_ == maxp) passes++, used_ = 0;
+        while (h->prof_pool.size() < h->prof_used + 2 * (size_t)ng * (size_t)(passes + 1)) {
+            hipEvent_t ev;
+            if (hipEventCreate(&ev) != hipSuccess) {
+                rc_pending = set_error(EKF_ERR_HIP, "hipEventCreate failed (dense-pass profiling)");
+                break;
+            }
+            h->prof_pool.push_back(ev);
+        }
+    }
     int i = 0;
-    while (i < nops) {
+    while (i < nops && rc_pending == EKF_OK) {
         int start = i, used = h->pending;
         while (i < nops && i - start < EKF_CHAIN_MAX_OPS) {
             if (consumes[i]) {
@@ -1030,14 +1057,7 @@ static int launch_ops_grouped(ekf_batch *h, const double *in, int k0, const unsi
             else hipLaunchKernelGGL(k_chain, dim3(1, nb), dim3(h->chain_threads), h->chain_lds, h->s_grp[g], h->dv, in, (const int *)nullptr, plan, b0);
             if (!do_pass) continue;
             hipEvent_t e0 = nullptr, e1 = nullptr;
-            if (h->prof_flush) {
-                while (h->prof_pool.size() < h->prof_used + 2) {
-                    hipEvent_t ev;
-                    HIP_TRY(hipEventCreate(&ev));
-                    h->prof_pool.push_back(ev);
-                }
-                e0 = h->prof_pool[h->prof_used++], e1 = h->prof_pool[h->prof_used++];
-            }
+            if (h->prof_flush && h->prof_used + 2 <= h->prof_pool.size()) e0 = h->prof_pool[h->prof_used++], e1 = h->prof_pool[h->prof_used++];  // (created above)
             if (interleave)
                 hipExtLaunchKernelGGL(k_flush_rb, dim3((unsigned)(cdiv(nb, 8) * 8 * nwg), 1), dim3(256), 0, h->s_grp[g], e0, e1, 0, h->dv, nT_hi, h->cur_set, maxp, h->buf_in, h->buf_in,
                                       (const int *)nullptr, nwg, rev, b0, nb);
@@ -1051,9 +1071,13 @@ static int launch_ops_grouped(ekf_batch *h, const double *in, int k0, const unsi
         }
     }
     for (int g = 1; g < ng; g++) {
-        if ((e = hipEventRecord(h->ev_join[g], h->s_grp[g])) != hipSuccess) return set_error(EKF_ERR_HIP, hipGetErrorString(e));
-        if ((e = hipStreamWaitEvent(h->s_chain, h->ev_join[g], 0)) != hipSuccess) return set_error(EKF_ERR_HIP, hipGetErrorString(e));
+        if ((e = hipEventRecord(h->ev_join[g], h->s_grp[g])) == hipSuccess) e = hipStreamWaitEvent(h->s_chain, h->ev_join[g], 0);
+        if (e != hipSuccess) {
+            (void)stream_wait(h->s_grp[g]);  // no event to order the streams with: drain this one here
+            if (rc_pending == EKF_OK) rc_pending = set_error(EKF_ERR_HIP, hipGetErrorString(e));
+        }
     }
+    if (rc_pending != EKF_OK) return rc_pending;
     return check_launch();
 }
 

@@ -147,10 +147,18 @@ extern "C" int feat_get_intermediates(feat_handle h, int scan, unsigned char *gr
     FEAT_TRY(hipMemcpy(&nl, h->dv.n_lines + s, sizeof(int), hipMemcpyDeviceToHost));
     FEAT_TRY(hipMemcpy(&ns, h->dv.n_segs + s, sizeof(int), hipMemcpyDeviceToHost));
     if (n_lines) *n_lines = nl;
-    if (n_segs) *n_segs = ns;
+    if (n_segs) *n_segs = ns < FEAT_MAX_SEGS ? ns : FEAT_MAX_SEGS;  // rows of segs that hold data (a caller loops over exactly these); the count FOUND: feat_segments_found
     if (lines && nl > 0) FEAT_TRY(hipMemcpy(lines, h->dv.lines + s * FEAT_NUM_PEAKS * 3, (size_t)nl * 3 * sizeof(double), hipMemcpyDeviceToHost));
     const int ns_stored = ns < FEAT_MAX_SEGS ? ns : FEAT_MAX_SEGS;
     if (segs && ns_stored > 0) FEAT_TRY(hipMemcpy(segs, h->dv.segs + s * FEAT_MAX_SEGS * 7, (size_t)ns_stored * 7 * sizeof(double), hipMemcpyDeviceToHost));
+    return EKF_OK;
+}
+
+extern "C" int feat_segments_found(feat_handle h, int scan, int *found_out) {
+    if (!h || !found_out || scan < 0 || scan >= h->last_scans) return ekf_set_last_error(EKF_ERR_BAD_ARG, "bad argument");
+    if (!h->keep) return ekf_set_last_error(EKF_ERR_STATE, "the handle was created without keep_intermediates");
+    FEAT_TRY(hipSetDevice(h->device));
+    FEAT_TRY(hipMemcpy(found_out, h->dv.n_segs + scan, sizeof(int), hipMemcpyDeviceToHost));
     return EKF_OK;
 }
 

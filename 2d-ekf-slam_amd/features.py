@@ -8,7 +8,7 @@ import numpy as np
 from . import ekfslam
 
 THETA_SIZE, RADIUS_SIZE, NUM_PEAKS, MAX_SEGS, MAX_POINTS = 180, 1601, 200, 128, 384
-FEAT_ABI_SYMBOLS = ["feat_create", "feat_destroy", "feat_extract", "feat_get_intermediates", "feat_last_kernel_ms", "feat_last_tail_share"]
+FEAT_ABI_SYMBOLS = ["feat_create", "feat_destroy", "feat_extract", "feat_get_intermediates", "feat_segments_found", "feat_last_kernel_ms", "feat_last_tail_share"]
 
 _dp = ctypes.POINTER(ctypes.c_double)
 _ip = ctypes.POINTER(ctypes.c_int)
@@ -25,6 +25,7 @@ def _lib():
         L.feat_destroy.argtypes = [_H]
         L.feat_extract.argtypes = [_H, ctypes.c_int, _ip, _dp, _dp, _dp, _ip, _dp]
         L.feat_get_intermediates.argtypes = [_H, ctypes.c_int, _up, _ip, _ip, _dp, _ip, _dp, _ip]
+        L.feat_segments_found.argtypes = [_H, ctypes.c_int, _ip]
         L.feat_last_kernel_ms.argtypes = [_H, _dp]
         L.feat_last_tail_share.argtypes = [_H, _dp]
         _bound = True
@@ -76,8 +77,11 @@ class FeatureExtractor:
         nl, ns, dropped = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
         ekfslam._chk(self.L.feat_get_intermediates(self.h, scan, grid.ctypes.data_as(_up), peaks.ctypes.data_as(_ip), ctypes.byref(nl),
                                                    lines.ctypes.data_as(_dp), ctypes.byref(ns), segs.ctypes.data_as(_dp), ctypes.byref(dropped)))
-        return dict(grid=grid, peaks=peaks, lines=lines[:nl.value].copy(), segs=segs[:min(ns.value, MAX_SEGS)].copy(), dropped=dropped.value,
-                    segs_found=ns.value)  # (segs_found > MAX_SEGS: the list was cut)
+        found = ctypes.c_int(0)
+        ekfslam._chk(self.L.feat_segments_found(self.h, scan, ctypes.byref(found)))
+        assert 0 <= ns.value <= MAX_SEGS
+        return dict(grid=grid, peaks=peaks, lines=lines[:nl.value].copy(), segs=segs[:ns.value].copy(), dropped=dropped.value,
+                    segs_found=found.value)  # (segs_found > MAX_SEGS: the list was cut)
 
     def kernel_ms(self):
         ms = ctypes.c_double(0)

@@ -43,11 +43,16 @@ int feat_extract(feat_handle h, int n_scans, const int *n_points, const double *
 /* Intermediate results of scan `scan` of the last feat_extract (any pointer may be NULL):
  * grid [180][1601] votes (HoughTransform::houghGrid), peaks [200] cell indices (getPeaks' array, position for position),
  * lines [n][3] = radius, theta, weight (houghLine), segs [n][7] = radius, theta, startX, startY, endX, endY, numPoints;
- * *n_segs = segments FOUND (the reference's vector is unbounded): more than EKF_FEAT_MAX_SEGS means only that many were
- * stored and paired into corners -- the same convention as n_corners_out / max_corners of feat_extract.
+ * *n_segs = rows of segs that hold data (at most EKF_FEAT_MAX_SEGS: a caller's loop over segs[0 .. *n_segs) stays inside its
+ * buffer); the reference's vector is unbounded -- how many segments were FOUND (more than were stored means the list was cut,
+ * and only the stored ones were paired into corners) is what feat_segments_found reports.
  * dropped_votes = votes whose radius bin fell outside its theta row (the reference writes outside the row there). */
 int feat_get_intermediates(feat_handle h, int scan, unsigned char *grid, int *peaks, int *n_lines, double *lines, int *n_segs, double *segs,
                            int *dropped_votes);
+
+/* Line segments scan `scan` of the last feat_extract FOUND (featuredetector.cpp:196-213 pushes every one of them); more than
+ * EKF_FEAT_MAX_SEGS: the stored list was cut there.  Needs keep_intermediates. */
+int feat_segments_found(feat_handle h, int scan, int *found_out);
 
 /* Device time of the last feat_extract's kernel in milliseconds (hipEvents around the launch). */
 int feat_last_kernel_ms(feat_handle h, double *ms_out);

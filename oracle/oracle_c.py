@@ -56,6 +56,64 @@ def _p(a):
     return a.ctypes.data_as(_dp)
 
 
+_eigen = False
+
+
+def eigen_lib():
+    """oracle/_build/libekf_oracle_eigen.so -- the same three operations on Eigen types (ekf_oracle_eigen.cpp) -- or None where
+    Eigen is not installed (oracle/Makefile builds it only when <Eigen/Dense> is found)."""
+    global _eigen
+    if _eigen is False:
+        build()
+        so = os.path.join(_HERE, "_build", "libekf_oracle_eigen.so")
+        _eigen = None
+        if os.path.exists(so):
+            L = ctypes.CDLL(so)
+            L.ekf_eigen_available.restype = ctypes.c_int
+            if L.ekf_eigen_available():
+                L.ekf_eigen_propagate.argtypes = [ctypes.c_int, _dp, _dp, ctypes.c_double, ctypes.c_double, _dp, ctypes.c_double, _dp, _dp]
+                L.ekf_eigen_propagate.restype = None
+                L.ekf_eigen_update.argtypes = [ctypes.c_int, _dp, _dp, ctypes.c_int, _dp, _dp, ctypes.c_int, ctypes.c_int, ctypes.c_double, _dp, _dp, _ip, _ip, _ip, _dp]
+                L.ekf_eigen_update.restype = None
+                L.ekf_eigen_compass.argtypes = [ctypes.c_int, _dp, _dp, ctypes.c_double, ctypes.c_double]
+                L.ekf_eigen_compass.restype = None
+                _eigen = L
+    return _eigen
+
+
+def eigen_propagate(x, P, v, w, Q, dt):
+    L = eigen_lib()
+    n = x.size
+    x, P, Q = (np.ascontiguousarray(a, dtype=np.float64) for a in (x, P, np.asarray(Q).ravel(order="F")))
+    xo, Po = np.empty(n), np.empty((n, n))
+    L.ekf_eigen_propagate(n, _p(x), _p(P), v, w, _p(Q), dt, _p(xo), _p(Po))
+    return xo, Po
+
+
+def eigen_update(x, P, z_chunk, R_chunk, gamma_max=50, gamma_min=10, cond_limit=80.0):
+    L = eigen_lib()
+    n = x.size
+    z = np.ascontiguousarray(np.asarray(z_chunk, dtype=np.float64).reshape(2, -1).ravel(order="F"))
+    n_z = z.size // 2
+    R = np.ascontiguousarray(np.asarray(R_chunk, dtype=np.float64).reshape(2, 2 * n_z).ravel(order="F"))
+    x, P = np.ascontiguousarray(x, dtype=np.float64), np.ascontiguousarray(P, dtype=np.float64)
+    cap = n + 2 * n_z
+    xo, Po = np.empty(cap), np.empty(cap * cap)
+    n_out = ctypes.c_int(0)
+    dec, mat = (ctypes.c_int * n_z)(), (ctypes.c_int * n_z)()
+    mah = np.empty(n_z)
+    L.ekf_eigen_update(n, _p(x), _p(P), n_z, _p(z), _p(R), gamma_max, gamma_min, cond_limit, _p(xo), _p(Po), ctypes.byref(n_out), dec, mat, _p(mah))
+    m = n_out.value
+    return xo[:m].copy(), Po[:m * m].reshape(m, m).copy(), list(dec), list(mat), list(mah)
+
+
+def eigen_compass(x, P, z, R):
+    L = eigen_lib()
+    x, P = np.array(x, dtype=np.float64), np.array(P, dtype=np.float64)
+    L.ekf_eigen_compass(x.size, _p(x), _p(P), z, R)
+    return x, P
+
+
 def set_threads(n):
     """Threads of the structured mode's element-wise O(n^2) loops (results are independent of it); the
     faithful mode, which bench.py times as the CPU baseline, is always single-threaded."""

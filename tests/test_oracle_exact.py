@@ -1,0 +1,100 @@
+"""How far is the (parity-unpinned) fp64 oracle from the EXACT value of the formulas the reference states?  Every operation of the
+committed golden sequences and a config-1 style lifecycle are re-evaluated in 50 decimal digits (oracle/ekf_exact.py, mpmath) on
+the oracle's own fp64 inputs: the oracle must be within 1e-12 (relative, norm-wise) of the exact result of EACH operation and
+within 1e-10 after a whole lifecycle, its decisions must be the exact ones, and every branch it took must have had a margin many
+orders of magnitude above that error (the designed exact tie KA7 excepted) -- so that any other correct fp64 evaluation of the
+same formulas, Eigen's included, takes the same branches and lands within 2e-12 of the oracle per operation."""
+import numpy as np
+import pytest
+
+from test_oracle import COMP, PROP, UPD, load_golden, split_update_inputs
+
+PER_OP = 1e-12      # oracle vs exact, one operation on the same fp64 inputs
+MARGIN = 1e-7       # smallest relative branch margin tolerated (the golden generator enforces 1e-6)
+
+
+@pytest.fixture(scope="module")
+def ex():
+    from oracle import ekf_exact
+    return ekf_exact
+
+
+def test_every_golden_operation_against_50_digit_arithmetic(oc, ex):
+    from mpmath import mpf
+    worst = dict(x=0.0, P=0.0, mahal=0.0)
+    smallest = dict(cond=np.inf, gate=np.inf, argmin=np.inf)
+    n_ops = n_meas = 0
+    for s in load_golden():
+        x, P = s["x0"].copy(), s["P0"].copy()
+        for k, op in enumerate(s["ops"]):
+            kind = int(op["kind"])
+            xm, Pm = ex.M(x), ex.M(P)          # the oracle's fp64 state in front of the operation, exactly
+            if kind == PROP:
+                v, w, dt = op["inp"][0:3]
+                Q = np.array([[op["inp"][3], op["inp"][5]], [op["inp"][4], op["inp"][6]]])
+                x, P = oc.propagate(x, P, v, w, Q, dt)
+                xe, Pe = ex.propagate(xm, Pm, mpf(float(v)), mpf(float(w)), ex.M(Q), mpf(float(dt)))
+            elif kind == UPD:
+                z, R = split_update_inputs(op["inp"])
+                x, P, dec, mat, mah = oc.update(x, P, z, R)
+                xe, Pe, dece, mate, mahe, margins = ex.update(xm, Pm, ex.M(z), ex.M(R))
+                tie = "KA7" in s["name"]
+                assert dec == dece and mat == mate, (s["name"], k, dec, dece, mat, mate)
+                for j, mg in enumerate(margins):
+                    n_meas += 1
+                    if mate[j] != 0:
+                        # (relative, with a floor of 1e-3: KA3 re-observes a landmark with a residual of rounding size, d = 4e-29 -- what matters
+                        # is the distance from the gates at 10 and 50)
+                        worst["mahal"] = max(worst["mahal"], abs(float(mahe[j]) - mah[j]) / max(abs(float(mahe[j])), 1e-3))
+                    for key in smallest:
+                        val = float(mg[key])
+                        if key == "argmin" and tie:
+                            continue  # two landmarks at exactly the same distance, by design: the first index wins in every evaluation
+                        smallest[key] = min(smallest[key], val)
+                        assert val > MARGIN, (s["name"], k, j, key, val)
+            else:
+                zc, Rc = op["inp"][0], op["inp"][1]
+                x, P = oc.compass(x, P, zc, Rc)
+                xe, Pe = ex.compass(xm, Pm, mpf(float(zc)), mpf(float(Rc)))
+            ex_, eP = ex.rel_err(x, xe), ex.rel_err(P, Pe)
+            worst["x"], worst["P"] = max(worst["x"], ex_), max(worst["P"], eP)
+            assert ex_ <= PER_OP and eP <= PER_OP, (s["name"], k, ex_, eP)
+            n_ops += 1
+    print("oracle vs 50-digit arithmetic over %d golden operations (%d measurements): max rel. error x %.2e, P %.2e, Mahalanobis distance %.2e; "
+          "smallest branch margins: cond %.2e, gates %.2e, arg-min %.2e" % (n_ops, n_meas, worst["x"], worst["P"], worst["mahal"],
+                                                                           smallest["cond"], smallest["gate"], smallest["argmin"]))
+    assert n_ops > 400 and worst["mahal"] <= 1e-11
+
+
+def test_lifecycle_trajectory_against_50_digit_arithmetic(pkg, oc, ex):
+    """The ACCUMULATED difference: a config-1 style lifecycle from x = 0, P = 0 (New, Old and Ignore decisions, compass updates)
+    run twice on the same inputs -- the fp64 oracle, and 50-digit arithmetic carried through from the first operation to the
+    last, never re-synchronised.  Same decisions and matched indices throughout; the final states agree to 1e-10."""
+    from mpmath import mpf
+    script = pkg.scenarios.lifecycle_script(seed=20260001, n_landmarks=50, steps=400, compass_every=9)
+    x, P = np.zeros(3), np.zeros((3, 3))
+    xe, Pe = ex.M(x), ex.M(P)
+    n_meas, kinds = 0, set()
+    smallest = np.inf
+    for st in script:
+        v, w, dt = st["v"], st["w"], st["dt"]
+        Q = oc.make_Q(v)
+        x, P = oc.propagate(x, P, v, w, Q, dt)
+        xe, Pe = ex.propagate(xe, Pe, mpf(float(v)), mpf(float(w)), ex.M(Q), mpf(float(dt)))
+        if st["compass"] is not None:
+            x, P = oc.compass(x, P, st["compass"], 0.0005)
+            xe, Pe = ex.compass(xe, Pe, mpf(float(st["compass"])), mpf(0.0005))
+        for fx, fy in st["feats_mm"]:
+            z, R = oc.make_measurement(fx, fy)
+            x, P, dec, mat, mah = oc.update(x, P, z.reshape(2, 1), R)
+            xe, Pe, dece, mate, mahe, margins = ex.update(xe, Pe, ex.M(z.reshape(2, 1)), ex.M(R))
+            assert dec == dece and mat == mate, (n_meas, dec, dece, mat, mate)
+            smallest = min(smallest, *(float(margins[0][k]) for k in ("cond", "gate", "argmin")))
+            kinds.add(dec[0])
+            n_meas += 1
+    assert kinds >= {oc.NEW, oc.OLD} and n_meas > 1000 and x.size > 3 + 2 * 8
+    ex_, eP = ex.rel_err(x, xe), ex.rel_err(P, Pe)
+    print("lifecycle of %d measurements (%d landmarks): fp64 oracle vs 50 digits carried through: x %.2e, P %.2e; smallest branch margin %.2e"
+          % (n_meas, (x.size - 3) // 2, ex_, eP, smallest))
+    assert ex_ <= 1e-10 and eP <= 1e-10
+    assert smallest > 1e-6
