@@ -458,7 +458,11 @@ static int create_impl(ekf_batch *h, int batch, int capacity_landmarks, int devi
     HIP_TRY(dev_alloc_zero(&dv.pass_flag, 1, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.seg_count, EKF_PLAN_MAX, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.bar, B * 2, &h->device_bytes, s));
+#ifdef EKF_CHAIN_STAMPS
+    HIP_TRY(dev_alloc_zero(&dv.dbg, 32 + 65 * 2048, &h->device_bytes, s));  // + publish times of every workgroup, 2048 exchanges (scripts/r04_skew.py)
+#else
     HIP_TRY(dev_alloc_zero(&dv.dbg, 32, &h->device_bytes, s));
+#endif
     HIP_TRY(dev_alloc_zero(&dv.part, B * 2 * dv.gmax * EKF_REC_DOUBLES, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.log, B * dv.logcap, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.log_count, B, &h->device_bytes, s));
@@ -1771,6 +1775,18 @@ extern "C" int ekf_debug_stamps(ekf_handle h, long long *out16, int reset) {
     if (reset) HIP_TRY(hipMemset(h->dv.dbg, 0, 32 * sizeof(long long)));
     return EKF_OK;
 }
+
+#ifdef EKF_CHAIN_STAMPS
+// Diagnostic: wall-clock ticks (100 MHz) at which every workgroup of filter 0 published its head in each of the first 2048
+// exchanges of the handle, row 64 = the moment workgroup 0's poll saw all of them.  out: [65][2048].
+extern "C" int ekf_debug_exchange_trace(ekf_handle h, long long *out) {
+    if (!h || !out) return EKF_ERR_BAD_ARG;
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(stream_wait(h->s_chain));
+    HIP_TRY(hipMemcpy(out, h->dv.dbg + 32, (size_t)65 * 2048 * sizeof(long long), hipMemcpyDeviceToHost));
+    return EKF_OK;
+}
+#endif
 
 // ---- timing ---------------------------------------------------------------------------------------
 extern "C" int ekf_timer_start(ekf_handle h) {

@@ -75,7 +75,7 @@ __device__ __forceinline__ void argmin_dpp_step(double &d, int &i, int &who) {
     who = take ? ow : who;
 }
 
-__device__ __forceinline__ void wave_argmin(double &d, int &i, int &who) {
+__device__ __forceinline__ void wave_argmin_full(double &d, int &i, int &who) {
     argmin_dpp_step<0x111, 0xf>(d, i, who);  // row_shr:1
     argmin_dpp_step<0x112, 0xf>(d, i, who);  // row_shr:2
     argmin_dpp_step<0x114, 0xf>(d, i, who);  // row_shr:4
@@ -85,6 +85,39 @@ __device__ __forceinline__ void wave_argmin(double &d, int &i, int &who) {
     d = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(d), 63), __builtin_amdgcn_readlane(__double2loint(d), 63));
     i = __builtin_amdgcn_readlane(i, 63);
     who = __builtin_amdgcn_readlane(who, 63);
+}
+
+// The same result in a third of the instructions (round 4): the MINIMUM of the distances alone travels through the DPP steps (two
+// moves and one v_min_f64 per step instead of four moves, two compares and four selects; no candidate is NaN -- the sweep never
+// accepts one, Update.cpp:140 -- so min(a, b) is the smaller one), then a ballot finds the lanes that hold it.  One such lane is
+// the rule: its (d, i, lane) are read with readlane.  Several (an exact tie, or no candidate at all: every lane holds
+// {EKF_INF, 0x7fffffff}) fall back to the full reduction, which keeps the lower index.  All 64 lanes must be active.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double min_dpp_step(double m) {
+    const int ml = __double2loint(m), mh = __double2hiint(m);
+    const int ol = __builtin_amdgcn_update_dpp(ml, ml, CTRL, ROW_MASK, 0xf, false);
+    const int oh = __builtin_amdgcn_update_dpp(mh, mh, CTRL, ROW_MASK, 0xf, false);
+    const double o = __hiloint2double(oh, ol);
+    return o < m ? o : m;  // (lanes the step does not write keep their own value in both halves: o == m there)
+}
+__device__ __forceinline__ void wave_argmin(double &d, int &i, int &who) {
+    double m = d;
+    m = min_dpp_step<0x111, 0xf>(m);
+    m = min_dpp_step<0x112, 0xf>(m);
+    m = min_dpp_step<0x114, 0xf>(m);
+    m = min_dpp_step<0x118, 0xf>(m);
+    m = min_dpp_step<0x142, 0xa>(m);
+    m = min_dpp_step<0x143, 0xc>(m);
+    m = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(m), 63), __builtin_amdgcn_readlane(__double2loint(m), 63));
+    const unsigned long long holders = __ballot(d == m);
+    if (__popcll(holders) == 1) {  // (wave-uniform)
+        const int l = __builtin_ctzll(holders);
+        d = m;
+        i = __builtin_amdgcn_readlane(i, l);
+        who = __builtin_amdgcn_readlane(who, l);
+        return;
+    }
+    wave_argmin_full(d, i, who);
 }
 
 struct ChainLds {
@@ -917,6 +950,13 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                 auto put = [=](unsigned long long *at, double v) {  // a double = two granules, written by one 16-byte store (each half validates itself)
                     st_sc1_b128(at, (uint4_t){(unsigned)__double2loint(v), (unsigned)(tag >> 32), (unsigned)__double2hiint(v), (unsigned)(tag >> 32)});
                 };
+#ifdef EKF_CHAIN_STAMPS
+                if (tid == 0 && b == 0 && ebase + epoch < 2048) {
+                    unsigned long long now_;
+                    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");
+                    dv.dbg[32 + (size_t)g * 2048 + (ebase + epoch)] = (long long)now_;
+                }
+#endif
                 if (tid == 0) {
                     put(rec + 2 * EKF_REC_HEAD, gd);
                     __hip_atomic_store(rec + 2 * EKF_REC_HEAD + 2, tag | (unsigned)gi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -951,6 +991,13 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                         }
                         __builtin_amdgcn_s_sleep(1);
                     }
+#ifdef EKF_CHAIN_STAMPS
+                    if (lane == 0 && b == 0 && lead && ebase + epoch < 2048) {
+                        unsigned long long now_;
+                        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");
+                        dv.dbg[32 + (size_t)64 * 2048 + (ebase + epoch)] = (long long)now_;
+                    }
+#endif
                     double d = EKF_INF;
                     int i = 0x7fffffff;
                     src = lane;
@@ -979,7 +1026,8 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
             const int on = (hdr == HDR_NEW || hdr == HDR_OLD) ? 1 : 0;
             const int n_lm_after = n_lm_before + (hdr == HDR_NEW ? 1 : 0);
             if (ctrl) {
-                // bookkeeping common to all branches
+                // bookkeeping common to all branches (round 4: moved behind the branch's own work it leaves workgroup 0's stage 0.3 us earlier
+                // -- and the read of the winner's record 0.3 us longer: the record is not there sooner.  No gain, left where it was)
                 if (lead) {
                     ekf_stats *st = &L.st;  // written back at the end of the launch
                     if (hdr == HDR_OLD) {
