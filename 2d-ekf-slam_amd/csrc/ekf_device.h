@@ -66,7 +66,9 @@ struct EkfMirror {
 
 // One k_chain launch runs a list of segments; a segment is what used to be a launch of its own: a run of operations inside one
 // slot set.  Several segments per launch keep the workgroups (their LDS caches, their registers) alive across window boundaries.
+#ifndef EKF_PLAN_MAX
 #define EKF_PLAN_MAX 12
+#endif
 struct ChainSeg {
     int k0, nops;        // operations [k0, k0 + nops) of the input
     int slot0;           // slots of the open set filled before this segment

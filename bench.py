@@ -245,13 +245,23 @@ def measure(pkg, mc, torch, dist, coll_device, rank, world, dev_id, workload, K,
     if latency:
         # per-step latency: one scripted step per call, host clock from the call to the moment the pose of
         # that step is readable (kernel launch + completion, no state copy); the window's dense pass falls on every fourth step
-        ts = []
-        for s_ in range(W + K, W + K + extra):
-            t0 = time.perf_counter()
-            f.script_run(s_, 1)
-            f.poses()
-            ts.append((time.perf_counter() - t0) * 1e6)
-        raw = np.array(ts)
+        # (the interpreter's cyclic garbage collector is off inside the loop and the samples go into a preallocated array: a one-off
+        # pause of 0.65-1.1 ms at a fixed iteration count of this very loop -- whatever the GPU was doing, DESIGN.md section 5 -- was the
+        # harness, not the library)
+        import gc
+        raw = np.empty(extra)
+        gc.collect()
+        gc_was_on = gc.isenabled()
+        gc.disable()
+        try:
+            for q_, s_ in enumerate(range(W + K, W + K + extra)):
+                t0 = time.perf_counter()
+                f.script_run(s_, 1)
+                f.poses()
+                raw[q_] = (time.perf_counter() - t0) * 1e6
+        finally:
+            if gc_was_on:
+                gc.enable()
         ts = np.sort(raw[8:])
         lat = {"unit": "us per step (1 Propagate + %d Updates, one call per step, pose read back)" % M, "samples": int(ts.size),
                "p10": float(np.percentile(ts, 10)), "p50": float(np.percentile(ts, 50)), "p90": float(np.percentile(ts, 90)),
