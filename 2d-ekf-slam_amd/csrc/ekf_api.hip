@@ -411,6 +411,10 @@ static int create_impl(ekf_batch *h, int batch, int capacity_landmarks, int devi
     int workers = (dv.lpw + 63) / 64 * 64;
     if (workers > max_workers) workers = max_workers;
     if (dv.lpw > 64 && dv.lpw <= 128) workers = 192;  // two owner waves and a third that shares their fold (k_chain: helper_on)
+    // one owner wave and two that take a third of its fold each (round 4: N = 768 / 12 workgroups 39.2 k -> 40.5 k steps/s, N = 1024 / 16:
+    // 38.0 k -> 39.5 k; with 32 workgroups -- N = 2048 -- the two extra waves at every barrier cost more than the shorter fold gives:
+    // 37.0 k -> 35.8 k, so only up to 16 workgroups)
+    if (dv.lpw <= 64 && G > 1 && G <= 16) workers = 192;
     h->chain_threads = 64 + workers;  // wave 0 is the control wave
     if (h->solo_kernel) h->chain_threads = (capacity_landmarks + 63) / 64 * 64;  // k_solo: one landmark per thread, no control wave
     {

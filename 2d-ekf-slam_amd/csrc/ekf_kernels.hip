@@ -151,7 +151,7 @@ struct ChainLds {
     alignas(16) double loM[2 * EKF_MAX_PENDING * 4];
     // the helper wave's share of the fold: component-major partial sums for up to 128 landmarks, and the number of the fold they belong to
     double hp[4 * 128];
-    int hflag;
+    int hflag, hflag2;  // (hflag2: the second helper wave of a workgroup of at most 64 landmarks)
 };
 
 // Header of the Old branch (Update.cpp:181-189): a pure function of the heading the sweep ran with and of the
@@ -462,7 +462,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
     typedef __attribute__((address_space(4))) const ChainSeg *SegPtr;
     const SegPtr segs = (SegPtr)((__attribute__((address_space(4))) const char *)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(ChainKArgs, plan) + offsetof(ChainPlan, s));
     const long long last_seq = segs[nseg - 1].seq;
-    if (tid == 0) L.abort = 0, L.hflag = -1;
+    if (tid == 0) L.abort = 0, L.hflag = -1, L.hflag2 = -1;
     int fold_no = 0;  // Old measurements whose fold the helper wave shared (wave-uniform, kept by every thread)
     // Launches without a measurement (Propagate, compass, truth samples) have no exchange, hence nothing that keeps the filter's
     // workgroups in step: workgroup 0 could finish the whole launch and write the new robot state, landmark count and counters
@@ -1135,12 +1135,26 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                 // The fold is bound by FMA issue of the one wave a SIMD holds (8 clocks each, 8 per slot).  With 128 landmarks on two
                 // worker waves the third worker wave is idle: it takes the last third of the slots for both (64 landmarks each),
                 // leaves its partial sums in LDS and raises a flag; the owners fold the first two thirds and add.
-                const bool helper_on = uni((bd == 256 && lpw_ > 64 && lpw_ <= 128 && nvs >= 6) ? 1 : 0) != 0;
-                const int n_help = helper_on ? nvs / 3 : 0, n_own = nvs - n_help;
+                // ... and where a workgroup's landmarks fit ONE worker wave (at most 64: the shape of every map up to 2048 landmarks since round 4)
+                // two helper waves take a third of the slots each for the same 64 landmarks (helpers == 2): the owner folds a third itself
+                const int helpers = uni((bd == 256 && nvs >= 6) ? (lpw_ <= 64 ? 2 : (lpw_ <= 128 ? 1 : 0)) : 0);
+                const bool helper_on = helpers != 0;
+                const int n_help = helper_on ? nvs / 3 : 0, n_own = nvs - helpers * n_help;
                 if (helper_on) fold_no++;
                 if (worker) {
                     const OldHdr h = old_header(RS.c, RS.s, L.w);
-                    if (helper_on && (wtid >> 6) == 2) {
+                    if (helpers == 2 && (wtid >> 6) >= 1) {
+                        // helper wave w (1, 2): slots [n_own + (w - 1) n_help, + n_help) of landmarks 0..63; partial sums in its own half of hp
+                        const int w = wtid >> 6, ll = wtid & 63, first = n_own + (w - 1) * n_help;
+                        double q00 = 0, q01 = 0, q10 = 0, q11 = 0;
+                        unsigned a0 = lds_off(own_rows + own_at(first, 0, ll)), am = lds_off(L.loM + first * 4);
+                        int n = n_help;
+                        asm volatile(FOLD_ASM : [p00] "+v"(q00), [p01] "+v"(q01), [p10] "+v"(q10), [p11] "+v"(q11), [a0] "+v"(a0), [am] "+v"(am), [n] "+s"(n) : : FOLD_CLOBBERS);
+                        const int at = (w - 1) * 64 + ll;
+                        L.hp[at] = q00, L.hp[128 + at] = q01, L.hp[256 + at] = q10, L.hp[384 + at] = q11;
+                        __hip_atomic_store(w == 1 ? &L.hflag : &L.hflag2, fold_no, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                    if (helpers == 1 && (wtid >> 6) == 2) {
                         for (int half = 0; half < 2; half++) {
                             const int ll = half * 64 + (wtid & 63);
                             double q00 = 0, q01 = 0, q10 = 0, q11 = 0;
@@ -1199,6 +1213,11 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                                 }
                                 const int ll = lm - own_lo;
                                 p[0][0] += L.hp[ll], p[0][1] += L.hp[128 + ll], p[1][0] += L.hp[256 + ll], p[1][1] += L.hp[384 + ll];
+                                if (helpers == 2) {  // (the second helper's sums lie 64 entries further on)
+                                    while (__hip_atomic_load(&L.hflag2, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != fold_no) {
+                                    }
+                                    p[0][0] += L.hp[64 + ll], p[0][1] += L.hp[192 + ll], p[1][0] += L.hp[320 + ll], p[1][1] += L.hp[448 + ll];
+                                }
                             }
                         }
                         apply_old(lm, st, p, slot, h, RS.Prr, L.w);
