@@ -9,14 +9,20 @@ tag = sys.argv[2]
 args = sys.argv[3] if len(sys.argv) > 3 else ""
 dst = "profiles"
 os.makedirs(dst, exist_ok=True)
-ks = glob.glob(os.path.join(src, "trace/*/*_kernel_stats.csv"))[0]
+def newest(pattern):
+    """gpurun MERGES a call's output into gpurun_out/: a re-run leaves the older files (other process ids in their names) beside the new ones."""
+    fs = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return fs[-1:] if fs else []
+
+
+ks = newest(os.path.join(src, "trace/*/*_kernel_stats.csv"))[0]
 shutil.copy(ks, os.path.join(dst, tag + "_kernel_stats.csv"))
 summary = {"command": "rocprofv3 --kernel-trace --stats | --pmc FETCH_SIZE | --pmc WRITE_SIZE | --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE  -- python3 bench.py %s   (scripts/profile_r0x.sh; EKF_OVERLAP=%s)" % (args, os.environ.get("EKF_OVERLAP", "unset")),
            "kernels": {}, "bench_lines": {}}
 for row in csv.DictReader(open(ks)):
     summary["kernels"][row["Name"].split("(")[0]] = {"calls": int(row["Calls"]), "avg_us": float(row["AverageNs"]) / 1e3, "pct": float(row["Percentage"])}
 for name in ("pmc_fetch", "pmc_write", "pmc_mfma"):
-    fs = glob.glob(os.path.join(src, name, "*/*_counter_collection.csv"))
+    fs = newest(os.path.join(src, name, "*/*_counter_collection.csv"))
     if not fs:
         continue
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
