@@ -573,7 +573,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
         st.dxx -= sym_u(Tt[0][0], Tt[0][1], K[0][0], K[0][1], Tt[0][0], Tt[0][1], K[0][0], K[0][1]);
         st.dxy -= sym_u(Tt[0][0], Tt[0][1], K[0][0], K[0][1], Tt[1][0], Tt[1][1], K[1][0], K[1][1]);
         st.dyy -= sym_u(Tt[1][0], Tt[1][1], K[1][0], K[1][1], Tt[1][0], Tt[1][1], K[1][0], K[1][1]);
-        lm_store(lm, st);
+        if (lm != lm0) lm_store(lm, st);  // (the register-resident landmark goes back to memory once, at the end of the launch)
         // slot: P_LL -= T K^T (rank 2; K S K^T is symmetric, only one triangle is stored).  A = -T, B = K.
         write_slot(lm, slot, -Tt[0][0], -Tt[0][1], -Tt[1][0], -Tt[1][1], K[0][0], K[0][1], K[1][0], K[1][1], false);
     };
@@ -592,7 +592,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
         st.dxx -= sym_u(Tt[0], 0, K[0], 0, Tt[0], 0, K[0], 0);
         st.dxy -= sym_u(Tt[0], 0, K[0], 0, Tt[1], 0, K[1], 0);
         st.dyy -= sym_u(Tt[1], 0, K[1], 0, Tt[1], 0, K[1], 0);
-        lm_store(lm, st);
+        if (lm != lm0) lm_store(lm, st);
         write_slot(lm, slot, -Tt[0], -0.0, -Tt[1], -0.0, K[0], 0, K[1], 0, false);
     };
     // New branch, an existing landmark lm < ln: its slot rows carry the new covariance column pair
@@ -615,7 +615,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
         st.x0 = L.newx[0], st.x1 = L.newx[1];
         for (int i = 0; i < 6; i++) st.rc[i] = L.newrc[i];
         st.dxx = L.newdd[0], st.dxy = L.newdd[1], st.dyy = L.newdd[2];
-        lm_store(lm, st);
+        if (lm != lm0) lm_store(lm, st);
         for (int sl = 0; sl < n_prev + slot; sl++)  // the landmark did not exist in the earlier slots of the open windows
             for (int cmp = 0; cmp < 4; cmp++) own_rows[own_at(sl, cmp, lm - own_lo)] = 0.0;
         write_slot(lm, slot, 0, 0, 0, 0, 1, 0, 0, 1, true);  // (its own P_xL rows are zero: the 2x2 block lives in D)
@@ -708,6 +708,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
     }
     __syncthreads();
     if (seg > 0 && L.abort) {
+        if (worker && lm0 < own_hi && lm0 < uni(L.rs[cur].n_lm)) lm_store(lm0, r0);  // (what the earlier segments of this launch did to it)
         give_up();
         return;
     }
@@ -857,11 +858,9 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                 const int n_now = uni(RS.n_lm);
                 const int hi = own_hi < n_now ? own_hi : n_now;
                 if (lm0 < hi) {
-                    for (int e = 0; e < 2; e++) {
+                    for (int e = 0; e < 2; e++) {  // (registers only: stored with the rest of the landmark at the end of the launch)
                         r0.rc[e] = r0.rc[e] + pa * r0.rc[4 + e];
                         r0.rc[2 + e] = r0.rc[2 + e] + pb * r0.rc[4 + e];
-                        R0[3 + 2 * lm0 + e] = r0.rc[e];
-                        R0[(size_t)xs + 3 + 2 * lm0 + e] = r0.rc[2 + e];
                     }
                 }
                 for (int lm = lm0 + nw; lm < hi; lm += nw)
@@ -1437,6 +1436,11 @@ finish:  // (also the way out when a bounded wait ran out: the sticky status say
         // (a workgroup can only get here after every workgroup of the filter has read ebase: it took part in each exchange)
         if (lead && epoch > 0) bar[0] = ebase + epoch;
     }
+    // The register-resident landmark (x, its columns of the robot rows, its 2x2 block) has lived in registers since the launch began:
+    // nobody else reads it meanwhile (other workgroups sweep their own landmarks; the dense pass reads slots and tiles; the host reads
+    // x / R / D only behind a synchronise), so it goes back to memory ONCE, with the last segment -- eleven scattered stores and their
+    // address arithmetic less in every measurement (round 4; k_solo has always done this).
+    if ((seg + 1 == nseg || L.abort) && worker && lm0 < own_hi && lm0 < uni(L.rs[cur].n_lm)) lm_store(lm0, r0);
     if (plan.signal) {
         // End of a segment of a multi-segment launch.  What a kernel boundary used to do: this workgroup's stores (slot rows,
         // slot_active, n_lm_flush) complete and written back, then one count.  The count reaching "every workgroup, this
