@@ -186,12 +186,19 @@ def kernel_source_digest():
     """sha256 (first 16 hex digits) over the device sources of the library: profiles/traffic_*.json carry the digest of the sources
     their counter passes ran on (scripts/summarize_profile.py), and a replayed number must come from the same ones."""
     import hashlib
+    import re
     h = hashlib.sha256()
     d = os.path.join(ROOT, "2d-ekf-slam_amd", "csrc")
     for name in sorted(os.listdir(d)):
         if name.endswith((".hip", ".h")) or name == "Makefile":
+            text = open(os.path.join(d, name), "r", errors="replace").read()
+            if name != "Makefile":
+                # the CODE: comments and layout do not change the binary (a reworded comment must not make a counter pass look stale)
+                text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+                text = re.sub(r"//[^\n]*", " ", text)
+            text = " ".join(text.split())
             h.update(name.encode())
-            h.update(open(os.path.join(d, name), "rb").read())
+            h.update(text.encode())
     return h.hexdigest()[:16]
 
 
