@@ -132,3 +132,35 @@ def test_gpu_lifecycle_against_50_digit_arithmetic(pkg, oc, ex):
     print("GPU vs 50 digits carried through %d measurements (%d landmarks): x %.2e, P %.2e" % (n_meas, (xg.size - 3) // 2, e_x, e_P))
     assert n_meas > 400 and e_x <= 1e-10 and e_P <= 1e-10
     kf._f.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kernel", ["k_solo", "k_chain"])
+def test_gpu_dense_state_against_50_digit_arithmetic(pkg, oc, ex, monkeypatch, kernel):
+    """The same comparison on a dense injected state (N = 160, every entry of P non-zero): two steps of one Propagate and four Old
+    updates, the window left open in between so that the second step's gains are built from folded slots; on the one-workgroup
+    kernel and on the chain kernel with its cross-workgroup exchange (three workgroups)."""
+    from mpmath import mpf
+    if kernel == "k_chain":
+        monkeypatch.setenv("EKF_SOLO", "0")
+        monkeypatch.setenv("EKF_CHAIN_WGS", "3")
+    N, M, steps = 160, 4, 2
+    x0, P0 = pkg.scenarios.injected_state(N, seed=31, extent=10.0)
+    sc = pkg.scenarios.steady_script(x0, steps=steps, M=M, seed=32, min_separation=1.0)
+    f = pkg.FilterBatch(1, N, max_pending=16)
+    f.set_state(x0, P0)
+    xe, Pe = ex.M(x0), ex.M(P0)
+    for s in range(steps):
+        v, w, dt = (float(c) for c in sc["ctrl"][s])
+        f.propagate(v, w, dt)
+        xe, Pe = ex.propagate(xe, Pe, mpf(v), mpf(w), ex.M(oc.make_Q(v)), mpf(dt))
+        for m in range(M):
+            z, R = sc["z"][s, m], sc["R"][s, m].reshape(2, 2, order="F")
+            dec = f.update(z.reshape(1, 1, 2), R.reshape(1, 1, 2, 2))[0]
+            xe, Pe, dece, mate, _, _ = ex.update(xe, Pe, ex.M(z.reshape(2, 1)), ex.M(R))
+            assert (dec[0][0], dec[0][1]) == (dece[0], mate[0]) and dece[0] == ex.OLD
+    xg, Pg = f.get_state()
+    e_x, e_P = ex.rel_err(xg, xe), ex.rel_err(Pg, Pe)
+    print("%s, N = %d dense, %d Old updates: GPU vs 50 digits: x %.2e, P %.2e" % (kernel, N, steps * M, e_x, e_P))
+    assert e_x <= 1e-12 and e_P <= 1e-12
+    f.close()
