@@ -1357,6 +1357,16 @@ extern "C" int ekf_num_landmarks(ekf_handle h) {
 extern "C" int ekf_get_robot_cov(ekf_handle h, double P_RR_out[9]) {
     if (!h || h->dv.B != 1 || !P_RR_out) return set_error(EKF_ERR_BAD_ARG, "single-filter call on a batch handle");
     HIP_TRY(hipSetDevice(h->device));
+    // The chain kernels leave the robot block in the host-mapped mirror beside the pose (round 4: a device-to-host copy here cost the
+    // compat shim's doPropagation 15-25 us of every step).  The copy stays for what does not write the mirror last (graph replays).
+    if (h->mirror_by_chain && h->chain_seq > 0) {
+        int rc = refresh_bounds(h, false);  // waits until the newest launch has written the mirror; sticky EKF_ERR_TIMEOUT
+        if (rc == EKF_ERR_TIMEOUT) return rc;
+        if (h->mirror_by_chain) {
+            for (int i = 0; i < 9; i++) P_RR_out[i] = h->mirror_h[0].Prr[i];
+            return EKF_OK;
+        }
+    }
     HIP_TRY(hipMemcpy2DAsync(P_RR_out, 3 * sizeof(double), h->dv.R, (size_t)h->dv.xs * sizeof(double), 3 * sizeof(double), 3,
                              hipMemcpyDeviceToHost, h->s_chain));
     HIP_TRY(stream_wait(h->s_chain));

@@ -61,6 +61,7 @@ struct EkfMirror {
     long long log_count;
     long long seq;  // number of the chain launch that wrote this mirror last (stored last, system scope): the host may spin on it
     ekf_stats stats;  // the filter's counters as of that launch (ekf_get_stats without a device-to-host copy)
+    double Prr[9];    // the robot block P[0:3,0:3], row-major (what kalmanfilter.cpp:51 logs a corner of: ekf_get_robot_cov without a copy)
     ekf_decision last[EKF_MIRROR_DECISIONS];  // entry i of the log lives at last[i % 64]
 };
 

@@ -1421,6 +1421,7 @@ finish:  // (also the way out when a bounded wait ran out: the sticky status say
                 dv.n_lm[b] = R.n_lm;
                 dv.n_lm_sweep[b] = R.n_sweep;
                 for (int i = 0; i < 3; i++) mr->pose[i] = R.pose[i];
+                for (int i = 0; i < 9; i++) mr->Prr[i] = R.Prr[i];
                 mr->n_lm = R.n_lm;
                 dv.stats[b] = L.st;
                 mr->stats = L.st;
@@ -1729,6 +1730,8 @@ __global__ void k_set_meta(EkfDev dv, int b, int n_lm) {
     dv.status[b] = 0;
     EkfMirror *mr = dv.mirror + b;
     for (int i = 0; i < 3; i++) mr->pose[i] = dv.x[(size_t)b * dv.xs + i];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) mr->Prr[i * 3 + j] = dv.R[((size_t)b * 3 + i) * dv.xs + j];
     mr->n_lm = n_lm;
     mr->status = 0;
     mr->log_count = dv.log_count[b];

@@ -663,6 +663,7 @@ __global__ __launch_bounds__(256) void k_solo(EkfDev dv, const double *in, const
                 dv.n_lm[b] = n_lm;
                 dv.n_lm_sweep[b] = n_sweep;
                 for (int i = 0; i < 3; i++) mr->pose[i] = rb.pose[i];
+                for (int i = 0; i < 9; i++) mr->Prr[i] = rb.Prr[i];
                 mr->n_lm = n_lm;
                 dv.stats[b] = L.st;
                 mr->stats = L.st;

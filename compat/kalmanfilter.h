@@ -64,7 +64,7 @@ public:
         double Prr[9];
         check(ekf_get_robot_cov(h, Prr));
         covFile << Prr[0] << " " << Prr[1] << " " << Prr[3] << " " << Prr[4] << std::endl;  // :51
-        if (Num_Landmarks > 0) {  // :53-60, including its stride-1 indexing
+        if (Num_Landmarks > 0 && knownfeaturesFile.good()) {  // :53-60, including its stride-1 indexing (a stream that cannot take the lines is not worth the O(N) copy of x)
             xbuf.resize(3 + 2 * (size_t)Num_Landmarks);
             check(ekf_get_x(h, 0, xbuf.data(), (int)xbuf.size()));
             // (same lines as the reference; one flush per call instead of its std::endl per line)
