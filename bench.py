@@ -297,6 +297,43 @@ def measure(pkg, mc, torch, dist, coll_device, rank, world, dev_id, workload, K,
             "value": B * world * K / elapsed, "roofline": roof, "latency": lat, "report": rep, "seed": seed, "extent": extent, "min_sep": min_sep}
 
 
+def immediate_leg(pkg, dev_id):
+    """The reference's own call pattern (slam.cpp:136-170): one synchronising call per operation -- doPropagation, then doUpdate per
+    feature, the public mirrors current after each -- from the C++ shim (compat/kalmanfilter.h) through the headless replay driver
+    (compat/replay --timing), starting from the injected state of configs 2 and 3.  Host time per 5-call step; never the headline."""
+    import subprocess
+    import tempfile
+    import numpy as np
+    replay = os.path.join(ROOT, "compat", "replay")
+    if not os.path.exists(replay):
+        return {"error": "compat/replay is not built"}
+    out = {"unit": "us per step of 1 doPropagation + 4 doUpdate calls (C++ shim, host clock)", "call_pattern": "slam.cpp:136-170"}
+    for name, N in (("n1024", 1024), ("n4096", 4096)):
+        _, _, _, _, seed, extent, min_sep = WORKLOADS[name]
+        x0, P0 = pkg.scenarios.injected_state(N, seed=seed, extent=extent)
+        sc = pkg.scenarios.steady_script(x0, steps=120, M=4, seed=seed + 7919, min_separation=min_sep)
+        with tempfile.TemporaryDirectory() as td:
+            with open(os.path.join(td, "rec.txt"), "w") as f:
+                for s_ in range(120):
+                    v, w, dt = (float(c) for c in sc["ctrl"][s_])
+                    feats = " ".join("%r %r" % (float(1000.0 * z[0]), float(1000.0 * z[1])) for z in sc["z"][s_])
+                    f.write("%r %r %r nan %d %s\n" % (dt, v * 1000.0, w * 180.0 / 3.141592654, 4, feats))
+            with open(os.path.join(td, "state.bin"), "wb") as f:
+                np.array([x0.size], dtype=np.float64).tofile(f)
+                np.ascontiguousarray(x0).tofile(f)
+                np.ascontiguousarray(P0).tofile(f)
+            del P0
+            p = subprocess.run([replay, os.path.join(td, "rec.txt"), td, str(N), "--state", os.path.join(td, "state.bin"), "--timing"],
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+            if p.returncode != 0 or "timing" not in p.stdout:
+                out[name] = {"error": p.stderr[-300:]}
+                continue
+            t = p.stdout.split("timing")[1].split()
+            med = float(t[3])
+            out[name] = {"median": med, "p90": float(t[5]), "max": float(t[7]), "iterations": int(t[1]), "steps_per_s": 1e6 / med}
+    return out
+
+
 def config1_leg(pkg, dev_id):
     """BASELINE.json config 1 as stated: one robot, N = 50 landmarks, 1000 steps of synthetic odometry + range/bearing
     measurements (seed 20260001) from x = 0_3, P = 0 (kalmanfilter.cpp:4-12): the GPU as one scripted run, the faithful-dense
@@ -528,6 +565,7 @@ def main():
         leg("config3_M1", lambda: summarise(measure(pkg, mc, torch, None, coll_device, 0, 1, dev_id, "n4096", 512, 32, 1, args.max_pending, False, True, alone=False)))
         leg("config3_512_steps", lambda: summarise(measure(pkg, mc, torch, None, coll_device, 0, 1, dev_id, "n4096", 512, 32, M, args.max_pending, False, True, alone=False)))
         leg("config1_n50", lambda: config1_leg(pkg, dev_id))
+        leg("immediate_calls", lambda: immediate_leg(pkg, dev_id))
         print(json.dumps({"secondary": secondary}))
         return
 
