@@ -71,6 +71,7 @@ struct ekf_batch {
     bool mirror_by_chain; // the newest writer of the host mirror is chain launch number chain_seq (else: some other kernel, synchronise)
     int flush_keep;       // pool key of s_flush: CUs kept free for the chain, -1 = unmasked
     bool solo = false;    // one workgroup per filter and one slot set (phase groups are possible)
+    bool solo_long = false;    // ... with a window longer than its own-row cache (k_solo<true>: the first half in accumulation registers)
     bool solo_kernel = false;  // ... run by k_solo (ekf_solo.hip: maps of up to 256 landmarks, one landmark per thread, one barrier per measurement)
     // Phase groups (solo batches): the filters are cut into ngroups ranges, each with a stream of its own on which its chain
     // launches and its dense passes alternate; the groups run out of phase, so that at any moment some groups are in their
@@ -383,7 +384,9 @@ static int create_impl(ekf_batch *h, int batch, int capacity_landmarks, int devi
     // k_solo (ekf_solo.hip): one landmark per thread, no control wave, no exchange, one barrier per measurement.  EKF_SOLO=0
     // keeps k_chain for them (A/B comparisons, tests of k_chain's one-workgroup path).
     const bool want_solo_kernel = !h->overlap && (getenv("EKF_SOLO") ? atoi(getenv("EKF_SOLO")) != 0 : true) && !getenv("EKF_CHAIN_WGS");
-    if (want_solo_kernel && capacity_landmarks <= 256 && ((long)capacity_landmarks + 63) / 64 * 64 * maxp * 32 <= lds_budget) G = 1;
+    // (k_solo runs windows of up to twice what its cache holds -- ekf_solo.hip, SOLO_HALF -- so 16 slots of cache are enough for any window)
+    if (want_solo_kernel && capacity_landmarks <= 256 &&
+        ((long)capacity_landmarks + 63) / 64 * 64 * (maxp > 2 * 16 ? maxp : (maxp > 16 ? 16 : maxp)) * 32 <= lds_budget) G = 1;
     if (getenv("EKF_CHAIN_WGS")) G = atoi(getenv("EKF_CHAIN_WGS")) > 0 ? atoi(getenv("EKF_CHAIN_WGS")) : G;
     if (G > EKF_CHAIN_MAX_WGS) G = EKF_CHAIN_MAX_WGS;
     if (G * batch > 256) G = 256 / batch > 0 ? 256 / batch : 1;
@@ -395,19 +398,31 @@ static int create_impl(ekf_batch *h, int batch, int capacity_landmarks, int devi
     dv.gmax = G;
     dv.lpw = (capacity_landmarks + G - 1) / G;
     const long lpw64 = ((long)dv.lpw + 63) / 64 * 64;  // the own-row cache holds whole chunks of 64 landmarks
+    int cache_slots = maxp * sets_in_lds;  // slots of own rows in LDS
     if (lpw64 * maxp * sets_in_lds * 32 > lds_budget) {
-        maxp = (int)(lds_budget / (lpw64 * sets_in_lds * 32));
-        if (maxp > 1) maxp &= ~1;  // whole slot pairs
+        const bool two_halves = h->solo_kernel && lds_budget / (lpw64 * 32) >= 16 && !(getenv("EKF_SOLO_LONG_WINDOW") && atoi(getenv("EKF_SOLO_LONG_WINDOW")) == 0);
+        if (two_halves) {
+            // k_solo: the window's first 16 slots move into registers when the cache is full (ekf_solo.hip: SOLO_HALF): a window of
+            // up to 32 with 16 slots of cache -- one dense pass per 32 measurements for a map of 256 landmarks
+            if (maxp > 32) maxp = 32;
+            cache_slots = 16;
+        } else {
+            maxp = (int)(lds_budget / (lpw64 * sets_in_lds * 32));
+            if (maxp > 1) maxp &= ~1;  // whole slot pairs
+            cache_slots = maxp * sets_in_lds;
+        }
     }
     if (maxp < 1) return set_error(EKF_ERR_BAD_ARG, "capacity too large for this batch size (one window slot does not fit LDS)");
     h->params.max_pending = maxp;  // the effective window, see ekf_window()
     dv.maxp = maxp;
     dv.maxpairs = (dv.maxp + 1) / 2;
     dv.f_stride = (size_t)(dv.maxpairs + 1) * dv.rows * 4;
-    dv.vs_cap = maxp * sets_in_lds;
-    h->chain_lds = (size_t)lpw64 * maxp * sets_in_lds * 32;
+    dv.vs_cap = cache_slots;
+    h->solo_long = h->solo_kernel && maxp > cache_slots;
+    h->chain_lds = (size_t)lpw64 * cache_slots * 32;
     HIP_TRY(hipFuncSetAttribute((const void *)k_chain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_budget));  // one setting for every handle
-    HIP_TRY(hipFuncSetAttribute((const void *)k_solo, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_budget));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_solo<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_budget));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_solo<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_budget));
     int workers = (dv.lpw + 63) / 64 * 64;
     if (workers > max_workers) workers = max_workers;
     if (dv.lpw > 64 && dv.lpw <= 128) workers = 192;  // two owner waves and a third that shares their fold (k_chain: helper_on)
@@ -419,7 +434,7 @@ static int create_impl(ekf_batch *h, int batch, int capacity_landmarks, int devi
     if (h->solo_kernel) h->chain_threads = (capacity_landmarks + 63) / 64 * 64;  // k_solo: one landmark per thread, no control wave
     {
         int per_cu = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, h->solo_kernel ? (const void *)k_solo : (const void *)k_chain, h->chain_threads, h->chain_lds));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, h->solo_kernel ? (h->solo_long ? (const void *)k_solo<true> : (const void *)k_solo<false>) : (const void *)k_chain, h->chain_threads, h->chain_lds));
         if (per_cu < 1) return set_error(EKF_ERR_STATE, "the chain kernel does not fit a CU with this capacity / window");
         // (one-workgroup filters wait for nobody: they need no co-residency and claim nothing)
         const int need = h->solo ? 0 : (G * h->chain_filters + per_cu - 1) / per_cu;
@@ -927,7 +942,8 @@ static int launch_ops(ekf_batch *h, const double *in, const int *cursor, int k0,
             const int nb = h->dv.B - b0 < h->chain_filters ? h->dv.B - b0 : h->chain_filters;
             const bool last = b0 + nb >= h->dv.B;
             if (solo)
-                hipExtLaunchKernelGGL(k_solo, dim3(1, nb), dim3(h->chain_threads), h->chain_lds, h->s_chain, nullptr, last ? stop_ev : nullptr, 0, h->dv, in, cursor, plan, b0);
+                if (h->solo_long) hipExtLaunchKernelGGL(k_solo<true>, dim3(1, nb), dim3(h->chain_threads), h->chain_lds, h->s_chain, nullptr, last ? stop_ev : nullptr, 0, h->dv, in, cursor, plan, b0);
+                else hipExtLaunchKernelGGL(k_solo<false>, dim3(1, nb), dim3(h->chain_threads), h->chain_lds, h->s_chain, nullptr, last ? stop_ev : nullptr, 0, h->dv, in, cursor, plan, b0);
             else
                 hipExtLaunchKernelGGL(k_chain, dim3(h->chain_wgs, nb), dim3(h->chain_threads), h->chain_lds, h->s_chain, nullptr, last ? stop_ev : nullptr, 0, h->dv, in,
                                       cursor, plan, b0);
@@ -1061,7 +1077,8 @@ static int launch_ops_grouped(ekf_batch *h, const double *in, int k0, const unsi
         for (int g = 0; g < ng; g++) {
             const int b0 = g * per, nb = B - b0 < per ? B - b0 : per;
             if (nb <= 0) break;
-            if (h->solo_kernel) hipLaunchKernelGGL(k_solo, dim3(1, nb), dim3(h->chain_threads), h->chain_lds, h->s_grp[g], h->dv, in, (const int *)nullptr, plan, b0);
+            if (h->solo_kernel && h->solo_long) hipLaunchKernelGGL(k_solo<true>, dim3(1, nb), dim3(h->chain_threads), h->chain_lds, h->s_grp[g], h->dv, in, (const int *)nullptr, plan, b0);
+            else if (h->solo_kernel) hipLaunchKernelGGL(k_solo<false>, dim3(1, nb), dim3(h->chain_threads), h->chain_lds, h->s_grp[g], h->dv, in, (const int *)nullptr, plan, b0);
             else hipLaunchKernelGGL(k_chain, dim3(1, nb), dim3(h->chain_threads), h->chain_lds, h->s_grp[g], h->dv, in, (const int *)nullptr, plan, b0);
             if (!do_pass) continue;
             hipEvent_t e0 = nullptr, e1 = nullptr;

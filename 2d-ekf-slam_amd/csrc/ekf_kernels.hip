@@ -1566,6 +1566,64 @@ __device__ __forceinline__ void flush_tile_rb(const double *tp, double *tq, cons
         }
 }
 
+// Nine to sixteen live slot pairs (windows of 17 to 32: k_solo's long windows): the whole tile is the accumulator (16 chains, 128
+// registers) and the pairs go over it in four sweeps of four, every operand of a sweep requested before its first MFMA, so that the
+// tile still crosses HBM once per pass.  (The rolling three-row-block form above has no room for sixteen pairs of B operands at two
+// waves per SIMD.)  Batch of 256 x N = 256, per pass: 137 us -- 103 us for eight pairs; the operands, which a batch re-reads from HBM,
+// are 134 MB instead of 67 MB beside 553 MB of tiles, and 256 MFMAs per tile are 61 us of every SIMD's matrix pipe, which one wave per
+// tile at two waves per SIMD overlaps with the tile traffic only in part.  Tried instead: the slot-major walk at the end of the kernel
+// (two pairs at a time behind each other's MFMAs) 165 us; sweeps of eight pairs, which spill to scratch; a workgroup per tile with a
+// row-block per wave and the B operands shared through LDS (four to five waves per SIMD) 155 us,
+// scripts/dropped/r04_dense_pass_workgroup_per_tile.patch.
+template <bool DIAG>
+__device__ __forceinline__ void flush_tile_whole(const double *tp, double *tq, const double *FA, const double *FB, unsigned lo, unsigned live, int zero_slot, size_t slot_stride) {
+    double4_t acc[16];
+#pragma unroll
+    for (int ch = 0; ch < 16; ch++) {
+        if (DIAG && (ch & 3) < (ch >> 2)) continue;
+        double2_t l2 = TILE_LD(tp + ch * 256);
+        double2_t h2 = TILE_LD(tp + ch * 256 + 128);
+        acc[ch] = (double4_t){l2.x, l2.y, h2.x, h2.y};
+    }
+    // (sweeps of four pairs: eight pairs of B operands beside the whole tile spilled to scratch under the basic allocator at two waves
+    // per SIMD; the operand loads are the same either way, and the other wave of the SIMD covers a row-block's wait for its A operands)
+#pragma unroll
+    for (int sweep = 0; sweep < 4; sweep++) {
+        size_t mo[4];
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            int m = live ? __builtin_ctz(live) : zero_slot;
+            live &= live - 1;
+            mo[p] = (size_t)m * slot_stride;
+        }
+        // every operand of the sweep is requested before the first MFMA: one exposed trip to L2 per sweep instead of five
+        double bq[4][4], a[4][4];
+#pragma unroll
+        for (int p = 0; p < 4; p++)
+#pragma unroll
+            for (int cc = 0; cc < 4; cc++) bq[p][cc] = (FB + mo[p] + cc * 64)[lo];
+#pragma unroll
+        for (int rc = 0; rc < 4; rc++)
+#pragma unroll
+            for (int p = 0; p < 4; p++) a[rc][p] = (FA + mo[p] + rc * 64)[lo];
+#pragma unroll
+        for (int rc = 0; rc < 4; rc++)
+#pragma unroll
+            for (int p = 0; p < 4; p++)
+#pragma unroll
+                for (int cc = 0; cc < 4; cc++) {
+                    if (DIAG && cc < rc) continue;
+                    acc[rc * 4 + cc] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[rc][p], bq[p][cc], acc[rc * 4 + cc], 0, 0, 0);
+                }
+    }
+#pragma unroll
+    for (int ch = 0; ch < 16; ch++) {
+        if (DIAG && (ch & 3) < (ch >> 2)) continue;
+        TILE_ST(tq + ch * 256, ((double2_t){acc[ch].x, acc[ch].y}));
+        TILE_ST(tq + ch * 256 + 128, ((double2_t){acc[ch].z, acc[ch].w}));
+    }
+}
+
 // Row-block form: the contraction runs row-block by row-block (16 rows x 64 columns = 4 chains) over ALL live
 // slot pairs, so that a row-block is stored as soon as it is finished: the stores of row-block r overlap the
 // MFMAs of r+1 instead of waiting behind the whole tile's contraction.  The B operands of up to 8 pairs stay in
@@ -1641,7 +1699,12 @@ __global__ __launch_bounds__(256, 2) void k_flush_rb(EkfDev dv, int nT_hi, int s
         else flush_tile_rb<8, false>(tp, tq, FA, FB, lo, live, zero_slot, slot_stride);
         return;
     }
-    // windows above 16: slot-major walk (whole tile loaded, all pairs, then stored), two pairs per iteration
+    if (npl <= 16) {  // windows of 17 to 32
+        if (uni(I) == uni(J)) flush_tile_whole<true>(tp, tq, FA, FB, lo, live, zero_slot, slot_stride);
+        else flush_tile_whole<false>(tp, tq, FA, FB, lo, live, zero_slot, slot_stride);
+        return;
+    }
+    // more than sixteen pairs (does not occur: EKF_MAX_PENDING = 32): slot-major walk (whole tile loaded, all pairs, then stored), two pairs per iteration
     double4_t acc[16];
 #pragma unroll
     for (int ch = 0; ch < 16; ch++) {

@@ -18,6 +18,16 @@
 // Everything else -- slots, the own-row cache, the hand-scheduled fold, the fragment-major P_LL reads -- is k_chain's.
 #include "ekf_device.h"
 
+// Windows of up to twice what the own-row cache holds.  A map of 256 landmarks fits 16 slots of its window into LDS (131 KB), and
+// every window costs one dense pass over P_LL -- the dominant cost of a batch.  When the window is longer than the cache (C slots),
+// it runs in two halves: once the first C slots are filled, every thread moves ITS landmark's rows of them into registers (the
+// register allocator parks such long-lived values in AGPRs; all indexing is static) and the cache starts again at the next slot.
+// From then on the fold adds the first half from registers, and the one thing another thread ever needs of them -- the matched
+// landmark's rows, for the slot matrices M -- travels like the winner record: the wave's winner lane leaves them in LDS before the
+// measurement's one barrier.  One dense pass per 32 measurements instead of 16.
+#define SOLO_HALF 16
+#include "solo_agpr.h"
+
 struct SoloLds {
     ekf_stats st;
     long long log_count;
@@ -28,9 +38,10 @@ struct SoloLds {
     int wi[2][4];
     double wcand[2][4][16];
     SlotMeta sm[EKF_MAX_PENDING];
-    // per wave: the matched landmark's cached rows of every open slot and the slot's 2x2 matrix M (k_chain: loC / loM)
-    alignas(16) double loC[4][EKF_MAX_PENDING * 4];
+    // per wave: the 2x2 matrix M of every open slot for the matched landmark (k_chain: loM)
     alignas(16) double loM[4][EKF_MAX_PENDING * 4];
+    // windows longer than the cache (below): a wave's winner candidate leaves its rows of the window's FIRST half here, beside its record
+    alignas(16) double wl2[2][4][SOLO_HALF * 4];
 };
 
 struct SoloRobot {  // the robot block as every thread holds it
@@ -99,6 +110,9 @@ __device__ __forceinline__ void solo_nees_sample(const SoloRobot &R, const doubl
 
 // grid (1, filters of the launch), blockDim = 64 * ceil(capacity / 64) <= 256 threads; arguments as k_chain's (segments with
 // n_prev = 0, need_pass = 0, drop = 0: one slot set, dense passes in place between the launches that fill a window).
+// LONG: the window may be longer than the own-row cache (its first half then lives in accumulation registers, solo_agpr.h); the
+// host launches k_solo<true> only for such handles -- windows the cache holds run the kernel without any of that code.
+template <bool LONG>
 __global__ __launch_bounds__(256) void k_solo(EkfDev dv, const double *in, const int *cursor, ChainPlan plan, int b_off) {
     __shared__ SoloLds L;
     __shared__ double recs[EKF_CHAIN_MAX_OPS * 8];
@@ -127,6 +141,14 @@ __global__ __launch_bounds__(256) void k_solo(EkfDev dv, const double *in, const
     SoloRobot rb;
     int n_lm = 0, n_sweep = 0;  // (uniform; kept by every thread)
     int par = 0;                // measurement parity of the candidate buffers
+    const int C = vs_cap;       // slots the own-row cache holds; the window (dv.maxp) may be up to twice that (SOLO_HALF = C then)
+    // this landmark's rows of slots [0, C) once the window is in its second half (slot >= C): accumulation registers a128..a255,
+    // explicit (solo_agpr.h: oh_set / oh_get with static slot numbers)
+    if (LONG) {
+        oh_reserve();
+#pragma unroll
+        for (int q = 0; q < SOLO_HALF; q++) oh_set(q, 0.0, 0.0, 0.0, 0.0);
+    }
 #ifdef EKF_CHAIN_STAMPS
     // diagnostic build: thread 0 of filter 0 adds up the 100 MHz ticks of [0] everything between measurements, [1] sweep + arg-min +
     // barrier, [2] pick + gate + slot matrices, [3] the wait for the P_LL entries, [4] fold, [5] gain + robot block, [6] emit
@@ -177,7 +199,7 @@ __global__ __launch_bounds__(256) void k_solo(EkfDev dv, const double *in, const
         // of the segment (emit below): the measurement loop then holds no global store at all, and the one dependent memory trip
         // of a measurement (the P_LL entries of the matched landmark) never queues behind the acknowledgements of earlier stores.
         auto cache_rows = [=](int lm, int slot, double r00, double r01, double r10, double r11) {
-            double *cr = own_rows + own_at(slot, 0, lm);
+            double *cr = own_rows + own_at(slot < C ? slot : slot - C, 0, lm);  // (second half: the cache starts again at slot C)
             *(double2_t *)cr = (double2_t){r00, r01};
             *(double2_t *)(cr + 128) = (double2_t){r10, r11};
         };
@@ -211,8 +233,10 @@ __global__ __launch_bounds__(256) void k_solo(EkfDev dv, const double *in, const
         if (seg == 0) {
             new_mask = 0;
             for (int q = 0; q < slot0; q++) new_mask |= (uni(L.sm[q].type) == SLOT_NEW ? 1ull : 0ull) << q;
+            // (a launch that continues a window in its second half finds slots [0, C) in registers, [C, slot0) in the cache)
+            const int c_lo = LONG && slot0 > C ? C : 0;
             if (lm0 < n_lm)
-                for (int v0 = 0; v0 < slot0; v0 += 8) {  // eight slots per trip, every load requested before the first LDS write
+                for (int v0 = c_lo; v0 < slot0; v0 += 8) {  // eight slots per trip, every load requested before the first LDS write
                     double2_t lo2[8], hi2[8];
 #pragma unroll
                     for (int j = 0; j < 8; j++) {
@@ -223,10 +247,18 @@ __global__ __launch_bounds__(256) void k_solo(EkfDev dv, const double *in, const
 #pragma unroll
                     for (int j = 0; j < 8; j++)
                         if (v0 + j < slot0) {
-                            double *cr = own_rows + own_at(v0 + j, 0, lm0);
+                            double *cr = own_rows + own_at(v0 + j - c_lo, 0, lm0);
                             *(double2_t *)cr = lo2[j], *(double2_t *)(cr + 128) = hi2[j];
                         }
                 }
+            if (LONG && slot0 > C && lm0 < n_lm) {
+#pragma unroll
+                for (int vs = 0; vs < SOLO_HALF; vs++) {
+                    const double *F = ((new_mask >> vs) & 1 ? FAb : FBb) + off_c + pair_offset(rows_, 2 * lm0, vs >> 1) + (vs & 1) * 2;
+                    const double2_t lo2 = *(const double2_t *)F, hi2 = *(const double2_t *)(F + 4);
+                    oh_set(vs, lo2.x, lo2.y, hi2.x, hi2.y);
+                }
+            }
         } else if (slot0 == 0) {
             new_mask = 0;  // a new window: no slot is open
         }
@@ -255,6 +287,19 @@ __global__ __launch_bounds__(256) void k_solo(EkfDev dv, const double *in, const
                 if (tid == 0) solo_nees_sample(rb, rec, L.st);
                 continue;
             }
+
+            if (LONG && slot == C && C < dv.maxp && (type == OP_SKIP_SLOT || type == OP_MEAS || type == OP_COMPASS)) {
+                // the window enters its second half: this landmark's rows of slots [0, C) move from the cache into registers (own rows,
+                // own thread: nobody else touches them; from here on other threads get the matched landmark's rows through wl2)
+                if (lm0 < n_lm) {
+#pragma unroll
+                    for (int q = 0; q < SOLO_HALF; q++) {
+                        const double2_t c01 = *(const double2_t *)(own_rows + own_at(q, 0, lm0)), c23 = *(const double2_t *)(own_rows + own_at(q, 2, lm0));
+                        oh_set(q, c01.x, c01.y, c23.x, c23.y);
+                    }
+                }
+            }
+            const bool h2 = LONG && slot >= C && C < dv.maxp;  // (uniform) second half: slots [0, C) in registers, [C, slot) in the cache
 
             if (type == OP_SKIP_SLOT) {
                 // a masked measurement: consumes its slot, changes nothing
@@ -286,6 +331,15 @@ __global__ __launch_bounds__(256) void k_solo(EkfDev dv, const double *in, const
                 if (best.lm == ri && ri != 0x7fffffff) {  // the lane that owns the wave's winner leaves its record
 #pragma unroll
                     for (int i = 0; i < 16; i++) L.wcand[par][wave][i] = best.w[i];
+                    if (h2 && rd < dv.gamma_min) {  // ... and, where it can become an Old match, its rows of the window's first half
+#pragma unroll
+                        for (int q = 0; q < SOLO_HALF; q++) {
+                            double o4[4];
+                            oh_get(q, o4);
+                            *(double2_t *)(L.wl2[par][wave] + q * 4) = (double2_t){o4[0], o4[1]};
+                            *(double2_t *)(L.wl2[par][wave] + q * 4 + 2) = (double2_t){o4[2], o4[3]};
+                        }
+                    }
                 }
                 __syncthreads();  // the one barrier of a measurement
                 STAMP(1);
@@ -295,6 +349,7 @@ __global__ __launch_bounds__(256) void k_solo(EkfDev dv, const double *in, const
                     if (cand_better(L.wd[par][wv], L.wi[par][wv], gd, gi)) gd = L.wd[par][wv], gi = L.wi[par][wv], gw = wv;
                 gi = uni(gi), gw = uni(gw);
                 const double *wrec = L.wcand[par][gw];
+                const double *wold = L.wl2[par][gw];  // (second half, Old: the matched landmark's rows of slots [0, C))
                 par ^= 1;
                 // ---- gate, Update.cpp:152,181,191: a pure function of the winner, evaluated by every thread -------------
                 const int w_lo = gi;
@@ -334,15 +389,23 @@ __global__ __launch_bounds__(256) void k_solo(EkfDev dv, const double *in, const
                     double wv[16];
 #pragma unroll
                     for (int i = 0; i < 16; i++) wv[i] = wrec[i];
-                    // the matched landmark's cached rows of every open slot -> the wave's loC, and from them the slot's 2x2 matrix M
-                    // -> the wave's loM (P[own rows, matched columns] += own cached rows * M; Old: M = -S K_lo^T; New: identity
+                    // from the matched landmark's rows of every open slot (the cache; first-half slots of a long window: wl2) the slot's
+                    // 2x2 matrix M -> the wave's loM (P[own rows, matched columns] += own rows * M; Old: M = -S K_lo^T; New: identity
                     // when the matched landmark is the new one): lanes 0..slot-1 of EVERY wave, read back by the same wave
                     const int nvs = slot;
-                    double *wC = L.loC[wave], *wM = L.loM[wave];
+                    double *wM = L.loM[wave];
+                    auto matched_rows = [=](int vs, double c4[4]) {  // rows of w_lo in open slot vs
+                        if (h2 && vs < C) {
+#pragma unroll
+                            for (int j = 0; j < 4; j++) c4[j] = wold[vs * 4 + j];
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 4; j++) c4[j] = own_rows[own_at(h2 ? vs - C : vs, j, w_lo)];
+                        }
+                    };
                     if (lane < nvs) {
                         double c4[4];
-#pragma unroll
-                        for (int j = 0; j < 4; j++) c4[j] = own_rows[own_at(lane, j, w_lo)];
+                        matched_rows(lane, c4);
                         const SlotMeta m = L.sm[lane];
                         double M[4] = {0, 0, 0, 0};  // M[k*2+e]
                         if (m.type == SLOT_OLD) {   // -S K_lo^T, K_lo rows e = c4[2e], c4[2e+1]
@@ -352,7 +415,7 @@ __global__ __launch_bounds__(256) void k_solo(EkfDev dv, const double *in, const
                             M[0] = 1.0, M[3] = 1.0;
                         }
 #pragma unroll
-                        for (int j = 0; j < 4; j++) wC[lane * 4 + j] = c4[j], wM[lane * 4 + j] = M[j];
+                        for (int j = 0; j < 4; j++) wM[lane * 4 + j] = M[j];
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (LDS operations of one wave execute in order; this keeps the compiler from moving them)
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -373,9 +436,22 @@ __global__ __launch_bounds__(256) void k_solo(EkfDev dv, const double *in, const
                         } else {
                             // the unflushed slots are not in Bm yet: P[lm rows, lo cols] += (own cached rows) * M_slot
                             double pe[2][2] = {{0, 0}, {0, 0}};
-                            if (nvs > 0) {  // (uniform)
-                                unsigned a0 = lds_off(own_rows + own_at(0, 0, lm0)), am = lds_off(wM);
-                                int n = uni(nvs);
+                            if (h2) {  // (uniform) the window's first half from registers: own rows * M_slot, four accumulators
+#pragma unroll
+                                for (int q = 0; q < SOLO_HALF; q++) {
+                                    const double2_t m01 = *(const double2_t *)(wM + q * 4), m23 = *(const double2_t *)(wM + q * 4 + 2);
+                                    double o4[4];
+                                    oh_get(q, o4);
+                                    pe[0][0] = fma(o4[0], m01.x, pe[0][0]), pe[0][1] = fma(o4[0], m01.y, pe[0][1]);
+                                    pe[1][0] = fma(o4[2], m01.x, pe[1][0]), pe[1][1] = fma(o4[2], m01.y, pe[1][1]);
+                                    pe[0][0] = fma(o4[1], m23.x, pe[0][0]), pe[0][1] = fma(o4[1], m23.y, pe[0][1]);
+                                    pe[1][0] = fma(o4[3], m23.x, pe[1][0]), pe[1][1] = fma(o4[3], m23.y, pe[1][1]);
+                                }
+                            }
+                            const int n_cache = h2 ? nvs - C : nvs;  // slots of the current half, in the cache from index 0
+                            if (n_cache > 0) {  // (uniform)
+                                unsigned a0 = lds_off(own_rows + own_at(0, 0, lm0)), am = lds_off(wM + (h2 ? C * 4 : 0));
+                                int n = uni(n_cache);
                                 asm volatile(FOLD_ASM
                                              : [p00] "+v"(pe[0][0]), [p01] "+v"(pe[0][1]), [p10] "+v"(pe[1][0]), [p11] "+v"(pe[1][1]), [a0] "+v"(a0), [am] "+v"(am), [n] "+s"(n)
                                              :
@@ -385,7 +461,8 @@ __global__ __launch_bounds__(256) void k_solo(EkfDev dv, const double *in, const
                             for (unsigned long long nm = new_mask; nm; nm &= nm - 1) {
                                 const int vs = __builtin_ctzll(nm);
                                 if (uni(L.sm[vs].ln) == lm0) {
-                                    const double *c = wC + vs * 4;  // rows e of the matched landmark, components k of the new one
+                                    double c[4];  // rows e of the matched landmark, components k of the new one
+                                    matched_rows(vs, c);
                                     pe[0][0] += c[0], pe[0][1] += c[2], pe[1][0] += c[1], pe[1][1] += c[3];
                                 }
                             }
@@ -522,9 +599,13 @@ __global__ __launch_bounds__(256) void k_solo(EkfDev dv, const double *in, const
                             r0.rc[r * 2 + 1] = u0 * s + u1 * c;
                         }
                         r0.x0 = nl0, r0.x1 = nl1;
-                        for (int sl = 0; sl < slot; sl++)  // the landmark did not exist in the earlier slots of the open window
+                        for (int sl = 0; sl < (h2 ? slot - C : slot); sl++)  // the landmark did not exist in the earlier slots of the open window
 #pragma unroll
                             for (int cmp = 0; cmp < 4; cmp++) own_rows[own_at(sl, cmp, lm0)] = 0.0;
+                        if (h2) {
+#pragma unroll
+                            for (int q = 0; q < SOLO_HALF; q++) oh_set(q, 0.0, 0.0, 0.0, 0.0);
+                        }
                         cache_rows(lm0, slot, 0, 0, 0, 0);  // A = 0 (its own P_xL rows are zero: the 2x2 block lives in D), B = unit rows
                     }
                     n_lm = n_lm_before + 1;
@@ -604,42 +685,66 @@ __global__ __launch_bounds__(256) void k_solo(EkfDev dv, const double *in, const
 
         // ---- segment epilogue: what the set's dense pass and later launches read; the host mirror at the end of the launch ----
         __syncthreads();  // (the slot kinds, thread 0's statistics and decisions are complete; the next segment's records may overwrite recs)
-        // emit: the rows of the slots this segment filled, rebuilt from the own-row cache, as the dense pass reads them -- two
-        // slots share one 64-byte row (slot 2p in [0..1], slot 2p+1 in [2..3]); a pair that is complete goes out as whole rows
-        if (lm0 < n_lm)
-            for (int p = slot0 >> 1; 2 * p < slot; p++) {
+        // emit: the rows of the slots this segment filled, rebuilt from the own-row cache (and, for a window in its second half, from
+        // the registers that hold its first half), as the dense pass reads them -- two slots share one 64-byte row (slot 2p in [0..1],
+        // slot 2p+1 in [2..3]); a pair that is complete goes out as whole rows
+        auto emit_pair = [=](int p, bool in0, bool in1, const double c0[4], const double c1[4]) {  // c0, c1: the landmark's rows of slots 2p, 2p+1
 #pragma clang fp contract(off)
-                double a[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, bq[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-                const bool in0 = 2 * p >= slot0, in1 = 2 * p + 1 < slot;
+            double a[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, bq[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
 #pragma unroll
-                for (int hh = 0; hh < 2; hh++) {
-                    const int sl = 2 * p + hh;
-                    if (hh == 0 ? in0 : in1) {
-                        const double2_t c01 = *(const double2_t *)(own_rows + own_at(sl, 0, lm0)), c23 = *(const double2_t *)(own_rows + own_at(sl, 2, lm0));
-                        const SlotMeta m = L.sm[sl];
-                        if (uni(m.type) == SLOT_OLD) {  // A = -(K S), B = K
-                            bq[hh][0] = c01.x, bq[hh][1] = c01.y, bq[hh][2] = c23.x, bq[hh][3] = c23.y;
-                            a[hh][0] = -(c01.x * m.S00 + c01.y * m.S01), a[hh][1] = -(c01.x * m.S01 + c01.y * m.S11);
-                            a[hh][2] = -(c23.x * m.S00 + c23.y * m.S01), a[hh][3] = -(c23.x * m.S01 + c23.y * m.S11);
-                        } else if (uni(m.type) == SLOT_NEW) {  // A = P_xL rows, B = unit rows at the appended landmark
-                            a[hh][0] = c01.x, a[hh][1] = c01.y, a[hh][2] = c23.x, a[hh][3] = c23.y;
-                            if (m.ln == lm0) bq[hh][0] = 1.0, bq[hh][3] = 1.0;
-                        }
+            for (int hh = 0; hh < 2; hh++) {
+                if (hh == 0 ? in0 : in1) {
+                    const double *c = hh == 0 ? c0 : c1;
+                    const SlotMeta m = L.sm[2 * p + hh];
+                    if (uni(m.type) == SLOT_OLD) {  // A = -(K S), B = K
+                        bq[hh][0] = c[0], bq[hh][1] = c[1], bq[hh][2] = c[2], bq[hh][3] = c[3];
+                        a[hh][0] = -(c[0] * m.S00 + c[1] * m.S01), a[hh][1] = -(c[0] * m.S01 + c[1] * m.S11);
+                        a[hh][2] = -(c[2] * m.S00 + c[3] * m.S01), a[hh][3] = -(c[2] * m.S01 + c[3] * m.S11);
+                    } else if (uni(m.type) == SLOT_NEW) {  // A = P_xL rows, B = unit rows at the appended landmark
+                        a[hh][0] = c[0], a[hh][1] = c[1], a[hh][2] = c[2], a[hh][3] = c[3];
+                        if (m.ln == lm0) bq[hh][0] = 1.0, bq[hh][3] = 1.0;
                     }
                 }
-                double *fa = FAc + pair_offset(rows_, 2 * lm0, p), *fb = FBc + pair_offset(rows_, 2 * lm0, p);
-                if (in0) {  // (the partner's half: its rows, or zeros while it has not been filled)
-                    *(double4_t *)fa = (double4_t){a[0][0], a[0][1], a[1][0], a[1][1]};
-                    *(double4_t *)(fa + 4) = (double4_t){a[0][2], a[0][3], a[1][2], a[1][3]};
-                    *(double4_t *)fb = (double4_t){bq[0][0], bq[0][1], bq[1][0], bq[1][1]};
-                    *(double4_t *)(fb + 4) = (double4_t){bq[0][2], bq[0][3], bq[1][2], bq[1][3]};
-                } else {    // (slot 2p was filled by an earlier launch)
-                    *(double2_t *)(fa + 2) = (double2_t){a[1][0], a[1][1]};
-                    *(double2_t *)(fa + 6) = (double2_t){a[1][2], a[1][3]};
-                    *(double2_t *)(fb + 2) = (double2_t){bq[1][0], bq[1][1]};
-                    *(double2_t *)(fb + 6) = (double2_t){bq[1][2], bq[1][3]};
-                }
             }
+            double *fa = FAc + pair_offset(rows_, 2 * lm0, p), *fb = FBc + pair_offset(rows_, 2 * lm0, p);
+            if (in0) {  // (the partner's half: its rows, or zeros while it has not been filled)
+                *(double4_t *)fa = (double4_t){a[0][0], a[0][1], a[1][0], a[1][1]};
+                *(double4_t *)(fa + 4) = (double4_t){a[0][2], a[0][3], a[1][2], a[1][3]};
+                *(double4_t *)fb = (double4_t){bq[0][0], bq[0][1], bq[1][0], bq[1][1]};
+                *(double4_t *)(fb + 4) = (double4_t){bq[0][2], bq[0][3], bq[1][2], bq[1][3]};
+            } else {    // (slot 2p was filled by an earlier launch)
+                *(double2_t *)(fa + 2) = (double2_t){a[1][0], a[1][1]};
+                *(double2_t *)(fa + 6) = (double2_t){a[1][2], a[1][3]};
+                *(double2_t *)(fb + 2) = (double2_t){bq[1][0], bq[1][1]};
+                *(double2_t *)(fb + 6) = (double2_t){bq[1][2], bq[1][3]};
+            }
+        };
+        if (lm0 < n_lm) {
+            const bool h2e = LONG && slot > C && C < dv.maxp;  // the segment ends in the window's second half: slots [0, C) are in registers
+            if (h2e && slot0 < C) {
+#pragma unroll
+                for (int q = 0; q < SOLO_HALF; q += 2)  // (static indices into the register copy)
+                    if (q + 1 >= slot0) {
+                        double oa[4], ob[4];
+                        oh_get(q, oa), oh_get(q + 1, ob);
+                        emit_pair(q >> 1, q >= slot0, true, oa, ob);
+                    }
+            }
+            const int first = h2e ? (slot0 > C ? slot0 : C) : slot0, off = h2e ? C : 0;  // slots [first, slot) live in the cache at index slot - off
+            for (int p = first >> 1; 2 * p < slot; p++) {
+                const bool in0 = 2 * p >= first, in1 = 2 * p + 1 < slot;
+                double c0[4] = {0, 0, 0, 0}, c1[4] = {0, 0, 0, 0};
+                if (in0) {
+                    const double2_t c01 = *(const double2_t *)(own_rows + own_at(2 * p - off, 0, lm0)), c23 = *(const double2_t *)(own_rows + own_at(2 * p - off, 2, lm0));
+                    c0[0] = c01.x, c0[1] = c01.y, c0[2] = c23.x, c0[3] = c23.y;
+                }
+                if (in1) {
+                    const double2_t c01 = *(const double2_t *)(own_rows + own_at(2 * p + 1 - off, 0, lm0)), c23 = *(const double2_t *)(own_rows + own_at(2 * p + 1 - off, 2, lm0));
+                    c1[0] = c01.x, c1[1] = c01.y, c1[2] = c23.x, c1[3] = c23.y;
+                }
+                emit_pair(p, in0, in1, c0, c1);
+            }
+        }
         STAMP(6);
 #ifdef EKF_CHAIN_STAMPS
         if (tid == 0 && b == 0)

@@ -51,6 +51,14 @@ WORKLOADS = {
     "batch256": (256, 256, 200, 10, 20260004, 12.5, 1.0),
 }
 
+def window_for(workload, asked):
+    """measurements per dense pass: --max-pending when given, else 16 -- and 32 for batch256, whose one-workgroup filters (k_solo) keep the
+    first half of a long window in accumulation registers: the chain and the pass are serial there, so half as many passes pay"""
+    if asked:
+        return asked
+    return 32 if workload == "batch256" else 16
+
+
 def make_filters(pkg, mc, workload, lo, hi, steps, M, dev_id, max_pending, log_entries, tail_windows=0):
     """A handle holding global filters [lo, hi) of `workload`, states injected and the step script loaded (all untimed):
     `steps` steps plus `tail_windows` windows' worth for measurements outside the timed region."""
@@ -119,7 +127,7 @@ def config5_legs(pkg, mc, torch, dist, coll_device, rank, world, dev_id, M, max_
     out = {"world_size": world, "N": 256, "M": M, "steps": K, "warmup": W}
     for leg, total in (("weak", per_gpu * world), ("strong", 2048)):
         lo, hi = mc.shard_range(total, rank, world)
-        f, _ = make_filters(pkg, mc, "batch256", lo, hi, W + K, M, dev_id, max_pending, (K + W) * M)
+        f, _ = make_filters(pkg, mc, "batch256", lo, hi, W + K, M, dev_id, window_for("batch256", max_pending), (K + W) * M)
         elapsed, _, gathered = timed_steps(f, mc, torch, dist, coll_device, W, K, False)
         st = f.stats()
         assert all(s["n_old"] == K * M for s in st), "a filter left the Old branch"
@@ -233,6 +241,7 @@ def measure(pkg, mc, torch, dist, coll_device, rank, world, dev_id, workload, K,
     lo, hi = mc.shard_range(B * world, rank, world)
     # (4 windows of untimed tail: dense passes measured one at a time, nothing beside them; latency: one step per call)
     extra = 264 if latency else 0
+    max_pending = window_for(workload, max_pending)
     f, scripts = make_filters(pkg, mc, workload, lo, hi, W + K + extra, M, dev_id, max_pending, (K + W + extra) * M, tail_windows=4 if alone else 0)
     window = f.window  # the library may shorten the window to fit its on-chip buffer
     win_steps = -(-window // M)
@@ -485,7 +494,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--workload", default="n4096", choices=sorted(WORKLOADS))
     ap.add_argument("--M", type=int, default=4, help="measurements per step")
-    ap.add_argument("--max-pending", type=int, default=16, help="measurements folded per dense pass over P_LL (1 = a dense pass per measurement, as the reference does)")
+    ap.add_argument("--max-pending", type=int, default=0, help="measurements folded per dense pass over P_LL (1 = a dense pass per measurement, as the reference does); "
+                    "0 = the workload's own default: 16, and 32 for the batch of one-workgroup filters (k_solo's long window)")
     ap.add_argument("--graph", type=int, default=0, help="replay steps through HIP graphs (one k_chain launch already covers several steps; plain launches keep the per-launch dense-pass events)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary records (configs 1, 2, 4 and M = 1) that ride on the default line")

@@ -22,7 +22,15 @@ SAVEEXEC = re.compile(r"^\s*s_(and|andn2|or)_saveexec_b64 ")
 def main():
     path = sys.argv[1]
     min_copies = int(sys.argv[2]) if len(sys.argv) > 2 else 8  # a few copies are ordinary phi moves of the region itself
-    lines = [l for l in open(path) if not re.match(r"^\s*(\.loc|;|\.Ltmp|\.cfi)", l)]
+    # inline-asm blocks (between ";;#ASMSTART" and ";;#ASMEND") are hand-written and checked by eye: both checks look at compiler output only
+    lines, in_asm = [], False
+    for l in open(path):
+        if "#ASMSTART" in l:
+            in_asm = True
+        elif "#ASMEND" in l:
+            in_asm = False
+        elif not in_asm and not re.match(r"^\s*(\.loc|;|\.Ltmp|\.cfi)", l):
+            lines.append(l)
     func, bad, run, body_only = None, [], 0, False
     for i, l in enumerate(lines):
         m = re.match(r"^(_Z\w+):", l)
@@ -37,6 +45,27 @@ def main():
         if WIDEN.match(l) and run >= min_copies and not body_only:
             bad.append((func, i + 1, run))
         run = 0
+    # second check (round 4): k_solo<true> keeps the first half of a long window in accumulation registers a128..a255 by explicit
+    # v_accvgpr instructions the register allocator does not see (csrc/solo_agpr.h).  That is only sound while the compiler's own use of
+    # accumulation registers (spill slots, from a0 upwards) stays below a128: no instruction outside an inline-asm block may name one.
+    agpr_hi, agpr_bad = -1, []
+    func = None
+    for i, l in enumerate(lines):
+        m = re.match(r"^(_Z\w+):", l)
+        if m:
+            func = m.group(1)
+        if func is None or "k_solo" not in func or re.match(r"^\s*\.", l):
+            continue
+        for m in re.finditer(r"\ba\[?(\d+)(?::(\d+))?\]?", l):
+            hi = int(m.group(2) or m.group(1))
+            agpr_hi = max(agpr_hi, hi)
+            if hi >= 128:
+                agpr_bad.append((func, i + 1, l.strip()))
+    for f, ln, text in agpr_bad[:10]:
+        print("%s: compiler-generated use of an accumulation register >= a128 (reserved for solo_agpr.h), line %d: %s" % (f, ln, text))
+    print("k_solo: highest accumulation register the compiler itself uses: a%d (a128..a255 are solo_agpr.h's)" % agpr_hi)
+    if agpr_bad:
+        bad.append(("k_solo", agpr_bad[0][1], len(agpr_bad)))
     for f, ln, n in bad:
         print("%s: %d register copies directly before an exec-widening s_or_b64 (line %d of the filtered listing)" % (f, n, ln))
     print("%s: %d suspicious site(s)" % (path, len(bad)))

@@ -8,7 +8,7 @@ import __graft_entry__ as ge
 pkg = ge.load_package()
 NAMES = ["between measurements", "sweep+argmin+barrier", "pick+gate+slot matrices", "wait P_LL", "fold", "gain+robot block", "emit (per window)"]
 
-def run(B, N, maxp=16, steps=64, warm=8, M=4):
+def run(B, N, maxp=int(os.environ.get("MAXP", "16")), steps=64, warm=8, M=4):
     f = pkg.FilterBatch(B, N, max_pending=maxp)
     x0, P0 = pkg.scenarios.injected_state(N, seed=1, extent=12.5)
     sc = pkg.scenarios.steady_script(x0, steps=steps + warm, M=M, seed=2, min_separation=1.0)
@@ -28,5 +28,5 @@ def run(B, N, maxp=16, steps=64, warm=8, M=4):
           ", ".join("%s %.2f" % (NAMES[i], buf[i] * 0.01 / (nm if i < 6 else nm / f.window)) for i in range(7)) + " | sum %.2f" % (sum(buf[i] for i in range(7)) * 0.01 / nm), flush=True)
     f.close()
 
-for B, N in ((1, 256), (64, 256), (256, 256), (256, 128), (1, 50)):
+for B, N in ((1, 256), (256, 256)):
     run(B, N)

@@ -95,7 +95,13 @@ def load_script(f, sc, B=1):
 
 
 @pytest.mark.parametrize("N,steps,max_pending,graph", [(256, 12, 4, False), (256, 12, 4, True), (256, 12, 1, False),
-                                                       (256, 9, 3, True), (1024, 4, 4, False)])
+                                                       (256, 9, 3, True), (1024, 4, 4, False),
+                                                       # k_solo's long windows on a FULL map (every thread owns a landmark; the first
+                                                       # sixteen slots' own rows live in accumulation registers, csrc/solo_agpr.h;
+                                                       # the dense pass folds nine to sixteen slot pairs): whole windows, a partial
+                                                       # last window, a window that is not a multiple of the step's four measurements
+                                                       (256, 24, 32, False), (256, 21, 32, True), (256, 18, 24, False), (256, 17, 17, False),
+                                                       (200, 16, 31, False)])
 def test_steady_script_vs_oracle(pkg, oc, N, steps, max_pending, graph):
     """Configs 2/4 shape: injected state, scripted steps of 1 propagate + 4 Old updates, no host traffic."""
     M = 4
@@ -863,7 +869,7 @@ def test_product_library_has_no_debug_hooks(pkg):
         assert b"EKF_DEBUG_" not in blob
 
 
-@pytest.mark.parametrize("N,max_pending", [(50, 4), (200, 16), (256, 16)])
+@pytest.mark.parametrize("N,max_pending", [(50, 4), (200, 16), (256, 16), (256, 32), (200, 24), (250, 31)])
 def test_one_workgroup_kernel_equals_the_chain_kernel(pkg, oc, monkeypatch, N, max_pending):
     """Maps of up to 256 landmarks run on k_solo (one landmark per thread, the robot block in every thread, one barrier per
     measurement, slot rows emitted once per launch); EKF_SOLO=0 keeps k_chain for them.  Same operations in the same order on
