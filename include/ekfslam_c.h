@@ -104,7 +104,8 @@ int ekf_reserve(ekf_handle h, int capacity_landmarks);
 int ekf_batch_size(ekf_handle h);
 int ekf_capacity(ekf_handle h);
 /* The effective max_pending: the requested window, shortened when capacity_landmarks x window does not fit
- * the on-chip buffer of the chain kernel (64 bytes per landmark and slot, about 148 KB per workgroup). */
+ * the on-chip buffer of the chain kernel (64 bytes per landmark and slot, about 148 KB per workgroup).  Maps of up to 256
+ * landmarks keep windows of up to 32 (the one-workgroup kernel holds the first 16 slots of a longer window in registers). */
 int ekf_window(ekf_handle h);
 /* 1 when the handle overlaps dense passes with chain kernels (ekf_params.overlap resolved), else 0. */
 int ekf_overlap(ekf_handle h);
