@@ -193,15 +193,37 @@ __global__ __launch_bounds__(256) void k_solo(EkfDev dv, const double *in, const
             p[0][0] = raw[0], p[1][1] = raw[3];
             p[0][1] = below ? raw[1] : raw[2], p[1][0] = below ? raw[2] : raw[1];
         };
-        // One landmark's two rows of a measurement's rank-2 slot go to the own-row cache only: K rows of an Old / compass slot (the
-        // fold needs one side, K S K^T is symmetric), P_xL rows of a New one, zeros of a dead one.  What the dense pass reads --
-        // FA = -K S and FB = K, or FA = P_xL and FB = unit rows -- is rebuilt from the cache and written to HBM once, at the end
-        // of the segment (emit below): the measurement loop then holds no global store at all, and the one dependent memory trip
-        // of a measurement (the P_LL entries of the matched landmark) never queues behind the acknowledgements of earlier stores.
+        // One landmark's two rows of a measurement's rank-2 slot go to the own-row cache: K rows of an Old / compass slot (the fold
+        // needs one side, K S K^T is symmetric), P_xL rows of a New one, zeros of a dead one ...
         auto cache_rows = [=](int lm, int slot, double r00, double r01, double r10, double r11) {
             double *cr = own_rows + own_at(slot < C ? slot : slot - C, 0, lm);  // (second half: the cache starts again at slot C)
             *(double2_t *)cr = (double2_t){r00, r01};
             *(double2_t *)(cr + 128) = (double2_t){r10, r11};
+        };
+        // ... and, since round 4, to HBM right away, as the dense pass reads them: FA = -(K S), FB = K of an Old / compass slot, FA = P_xL
+        // rows and FB = unit rows (the appended landmark's thread only) of a New one, zeros of a dead one -- the slot's half (two of the
+        // four doubles) of the landmark's two 32-byte rows of FA and of FB.  Rounds 3's form rebuilt all rows from the cache at the end of
+        // the segment: a burst of 8 stores per thread and slot pair that nothing overlapped (8 us per 16-slot window for one filter, 19 /
+        // 36 us per window of 16 / 32 for 256 filters at once: 134 MB leaving 256 CUs).  Issued here, four stores per measurement drain
+        // under the next measurement's sweep; the one dependent memory trip of a measurement (the P_LL entries of the matched landmark)
+        // is waited for 3 us later, when they have long been acknowledged.
+        auto emit_slot = [=](int slot, int type, bool appended_self, double c0, double c1, double c2, double c3, double S00, double S01, double S11) {
+#pragma clang fp contract(off)
+            double a[4] = {0, 0, 0, 0}, bq[4] = {0, 0, 0, 0};
+            if (type == SLOT_OLD) {  // A = -(K S), B = K
+                bq[0] = c0, bq[1] = c1, bq[2] = c2, bq[3] = c3;
+                a[0] = -(c0 * S00 + c1 * S01), a[1] = -(c0 * S01 + c1 * S11);
+                a[2] = -(c2 * S00 + c3 * S01), a[3] = -(c2 * S01 + c3 * S11);
+            } else if (type == SLOT_NEW) {  // A = P_xL rows, B = unit rows at the appended landmark
+                a[0] = c0, a[1] = c1, a[2] = c2, a[3] = c3;
+                if (appended_self) bq[0] = 1.0, bq[3] = 1.0;
+            }
+            const size_t at = pair_offset(rows_, 2 * lm0, slot >> 1) + (slot & 1) * 2;  // two slots share a row: slot 2p in [0..1], slot 2p+1 in [2..3]
+            double *fa = FAc + at, *fb = FBc + at;
+            *(double2_t *)fa = (double2_t){a[0], a[1]};
+            *(double2_t *)(fa + 4) = (double2_t){a[2], a[3]};
+            *(double2_t *)fb = (double2_t){bq[0], bq[1]};
+            *(double2_t *)(fb + 4) = (double2_t){bq[2], bq[3]};
         };
         // thread 0 records what kind of slot the operation leaves (HBM gets it at the end of the segment)
         auto note_slot = [=](int slot, int type, int ln, double S00, double S01, double S11) {
@@ -305,7 +327,10 @@ __global__ __launch_bounds__(256) void k_solo(EkfDev dv, const double *in, const
                 // a masked measurement: consumes its slot, changes nothing
                 if (tid == 0) note_slot(slot, SLOT_DEAD, 0, 0, 0, 0);
                 if (rec[6] == 2.0) n_sweep = n_lm;
-                if (lm0 < n_lm) cache_rows(lm0, slot, 0, 0, 0, 0);
+                if (lm0 < n_lm) {
+                    cache_rows(lm0, slot, 0, 0, 0, 0);
+                    emit_slot(slot, SLOT_DEAD, false, 0, 0, 0, 0, 0, 0, 0);
+                }
                 slot++;
                 continue;
             }
@@ -507,6 +532,7 @@ __global__ __launch_bounds__(256) void k_solo(EkfDev dv, const double *in, const
                         r0.dyy -= sym_u(Tt[1][0], Tt[1][1], K[1][0], K[1][1], Tt[1][0], Tt[1][1], K[1][0], K[1][1]);
                         // slot: P_LL -= T K^T (rank 2; K S K^T is symmetric, only one triangle is stored): A = -T = -K S, B = K
                         cache_rows(lm0, slot, K[0][0], K[0][1], K[1][0], K[1][1]);
+                        emit_slot(slot, SLOT_OLD, false, K[0][0], K[0][1], K[1][0], K[1][1], h.S00, h.S01, h.S11);
                     }
                     // robot block, by every thread: x_R += K_R res (:187), P_RR -= sym(K_R S K_R^T) (:188,193-194)
                     {
@@ -558,6 +584,7 @@ __global__ __launch_bounds__(256) void k_solo(EkfDev dv, const double *in, const
                             v[a][1] = u0 * s + u1 * c;
                         }
                         cache_rows(lm0, slot, v[0][0], v[0][1], v[1][0], v[1][1]);  // A = P_xL rows, B = 0
+                        emit_slot(slot, SLOT_NEW, false, v[0][0], v[0][1], v[1][0], v[1][1], 0, 0, 0);
                     } else if (lm0 == ln) {
                         // the appended landmark itself (ln < capacity <= blockDim): state and blocks from the header, unit B rows
                         double M[4];  // H_R P_RR H_R^T + R
@@ -607,6 +634,9 @@ __global__ __launch_bounds__(256) void k_solo(EkfDev dv, const double *in, const
                             for (int q = 0; q < SOLO_HALF; q++) oh_set(q, 0.0, 0.0, 0.0, 0.0);
                         }
                         cache_rows(lm0, slot, 0, 0, 0, 0);  // A = 0 (its own P_xL rows are zero: the 2x2 block lives in D), B = unit rows
+                        // (its rows of the window's earlier slots are zero in HBM already: nobody writes the rows of a landmark that does not
+                        // exist, ekf_set_state clears them, and the passes of earlier windows only read them)
+                        emit_slot(slot, SLOT_NEW, true, 0, 0, 0, 0, 0, 0, 0);
                     }
                     n_lm = n_lm_before + 1;
                     if (rec[6] == 2.0) n_sweep = n_lm;
@@ -614,7 +644,10 @@ __global__ __launch_bounds__(256) void k_solo(EkfDev dv, const double *in, const
                     if (tid == 0) note_slot(slot, SLOT_NEW, ln, 0, 0, 0);
                 } else {
                     // ---- Ignore (:191), no room: the slot changes nothing -------------------------------------------------------
-                    if (lm0 < n_lm_before) cache_rows(lm0, slot, 0, 0, 0, 0);
+                    if (lm0 < n_lm_before) {
+                        cache_rows(lm0, slot, 0, 0, 0, 0);
+                        emit_slot(slot, SLOT_DEAD, false, 0, 0, 0, 0, 0, 0, 0);
+                    }
                     if (rec[6] == 2.0) n_sweep = n_lm_before;
                     if (tid == 0) note_slot(slot, SLOT_DEAD, n_lm_before, 0, 0, 0);
                 }
@@ -657,6 +690,7 @@ __global__ __launch_bounds__(256) void k_solo(EkfDev dv, const double *in, const
                     r0.dxy -= sym_u(Tt[0], 0, K[0], 0, Tt[1], 0, K[1], 0);
                     r0.dyy -= sym_u(Tt[1], 0, K[1], 0, Tt[1], 0, K[1], 0);
                     cache_rows(lm0, slot, K[0], 0, K[1], 0);  // A = -K S, B = K with a zero second column
+                    emit_slot(slot, SLOT_OLD, false, K[0], 0, K[1], 0, S, 0, 0);
                 }
                 {
                     double pose_n[3], Pn[9];
@@ -685,65 +719,13 @@ __global__ __launch_bounds__(256) void k_solo(EkfDev dv, const double *in, const
 
         // ---- segment epilogue: what the set's dense pass and later launches read; the host mirror at the end of the launch ----
         __syncthreads();  // (the slot kinds, thread 0's statistics and decisions are complete; the next segment's records may overwrite recs)
-        // emit: the rows of the slots this segment filled, rebuilt from the own-row cache (and, for a window in its second half, from
-        // the registers that hold its first half), as the dense pass reads them -- two slots share one 64-byte row (slot 2p in [0..1],
-        // slot 2p+1 in [2..3]); a pair that is complete goes out as whole rows
-        auto emit_pair = [=](int p, bool in0, bool in1, const double c0[4], const double c1[4]) {  // c0, c1: the landmark's rows of slots 2p, 2p+1
-#pragma clang fp contract(off)
-            double a[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, bq[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-#pragma unroll
-            for (int hh = 0; hh < 2; hh++) {
-                if (hh == 0 ? in0 : in1) {
-                    const double *c = hh == 0 ? c0 : c1;
-                    const SlotMeta m = L.sm[2 * p + hh];
-                    if (uni(m.type) == SLOT_OLD) {  // A = -(K S), B = K
-                        bq[hh][0] = c[0], bq[hh][1] = c[1], bq[hh][2] = c[2], bq[hh][3] = c[3];
-                        a[hh][0] = -(c[0] * m.S00 + c[1] * m.S01), a[hh][1] = -(c[0] * m.S01 + c[1] * m.S11);
-                        a[hh][2] = -(c[2] * m.S00 + c[3] * m.S01), a[hh][3] = -(c[2] * m.S01 + c[3] * m.S11);
-                    } else if (uni(m.type) == SLOT_NEW) {  // A = P_xL rows, B = unit rows at the appended landmark
-                        a[hh][0] = c[0], a[hh][1] = c[1], a[hh][2] = c[2], a[hh][3] = c[3];
-                        if (m.ln == lm0) bq[hh][0] = 1.0, bq[hh][3] = 1.0;
-                    }
-                }
-            }
-            double *fa = FAc + pair_offset(rows_, 2 * lm0, p), *fb = FBc + pair_offset(rows_, 2 * lm0, p);
-            if (in0) {  // (the partner's half: its rows, or zeros while it has not been filled)
-                *(double4_t *)fa = (double4_t){a[0][0], a[0][1], a[1][0], a[1][1]};
-                *(double4_t *)(fa + 4) = (double4_t){a[0][2], a[0][3], a[1][2], a[1][3]};
-                *(double4_t *)fb = (double4_t){bq[0][0], bq[0][1], bq[1][0], bq[1][1]};
-                *(double4_t *)(fb + 4) = (double4_t){bq[0][2], bq[0][3], bq[1][2], bq[1][3]};
-            } else {    // (slot 2p was filled by an earlier launch)
-                *(double2_t *)(fa + 2) = (double2_t){a[1][0], a[1][1]};
-                *(double2_t *)(fa + 6) = (double2_t){a[1][2], a[1][3]};
-                *(double2_t *)(fb + 2) = (double2_t){bq[1][0], bq[1][1]};
-                *(double2_t *)(fb + 6) = (double2_t){bq[1][2], bq[1][3]};
-            }
-        };
-        if (lm0 < n_lm) {
-            const bool h2e = LONG && slot > C && C < dv.maxp;  // the segment ends in the window's second half: slots [0, C) are in registers
-            if (h2e && slot0 < C) {
-#pragma unroll
-                for (int q = 0; q < SOLO_HALF; q += 2)  // (static indices into the register copy)
-                    if (q + 1 >= slot0) {
-                        double oa[4], ob[4];
-                        oh_get(q, oa), oh_get(q + 1, ob);
-                        emit_pair(q >> 1, q >= slot0, true, oa, ob);
-                    }
-            }
-            const int first = h2e ? (slot0 > C ? slot0 : C) : slot0, off = h2e ? C : 0;  // slots [first, slot) live in the cache at index slot - off
-            for (int p = first >> 1; 2 * p < slot; p++) {
-                const bool in0 = 2 * p >= first, in1 = 2 * p + 1 < slot;
-                double c0[4] = {0, 0, 0, 0}, c1[4] = {0, 0, 0, 0};
-                if (in0) {
-                    const double2_t c01 = *(const double2_t *)(own_rows + own_at(2 * p - off, 0, lm0)), c23 = *(const double2_t *)(own_rows + own_at(2 * p - off, 2, lm0));
-                    c0[0] = c01.x, c0[1] = c01.y, c0[2] = c23.x, c0[3] = c23.y;
-                }
-                if (in1) {
-                    const double2_t c01 = *(const double2_t *)(own_rows + own_at(2 * p + 1 - off, 0, lm0)), c23 = *(const double2_t *)(own_rows + own_at(2 * p + 1 - off, 2, lm0));
-                    c1[0] = c01.x, c1[1] = c01.y, c1[2] = c23.x, c1[3] = c23.y;
-                }
-                emit_pair(p, in0, in1, c0, c1);
-            }
+        // the slots' rows went to HBM as they were computed (emit_slot); what is left is the partner half of a last, incomplete pair:
+        // the pass reads whole rows of a pair that has one live slot, so the unfilled half holds zeros until a later launch fills it
+        if (lm0 < n_lm && (slot & 1) && slot > slot0) {
+            const size_t at = pair_offset(rows_, 2 * lm0, slot >> 1) + 2;
+            const double2_t zz = {0.0, 0.0};
+            *(double2_t *)(FAc + at) = zz, *(double2_t *)(FAc + at + 4) = zz;
+            *(double2_t *)(FBc + at) = zz, *(double2_t *)(FBc + at + 4) = zz;
         }
         STAMP(6);
 #ifdef EKF_CHAIN_STAMPS
