@@ -872,7 +872,7 @@ def test_product_library_has_no_debug_hooks(pkg):
 @pytest.mark.parametrize("N,max_pending", [(50, 4), (200, 16), (256, 16), (256, 32), (200, 24), (250, 31)])
 def test_one_workgroup_kernel_equals_the_chain_kernel(pkg, oc, monkeypatch, N, max_pending):
     """Maps of up to 256 landmarks run on k_solo (one landmark per thread, the robot block in every thread, one barrier per
-    measurement, slot rows emitted once per launch); EKF_SOLO=0 keeps k_chain for them.  Same operations in the same order on
+    measurement, slot rows emitted as they are computed); EKF_SOLO=0 keeps k_chain for them.  Same operations in the same order on
     the same layout: a lifecycle from x = 0, P = 0 (New / Old / Ignore, compass, masked measurements, state reads in the
     middle of windows) gives identical decisions and states within rounding of each other, and both match the oracle."""
     steps, M = 120, 3
