@@ -236,6 +236,9 @@ __global__ __launch_bounds__(256) void k_solo(EkfDev dv, const double *in, const
         for (int q = tid; q < nops * 8; q += bd) recs[q] = op_record(in, cursor, k0 + (q >> 3), dv.B, b)[q & 7];
         if (seg == 0) {
             for (int q = tid; q < slot0; q += bd) L.sm[q] = dv.slot_meta[((size_t)b * 2 + set) * dv.maxp + q];
+            // (the landmark's state is requested beside the landmark count that decides whether it exists -- one memory trip at the start
+            // of every launch instead of two; a thread past the capacity reads the last landmark's and drops it)
+            const LmState r_pre = lm_load(lm0 < dv.Ncap ? lm0 : dv.Ncap - 1);
             n_lm = dv.n_lm[b], n_sweep = dv.n_lm_sweep[b];
 #pragma unroll
             for (int i = 0; i < 3; i++) {
@@ -248,7 +251,7 @@ __global__ __launch_bounds__(256) void k_solo(EkfDev dv, const double *in, const
                 L.st = dv.stats[b];
                 L.log_count = dv.log_count[b];
             }
-            if (lm0 < n_lm) r0 = lm_load(lm0);
+            if (lm0 < n_lm) r0 = r_pre;
         }
         if (tid == 0) L.n_dec = 0;
         __syncthreads();
@@ -733,36 +736,44 @@ __global__ __launch_bounds__(256) void k_solo(EkfDev dv, const double *in, const
             for (int i = 0; i < 8; i++) dv.dbg[i] += stamp_acc[i], stamp_acc[i] = 0;
 #endif
         if (seg + 1 == nseg && lm0 < n_lm) lm_store(lm0, r0);  // the landmark lived in registers for the whole launch: x, its P_RL columns and its 2x2 block go back once
-        if (tid == 0) {
-            for (int sl = slot0; sl < slot; sl++) {
-                act_c[sl] = L.sm[sl].type != SLOT_DEAD ? 1 : 0;
-                dv.slot_meta[((size_t)b * 2 + set) * dv.maxp + sl] = L.sm[sl];
+        // The segment's slot kinds, activity flags and decisions: wave 0, a lane per entry (thread 0 alone used to walk them: 32 slots and
+        // 32 decisions of a long window are some 400 dependent LDS-read / store pairs, 4 us at the end of every launch).  The host
+        // mirror's sequence number goes last, behind a release fence that every lane of the wave executes for its own stores.
+        if (wave == 0) {
+            EkfMirror *mr = dv.mirror + b;
+            for (int sl = slot0 + lane; sl < slot; sl += 64) {
+                const SlotMeta m = L.sm[sl];
+                act_c[sl] = m.type != SLOT_DEAD ? 1 : 0;
+                dv.slot_meta[((size_t)b * 2 + set) * dv.maxp + sl] = m;
             }
-            for (int i = 0; i < L.n_dec; i++) dv.log[(size_t)b * dv.logcap + ((L.log_count - L.n_dec + i) % dv.logcap)] = L.dec_buf[i];
-            dv.n_lm_flush[(size_t)b * 2 + set] = n_lm;
+            const int nd = L.n_dec;
+            const long long first = L.log_count - nd;
+            for (int i = lane; i < nd; i += 64) {  // (rings: only the newest logcap / EKF_MIRROR_DECISIONS entries are written, one lane each)
+                const ekf_decision e = L.dec_buf[i];
+                if (i >= nd - dv.logcap) dv.log[(size_t)b * dv.logcap + ((first + i) % dv.logcap)] = e;
+                if (i >= nd - EKF_MIRROR_DECISIONS) mr->last[(first + i) % EKF_MIRROR_DECISIONS] = e;
+            }
+            if (lane == 0) dv.n_lm_flush[(size_t)b * 2 + set] = n_lm;
             if (seg + 1 == nseg) {
-                EkfMirror *mr = dv.mirror + b;
-                for (int i = 0; i < L.n_dec; i++) mr->last[(L.log_count - L.n_dec + i) % EKF_MIRROR_DECISIONS] = L.dec_buf[i];
-                for (int i = 0; i < 3; i++) {
-                    x[i] = rb.pose[i];
-                    for (int j = 0; j < 3; j++) R0[(size_t)i * xs + j] = rb.Prr[i * 3 + j];
+                if (lane == 0) {
+                    for (int i = 0; i < 3; i++) {
+                        x[i] = rb.pose[i];
+                        for (int j = 0; j < 3; j++) R0[(size_t)i * xs + j] = rb.Prr[i * 3 + j];
+                    }
+                    dv.n_lm[b] = n_lm;
+                    dv.n_lm_sweep[b] = n_sweep;
+                    for (int i = 0; i < 3; i++) mr->pose[i] = rb.pose[i];
+                    for (int i = 0; i < 9; i++) mr->Prr[i] = rb.Prr[i];
+                    mr->n_lm = n_lm;
+                    dv.stats[b] = L.st;
+                    mr->stats = L.st;
+                    dv.log_count[b] = L.log_count;
+                    if (dv.status[b] != 0) mr->status = dv.status[b];  // (k_set_meta clears both)
+                    mr->log_count = L.log_count;
                 }
-                dv.n_lm[b] = n_lm;
-                dv.n_lm_sweep[b] = n_sweep;
-                for (int i = 0; i < 3; i++) mr->pose[i] = rb.pose[i];
-                for (int i = 0; i < 9; i++) mr->Prr[i] = rb.Prr[i];
-                mr->n_lm = n_lm;
-                dv.stats[b] = L.st;
-                mr->stats = L.st;
-                dv.log_count[b] = L.log_count;
-                if (dv.status[b] != 0) mr->status = dv.status[b];  // (k_set_meta clears both)
-                mr->log_count = L.log_count;
                 // everything above is in host memory before the sequence number is: a host thread spinning on seq reads a complete mirror
                 __atomic_thread_fence(__ATOMIC_RELEASE);
-                __hip_atomic_store(&mr->seq, last_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            } else {
-                EkfMirror *mr = dv.mirror + b;
-                for (int i = 0; i < L.n_dec; i++) mr->last[(L.log_count - L.n_dec + i) % EKF_MIRROR_DECISIONS] = L.dec_buf[i];
+                if (lane == 0) __hip_atomic_store(&mr->seq, last_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
         if (seg + 1 < nseg) __syncthreads();

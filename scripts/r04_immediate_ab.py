@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import __graft_entry__ as ge
 pkg = ge.load_package()
-for N in (1024, 4096):
+for N in [int(v) for v in os.environ.get("IMM_N", "1024,4096").split(",")]:
     M, steps = 4, 200
     x0, P0 = pkg.scenarios.injected_state(N, seed=1, extent=50.0 * (N / 4096.0) ** 0.5)
     sc = pkg.scenarios.steady_script(x0, steps=steps, M=M, seed=2, min_separation=1.0)
