@@ -197,11 +197,13 @@ def test_config2_n1024_after_steps_1_10_200(pkg, oc):
     f.close()
 
 
-def test_config4_full_size_batch_256_filters(pkg, oc):
+@pytest.mark.parametrize("max_pending", [32, 16])
+def test_config4_full_size_batch_256_filters(pkg, oc, max_pending):
     """256 independent filters x N = 256 behind one handle, 200 steps of 1 Propagate + 4 Updates (bench.py's batch256
     inputs): every filter's decisions are the intended Old matches; 9 sampled filters are compared with the oracle
     state for state, and their device-side NIS / NEES sums with values computed from the oracle's Mahalanobis
-    distances and P_RR."""
+    distances and P_RR.  Window 32 is what bench.py runs configs 4 / 5 with (k_solo's long window: 16-pair dense passes),
+    16 the library's default."""
     B, M, steps = 256, 4, 200
     sampled = [0, 1, 37, 74, 111, 148, 185, 222, 255]
 
@@ -212,7 +214,8 @@ def test_config4_full_size_batch_256_filters(pkg, oc):
 
     ins, refs = cached("config4", build)
     N = ins[0][0]
-    f = pkg.FilterBatch(B, N, max_pending=16, log_capacity=steps * M)
+    f = pkg.FilterBatch(B, N, max_pending=max_pending, log_capacity=steps * M)
+    assert f.window == max_pending
     for b in range(B):
         f.set_state(ins[b][1], ins[b][2], index=b)
     load_script(f, [i[3] for i in ins])
