@@ -82,3 +82,30 @@ def test_generated_assembly_passes_the_exec_mask_lint(built):
     r = subprocess.run(["make", "-C", csrc, "lint"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "0 suspicious site(s)" in r.stdout
+
+
+def test_register_half_of_the_long_window_is_what_the_lint_guards(built):
+    """k_solo<true> keeps 16 slots of a long window in accumulation registers a128..a255 through inline asm the register allocator
+    does not see (csrc/solo_agpr.h).  The header is generated (scripts/r04_gen_solo_agpr.py --check), and the assembly lint reports the
+    highest accumulation register the compiler itself uses in k_solo: it must stay below a128."""
+    import re
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "r04_gen_solo_agpr.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "2d-ekf-slam_amd", "csrc"), "lint"], capture_output=True, text=True)
+    m = re.search(r"highest accumulation register the compiler itself uses: a(-?\d+)", r.stdout)
+    assert r.returncode == 0 and m, r.stdout + r.stderr
+    assert int(m.group(1)) < 128
+    # the lint does flag a compiler-generated use: feed it a doctored listing
+    asm = os.path.join(ROOT, "2d-ekf-slam_amd", "lib", "asm", "ekf_kernels.s")
+    text = open(asm).read()
+    at = text.index("_Z6k_soloILb1EE")
+    at = text.index("\n", text.index("s_waitcnt", at)) + 1
+    doctored = os.path.join(ROOT, "2d-ekf-slam_amd", "lib", "asm", "doctored.s")
+    open(doctored, "w").write(text[:at] + "\tv_accvgpr_write_b32 a130, v1\n" + text[at:])
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "check_exec_split.py"), doctored], capture_output=True, text=True)
+        assert r.returncode == 1 and "reserved for solo_agpr.h" in r.stdout, r.stdout
+    finally:
+        os.remove(doctored)
