@@ -27,5 +27,5 @@ def run(N, maxp, steps=32, warm=8, M=int(os.environ.get("MEAS", "4"))):
           + "; segment prologue per window (us): end of the segment before + waits %.2f, records + slot kinds %.2f, LDS refill / shift + state %.2f" % (buf[26] * 0.01 / (nm / maxp), buf[27] * 0.01 / (nm / maxp), buf[23] * 0.01 / (nm / maxp)) + "; control lane: record read %.2f of its stage" % (buf[12] * 0.01 / nm), flush=True)
     f.close()
 
-for N, maxp in ((4096, 16),):
+for N, maxp in [(int(v), 16) for v in os.environ.get("STAMP_N", "4096").split(",")]:
     run(N, maxp)
