@@ -911,7 +911,7 @@ def test_one_workgroup_kernel_equals_the_chain_kernel(pkg, oc, monkeypatch, N, m
     assert_state_close(e0[0], e0[1], x, P, "k_chain N=%d" % N)
 
 
-@pytest.mark.parametrize("seed", list(range(160)) + [1000, 1001, 1002, 1003, 1004, 1005])
+@pytest.mark.parametrize("seed", list(range(160)) + [1000, 1001, 1002, 1003, 1004, 1005] + list(range(2000, 2016)))
 def test_random_operation_sequences_vs_oracle(pkg, oc, monkeypatch, seed):
     """Randomised API traffic against the oracle, decision for decision and state for state: random capacity, window and
     workgroup count; Propagates with random controls (v = 0 included: Q = 0), doUpdate chunks of 1-3 measurements of a hidden
@@ -932,7 +932,14 @@ def test_random_operation_sequences_vs_oracle(pkg, oc, monkeypatch, seed):
         cap = (400, 900, 1500)[(seed - 1000) % 3]
         world = rng.uniform(-30.0, 30.0, size=((150, 300, 500)[(seed - 1000) % 3], 2))
         n_steps = 40
+    long_window = seed >= 2000  # k_solo's long windows (capacity 200-256, window 20-32: the first 16 slots in accumulation registers):
+    if long_window:             # longer chunks and fewer reads / flushes / closes, so that windows do reach their second half
+        cap = int(rng.integers(200, 257))
+        max_pending = int(rng.choice([20, 24, 31, 32]))
+        monkeypatch.delenv("EKF_CHAIN_WGS", raising=False)
     f = pkg.FilterBatch(1, cap, max_pending=max_pending, log_capacity=4096)
+    if long_window and not f.overlap:
+        assert f.window == max_pending
     x, P = np.zeros(3), np.zeros((3, 3))
     pose = np.zeros(3)  # hidden truth
     n_checks = 0
@@ -946,7 +953,7 @@ def test_random_operation_sequences_vs_oracle(pkg, oc, monkeypatch, seed):
             zc = float(pose[2] % 6.283185307 + rng.normal(0, 0.02))
             f.update_compass(zc, 0.0005)
             x, P = oc.compass(x, P, zc, 0.0005)
-        n_z = int(rng.integers(0, 4)) if seed < 1000 else int(rng.integers(2, 9))
+        n_z = int(rng.integers(0, 4)) if seed < 1000 else (int(rng.integers(2, 9)) if seed < 2000 else int(rng.integers(1, 6)))
         if n_z:
             c, s = np.cos(pose[2]), np.sin(pose[2])
             zs = []
@@ -966,7 +973,7 @@ def test_random_operation_sequences_vs_oracle(pkg, oc, monkeypatch, seed):
             dec = f.update(zs.reshape(1, n_z, 2), Rs.reshape(1, n_z, 2, 2))[0]
             x, P, deco, mato, _ = oc.update(x, P, zs.T, np.concatenate(list(Rs), axis=1))
             assert [(d[0], d[1]) for d in dec] == list(zip(deco, mato)), (seed, step)
-        r = rng.random()
+        r = rng.random() * (4.0 if long_window else 1.0)
         if r < 0.12:
             xg, Pg = f.get_state()
             assert_state_close(xg, Pg, x, P, "seed %d step %d" % (seed, step))
