@@ -71,6 +71,9 @@ struct ekf_batch {
     bool mirror_by_chain; // the newest writer of the host mirror is chain launch number chain_seq (else: some other kernel, synchronise)
     int flush_keep;       // pool key of s_flush: CUs kept free for the chain, -1 = unmasked
     bool solo = false;    // one workgroup per filter and one slot set (phase groups are possible)
+    bool solo_fuse = false;    // ... and k_solo folds the windows it fills itself (ChainSeg::self_pass; EKF_SOLO_FUSE=0: k_flush_rb launches between the windows)
+    long long prof_fused_passes = 0;  // dense passes executed inside profiled k_solo launches since the last ekf_flush_profile_read
+    long long prof_solo_pairs = 0;    // ... and the number of those launches (event pairs that bracket a k_solo launch, not a k_flush_rb)
     bool solo_long = false;    // ... with a window longer than its own-row cache (k_solo<true>: the first half in accumulation registers)
     bool solo_kernel = false;  // ... run by k_solo (ekf_solo.hip: maps of up to 256 landmarks, one landmark per thread, one barrier per measurement)
     // Phase groups (solo batches): the filters are cut into ngroups ranges, each with a stream of its own on which its chain
@@ -419,6 +422,7 @@ static int create_impl(ekf_batch *h, int batch, int capacity_landmarks, int devi
     dv.f_stride = (size_t)(dv.maxpairs + 1) * dv.rows * 4;
     dv.vs_cap = cache_slots;
     h->solo_long = h->solo_kernel && maxp > cache_slots;
+    h->solo_fuse = h->solo_long && (getenv("EKF_SOLO_FUSE") ? atoi(getenv("EKF_SOLO_FUSE")) != 0 : true);  // (k_solo<true>: its pass tile lives in the registers of the window's first half)
     h->chain_lds = (size_t)lpw64 * cache_slots * 32;
     HIP_TRY(hipFuncSetAttribute((const void *)k_chain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_budget));  // one setting for every handle
     HIP_TRY(hipFuncSetAttribute((const void *)k_solo<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_budget));
@@ -927,7 +931,11 @@ static int launch_ops(ekf_batch *h, const double *in, const int *cursor, int k0,
         persist = (g_cus_claimed[h->device] + g_cus_solo[h->device] - h->solo_cus) * 2 <= h->ncu;  // (everybody else's chain workgroups, solo launches included)
     }
     const bool solo = h->solo_kernel;  // one-workgroup filters run by k_solo
-    if (h->solo && h->ngroups > 1 && cursor == nullptr) {
+    // k_solo folds a window it fills itself (ChainSeg::self_pass): the launches of one call are the segments of one launch, with
+    // no dense-pass launch between them (EKF_SOLO_FUSE=0: one launch per window and k_flush_rb, for comparisons)
+    const bool fuse = solo && h->solo_fuse;
+    const bool multi = persist || fuse;
+    if (!fuse && h->solo && h->ngroups > 1 && cursor == nullptr) {
         long slots = h->pending;
         for (int q = 0; q < nops; q++) slots += consumes[q] ? 1 : 0;
         if (slots >= 2L * h->dv.maxp) return launch_ops_grouped(h, in, k0, consumes, nops);  // the call closes at least two windows (scripted runs, and immediate-mode chunks that long)
@@ -938,13 +946,34 @@ static int launch_ops(ekf_batch *h, const double *in, const int *cursor, int k0,
     int next_drop = 0;
     auto launch_plan = [&](hipEvent_t stop_ev) -> int {
         if (plan.nseg == 0) return EKF_OK;
+        hipEvent_t pe0 = nullptr, pe1 = nullptr;
+        if (fuse) {
+            int sp = 0;
+            for (int q = 0; q < plan.nseg; q++) sp += plan.s[q].self_pass;
+            // EKF_SOLO_FUSE_STAGGER_US: a one-off phase shift between the filters of a batch (four groups), so that their own passes take
+            // turns in HBM.  Measured: nothing to gain (6.53 M filter-steps/s without, 6.51 / 6.42 / 6.35 M with 35 / 67 / 90 us: one wave
+            // per SIMD is latency-bound on its own tile, not bandwidth-bound), so the default is none.
+            static const int fuse_stagger = getenv("EKF_SOLO_FUSE_STAGGER_US") ? atoi(getenv("EKF_SOLO_FUSE_STAGGER_US")) * 100 : 0;
+            plan.s[0].stagger = (sp >= 4 && h->dv.B >= 16) ? fuse_stagger : 0;
+            if (h->prof_flush && sp > 0) {  // the passes live inside this launch: time the launch, count the passes
+                while (h->prof_pool.size() < h->prof_used + 2) {
+                    hipEvent_t ev;
+                    HIP_TRY(hipEventCreate(&ev));
+                    h->prof_pool.push_back(ev);
+                }
+                pe0 = h->prof_pool[h->prof_used++], pe1 = h->prof_pool[h->prof_used++];
+                h->prof_fused_passes += sp;
+                h->prof_solo_pairs++;
+            }
+        }
         for (int b0 = 0; b0 < h->dv.B; b0 += h->chain_filters) {
             const int nb = h->dv.B - b0 < h->chain_filters ? h->dv.B - b0 : h->chain_filters;
             const bool last = b0 + nb >= h->dv.B;
-            if (solo)
-                if (h->solo_long) hipExtLaunchKernelGGL(k_solo<true>, dim3(1, nb), dim3(h->chain_threads), h->chain_lds, h->s_chain, nullptr, last ? stop_ev : nullptr, 0, h->dv, in, cursor, plan, b0);
-                else hipExtLaunchKernelGGL(k_solo<false>, dim3(1, nb), dim3(h->chain_threads), h->chain_lds, h->s_chain, nullptr, last ? stop_ev : nullptr, 0, h->dv, in, cursor, plan, b0);
-            else
+            if (solo) {
+                hipEvent_t ev0 = b0 == 0 ? pe0 : nullptr, ev1 = last ? (pe1 ? pe1 : stop_ev) : nullptr;
+                if (h->solo_long) hipExtLaunchKernelGGL(k_solo<true>, dim3(1, nb), dim3(h->chain_threads), h->chain_lds, h->s_chain, ev0, ev1, 0, h->dv, in, cursor, plan, b0);
+                else hipExtLaunchKernelGGL(k_solo<false>, dim3(1, nb), dim3(h->chain_threads), h->chain_lds, h->s_chain, ev0, ev1, 0, h->dv, in, cursor, plan, b0);
+            } else
                 hipExtLaunchKernelGGL(k_chain, dim3(h->chain_wgs, nb), dim3(h->chain_threads), h->chain_lds, h->s_chain, nullptr, last ? stop_ev : nullptr, 0, h->dv, in,
                                       cursor, plan, b0);
         }
@@ -987,6 +1016,8 @@ static int launch_ops(ekf_batch *h, const double *in, const int *cursor, int k0,
         sg.need_pass = h->need_pass, sg.drop = next_drop;
         sg.seq = ++h->chain_seq;  // (one number per segment: every filter's mirror reaches it)
         sg.gate = h->seg_count_base[plan.nseg] + (unsigned long long)h->chain_wgs * h->dv.B;  // every workgroup of the launch has finished this segment
+        sg.self_pass = (fuse && used == h->dv.maxp && !h->dbg_skip_flush) ? 1 : 0;
+        sg.stagger = 0;
         next_drop = 0;
         plan.s[plan.nseg++] = sg;
         plan.signal = persist ? 1 : 0;
@@ -994,20 +1025,23 @@ static int launch_ops(ekf_batch *h, const double *in, const int *cursor, int k0,
         h->mirror_by_chain = true;
         h->stats_in_mirror = true;
         h->pending = used;
-        if (!persist) {
+        if (!multi) {
             int rc = launch_plan(closes ? h->ev_chain : nullptr);
             if (rc) return rc;
             h->chain_signalled = closes;
         } else {
             h->chain_signalled = false;
-            if (used == h->dv.maxp) h->open_set_gate = sg.gate, h->open_gate_idx = plan.nseg - 1;
+            if (persist && used == h->dv.maxp) h->open_set_gate = sg.gate, h->open_gate_idx = plan.nseg - 1;
         }
-        if (used == h->dv.maxp && !(defer_last_close && i == nops)) {
+        if (sg.self_pass) {
+            h->cur_set ^= 1;  // folded by the launch itself: the next segment starts an empty window
+            h->pending = 0;
+        } else if (used == h->dv.maxp && !(defer_last_close && i == nops)) {
             int rc = close_set(h, false, persist ? &passes : nullptr);
             if (rc) return rc;
             next_drop = sg.n_prev;  // the next segment starts a window: the set whose pass has finished leaves the LDS caches
         }
-        if (persist && plan.nseg == EKF_PLAN_MAX) {
+        if (multi && plan.nseg == EKF_PLAN_MAX) {
             int rc = launch_plan(nullptr);
             if (rc) return rc;
         }
@@ -1064,7 +1098,7 @@ static int launch_ops_grouped(ekf_batch *h, const double *in, int k0, const unsi
         ChainSeg &sg = plan.s[0];
         sg.k0 = k0 + start, sg.nops = i - start, sg.slot0 = h->pending, sg.set = h->cur_set, sg.buf_read = h->buf_in;
         sg.seq = ++h->chain_seq;
-        sg.gate = 0;
+        sg.gate = 0, sg.self_pass = 0, sg.stagger = 0;
         plan.nseg = 1;
         h->mirror_by_chain = true;
         h->stats_in_mirror = true;
@@ -1845,6 +1879,8 @@ extern "C" int ekf_flush_profile(ekf_handle h, int enable) {
     return EKF_OK;
 }
 
+extern "C" int ekf_fused_pass(ekf_handle h) { return h && h->solo_fuse ? 1 : 0; }
+
 extern "C" int ekf_flush_profile_read(ekf_handle h, long long *launches_out, double *total_ms_out) {
     if (!h) return set_error(EKF_ERR_BAD_ARG, "null handle");
     HIP_TRY(hipSetDevice(h->device));
@@ -1855,6 +1891,12 @@ extern "C" int ekf_flush_profile_read(ekf_handle h, long long *launches_out, dou
         HIP_TRY(hipEventElapsedTime(&ms, h->prof_pool[i], h->prof_pool[i + 1]));
         h->prof_ms += ms;
         h->prof_launches++;
+    }
+    if (h->prof_fused_passes > 0) {
+        // k_solo launches were timed whole: report dense passes, not launches -- the time per pass then includes the measurement
+        // loop of its window (the pass is not a kernel of its own there; ekf_fused_pass() tells the caller)
+        h->prof_launches = h->prof_launches - h->prof_solo_pairs + h->prof_fused_passes;
+        h->prof_fused_passes = h->prof_solo_pairs = 0;
     }
     h->prof_used = 0;
     if (launches_out) *launches_out = h->prof_launches;

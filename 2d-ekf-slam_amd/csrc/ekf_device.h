@@ -79,6 +79,9 @@ struct ChainSeg {
     int drop;            // segments after the first: virtual slots that leave the LDS caches in front (the set whose pass has finished)
     long long seq;       // launch number (the host mirror shows the newest one that has finished)
     unsigned long long gate;  // multi-segment launches: the value dv.seg_count[this segment's index] shows when every workgroup has finished the segment
+    int self_pass;       // k_solo: the segment fills its window and the workgroup folds it into its own P_LL tiles before it goes on (no dense-pass launch)
+    int stagger;         // k_solo, first segment: filter b starts (b mod 4) * stagger ticks of the 100 MHz clock late (a phase shift between the
+                         // filters of a batch, so that their own dense passes take turns in HBM); 0 = none
 };
 struct ChainPlan {
     int nseg;

@@ -402,7 +402,7 @@ __device__ __forceinline__ unsigned lds_off(const void *p) { return (unsigned)(s
         "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240",     \
         "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255"
 
-static_assert(sizeof(ChainSeg) == 48 && sizeof(ChainPlan) == 16 + EKF_PLAN_MAX * 48, "the segment table is read from the kernel-argument segment by offset");
+static_assert(sizeof(ChainSeg) == 56 && sizeof(ChainPlan) == 16 + EKF_PLAN_MAX * 56, "the segment table is read from the kernel-argument segment by offset");
 struct ChainKArgs {  // k_chain's arguments as they lie in the kernel-argument segment
     EkfDev dv;
     const double *in;
@@ -1576,7 +1576,7 @@ __device__ __forceinline__ void flush_tile_rb(const double *tp, double *tq, cons
 // row-block per wave and the B operands shared through LDS (four to five waves per SIMD) 155 us,
 // scripts/dropped/r04_dense_pass_workgroup_per_tile.patch.
 template <bool DIAG>
-__device__ __forceinline__ void flush_tile_whole(const double *tp, double *tq, const double *FA, const double *FB, unsigned lo, unsigned live, int zero_slot, size_t slot_stride) {
+__device__ __forceinline__ void flush_tile_whole(const double *tp, double *tq, const double *FA, const double *FB, unsigned lo, unsigned live, int npl, int zero_slot, size_t slot_stride) {
     double4_t acc[16];
 #pragma unroll
     for (int ch = 0; ch < 16; ch++) {
@@ -1589,6 +1589,7 @@ __device__ __forceinline__ void flush_tile_whole(const double *tp, double *tq, c
     // per SIMD; the operand loads are the same either way, and the other wave of the SIMD covers a row-block's wait for its A operands)
 #pragma unroll
     for (int sweep = 0; sweep < 4; sweep++) {
+        if (sweep * 4 >= npl) break;  // (uniform; npl = the live pairs: a window with dead slots, or k_solo's own pass over a short window)
         size_t mo[4];
 #pragma unroll
         for (int p = 0; p < 4; p++) {
@@ -1700,8 +1701,8 @@ __global__ __launch_bounds__(256, 2) void k_flush_rb(EkfDev dv, int nT_hi, int s
         return;
     }
     if (npl <= 16) {  // windows of 17 to 32
-        if (uni(I) == uni(J)) flush_tile_whole<true>(tp, tq, FA, FB, lo, live, zero_slot, slot_stride);
-        else flush_tile_whole<false>(tp, tq, FA, FB, lo, live, zero_slot, slot_stride);
+        if (uni(I) == uni(J)) flush_tile_whole<true>(tp, tq, FA, FB, lo, live, npl, zero_slot, slot_stride);
+        else flush_tile_whole<false>(tp, tq, FA, FB, lo, live, npl, zero_slot, slot_stride);
         return;
     }
     // more than sixteen pairs (does not occur: EKF_MAX_PENDING = 32): slot-major walk (whole tile loaded, all pairs, then stored), two pairs per iteration

@@ -27,6 +27,7 @@
 // measurement's one barrier.  One dense pass per 32 measurements instead of 16.
 #define SOLO_HALF 16
 #include "solo_agpr.h"
+#include "solo_pass_agpr.h"
 
 struct SoloLds {
     ekf_stats st;
@@ -159,6 +160,16 @@ __global__ __launch_bounds__(256) void k_solo(EkfDev dv, const double *in, const
 
     for (int seg = 0; seg < nseg; seg++) {
         const int k0 = segs[seg].k0, nops = segs[seg].nops, slot0 = segs[seg].slot0, set = segs[seg].set, buf_read = segs[seg].buf_read;
+        const int self_pass = segs[seg].self_pass;
+        if (seg == 0 && segs[0].stagger > 0 && (b & 3) != 0) {  // phase shift between the filters of a batch (see "the workgroup's own dense pass" below)
+            unsigned long long t0, now;
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+            const long long wait_ticks = (long long)(b & 3) * segs[0].stagger;
+            do {
+                __builtin_amdgcn_s_sleep(32);
+                asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now)::"memory");
+            } while ((long long)(now - t0) < wait_ticks);
+        }
         const double *Bmr = dv.Bm[buf_read] + (size_t)b * dv.bm_stride;
         double *FAc = dv.FA + ((size_t)b * 2 + set) * dv.f_stride;
         double *FBc = dv.FB + ((size_t)b * 2 + set) * dv.f_stride;
@@ -731,6 +742,90 @@ __global__ __launch_bounds__(256) void k_solo(EkfDev dv, const double *in, const
             *(double2_t *)(FBc + at) = zz, *(double2_t *)(FBc + at + 4) = zz;
         }
         STAMP(6);
+        // ---- the workgroup's own dense pass (ChainSeg::self_pass) ------------------------------------------------------------------
+        // A one-workgroup filter cannot start its next window before the pass over its P_LL has finished (its slot rows fill the CU's
+        // LDS and registers), so the workgroup that would wait does the pass itself: its waves take the filter's tiles in turn,
+        // P_LL += sum over the window's slots of A B^T, in place, with the operands the measurement loop has written to FA / FB
+        // (k_flush_rb's whole-tile form).  No second kernel, no launch gaps, the landmark and the robot block stay in registers across
+        // windows -- and the filters of a batch drift apart in phase (ChainSeg::stagger), so that while some stream their tiles the
+        // others run their latency-bound measurement loops: HBM sees a steady third of the traffic instead of bursts of all of it.
+        if constexpr (LONG) if (self_pass) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's slot rows have left
+            __syncthreads();                                  // ... everybody's have
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // (the CU's L1 may hold the rows of the window before, and tiles this workgroup read)
+            // The tile is the accumulator, and it lives in a128..a255 -- the registers that held the first half of the window, dead now --
+            // through the inline-asm statements of solo_pass_agpr.h: the register allocator never sees it, and the pass costs the
+            // measurement loop's register budget four pairs of operands (the landmark and the robot block stay where they are).
+            unsigned live_all = 0;
+            for (int m = 0; m < slot; m++) live_all |= (uni(L.sm[m].type) != SLOT_DEAD ? 1u : 0u) << (m >> 1);
+            live_all = (unsigned)uni((int)live_all);
+            const int npl = __builtin_popcount(live_all);
+            const int nT = (2 * n_lm + 63) >> 6, total = nT * (nT + 1) / 2;
+            const unsigned lo = (unsigned)((lane & 15) * 4 + (lane >> 4));
+            const unsigned voff = (unsigned)lane * 16u;
+            const size_t slot_stride = (size_t)rows_ * 4;
+            const int zero_slot = dv.maxpairs;
+            // (Requesting the operands of sweep s + 1 in front of the MFMAs of sweep s -- two compiler-managed buffers -- starves the
+            // register allocator of this kernel: 144 spills, the requests serialised through them, 6.27 M against 6.53 M filter-steps/s.)
+            if (npl > 0)
+                for (int u = wave; u < total; u += nwaves) {  // (uniform per wave)
+                    int I = 0;
+                    while ((I + 1) * nT - ((I + 1) * I) / 2 <= u) I++;
+                    const int J = I + (u - (I * nT - (I * (I - 1)) / 2));
+                    const bool diag = I == J;
+                    const size_t t = (size_t)I * T_ - ((size_t)I * (I - 1)) / 2 + (size_t)(J - I);
+                    double *tile = dv.Bm[buf_read] + (size_t)b * dv.bm_stride + t * 4096;  // (uniform)
+                    const double *FAt = FAc + (size_t)64 * I * 4, *FBt = FBc + (size_t)64 * J * 4;
+                    unsigned live = live_all;
+#pragma unroll
+                    for (int ch = 0; ch < 16; ch++) {
+                        if (diag && (ch & 3) < (ch >> 2)) continue;  // (a diagonal tile's chains below the diagonal are dead storage)
+                        pt_load(2 * ch, tile + ch * 256, voff);
+                        pt_load(2 * ch + 1, tile + ch * 256 + 128, voff);
+                    }
+#pragma unroll
+                    for (int sweep = 0; sweep < 4; sweep++) {
+                        if (sweep * 4 < npl) {  // (uniform)
+                            size_t mo[4];
+#pragma unroll
+                            for (int p = 0; p < 4; p++) {
+                                const int m = live ? __builtin_ctz(live) : zero_slot;
+                                live &= live - 1;
+                                mo[p] = (size_t)m * slot_stride;
+                            }
+                            double bq[4][4], a[4][4];
+#pragma unroll
+                            for (int p = 0; p < 4; p++)
+#pragma unroll
+                                for (int cc = 0; cc < 4; cc++) bq[p][cc] = (FBt + mo[p] + cc * 64)[lo];
+#pragma unroll
+                            for (int rc = 0; rc < 4; rc++)
+#pragma unroll
+                                for (int p = 0; p < 4; p++) a[rc][p] = (FAt + mo[p] + rc * 64)[lo];
+                            if (sweep == 0) pt_wait_loads();  // the tile (and, being younger, this sweep's operands) has arrived
+#pragma unroll
+                            for (int rc = 0; rc < 4; rc++)
+#pragma unroll
+                                for (int p = 0; p < 4; p++)
+#pragma unroll
+                                    for (int cc = 0; cc < 4; cc++) {
+                                        if (diag && cc < rc) continue;
+                                        pt_mfma(rc * 4 + cc, a[rc][p], bq[p][cc]);
+                                    }
+                        }
+                    }
+                    pt_settle();
+#pragma unroll
+                    for (int ch = 0; ch < 16; ch++) {
+                        if (diag && (ch & 3) < (ch >> 2)) continue;
+                        pt_store(2 * ch, tile + ch * 256, voff);
+                        pt_store(2 * ch + 1, tile + ch * 256 + 128, voff);
+                    }
+                }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tiles are back
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // (the next window reads P_LL entries: not from lines the L1 kept)
+        }
 #ifdef EKF_CHAIN_STAMPS
         if (tid == 0 && b == 0)
             for (int i = 0; i < 8; i++) dv.dbg[i] += stamp_acc[i], stamp_acc[i] = 0;

@@ -21,7 +21,7 @@ ABI_SYMBOLS = [
     "ekf_num_landmarks", "ekf_get_robot_cov", "ekf_get_x", "ekf_batch_propagate", "ekf_batch_propagate_q", "ekf_batch_update",
     "ekf_batch_update_compass", "ekf_batch_get_pose", "ekf_batch_num_landmarks", "ekf_get_state", "ekf_set_state",
     "ekf_broadcast_state", "ekf_script_load", "ekf_script_run", "ekf_sync", "ekf_flush", "ekf_close_window", "ekf_timer_start",
-    "ekf_timer_stop", "ekf_flush_profile", "ekf_flush_profile_read", "ekf_get_decisions", "ekf_get_stats",
+    "ekf_timer_stop", "ekf_flush_profile", "ekf_flush_profile_read", "ekf_fused_pass", "ekf_get_decisions", "ekf_get_stats",
     "ekf_reset_stats", "ekf_stats_means_device", "ekf_record_truth", "ekf_stream", "ekf_device_bytes",
 ]
 
@@ -77,6 +77,7 @@ def load():
     L.ekf_capacity.argtypes = [_H]
     L.ekf_window.argtypes = [_H]
     L.ekf_overlap.argtypes = [_H]
+    L.ekf_fused_pass.argtypes = [_H]
     L.ekf_propagate.argtypes = [_H, ctypes.c_double, ctypes.c_double, ctypes.c_double]
     L.ekf_propagate_q.argtypes = [_H, ctypes.c_double, ctypes.c_double, _dp, ctypes.c_double]
     L.ekf_update.argtypes = [_H, _dp, _dp, ctypes.c_int, ctypes.POINTER(EkfDecision)]
@@ -150,6 +151,7 @@ class FilterBatch:
         self.capacity = capacity_landmarks
         self.window = int(self.L.ekf_window(self.h))  # effective max_pending
         self.overlap = bool(self.L.ekf_overlap(self.h))
+        self.fused_pass = bool(self.L.ekf_fused_pass(self.h))
 
     def reserve(self, capacity_landmarks):
         """Grow the landmark capacity (ekf_reserve: the state moves to larger device buffers, the handle stays)."""
@@ -157,6 +159,7 @@ class FilterBatch:
         self.capacity = int(self.L.ekf_capacity(self.h))
         self.window = int(self.L.ekf_window(self.h))
         self.overlap = bool(self.L.ekf_overlap(self.h))
+        self.fused_pass = bool(self.L.ekf_fused_pass(self.h))
 
     def close(self):
         if self.h:

@@ -168,6 +168,13 @@ def roofline_record(pkg, f, workload, B, N, K, M, window, launches, flush_ms, al
         # every pass of the timed region against the whole timed region: what the headline cannot hide (the sequential chain
         # kernels, launch gaps, fill and drain all count as time in which HBM should have been busy)
         r["end_to_end_hbm_frac"] = launches * bytes_per_launch / elapsed / 1e9 / HBM_PEAK_GBS
+        if getattr(f, "fused_pass", False):
+            # one-workgroup filters with a long window fold their windows inside the chain kernel (k_solo<true>, ChainSeg::self_pass): there is
+            # no dense-pass launch to time.  `launches` counts the passes, the duration is that of the k_solo launches that contain them --
+            # measurement loops included -- so this fraction is a LOWER bound of the pass's own (the stamps build separates the two:
+            # DESIGN.md 4.1b); EKF_SOLO_FUSE=0 runs the passes as k_flush_rb launches again.
+            r["kernel"] = "k_solo<true>: measurement loop + its own dense pass (no separate pass launch; avg_launch_us is per window, loop included)"
+            r["fused_pass"] = True
     if alone_launches:
         a_s = alone_ms / 1e3 / alone_launches
         r["alone"] = {"avg_launch_us": a_s * 1e6, "achieved": bytes_per_launch / a_s / 1e9, "frac": bytes_per_launch / a_s / 1e9 / HBM_PEAK_GBS,
@@ -186,6 +193,8 @@ def roofline_record(pkg, f, workload, B, N, K, M, window, launches, flush_ms, al
                     continue
                 r["traffic"] = tj.get("hbm_bytes_per_launch")
                 r["traffic_source"] = "replayed from profiles/%s (separate rocprofv3 --pmc passes of these kernel sources, %s), not measured in this run" % (tname, have)
+                if getattr(f, "fused_pass", False):
+                    r["traffic_source"] += "; counted on the pass as a kernel of its own (EKF_SOLO_FUSE=0): the in-kernel pass issues the same tile and operand accesses"
                 break
     return r
 

@@ -183,6 +183,10 @@ int ekf_timer_stop(ekf_handle h, double *ms_out);
  * bracketed by hipEvents on the handle's stream. ekf_flush_profile_read synchronises. */
 int ekf_flush_profile(ekf_handle h, int enable);
 int ekf_flush_profile_read(ekf_handle h, long long *launches_out, double *total_ms_out);
+/* 1 when the handle's chain kernel folds the windows it fills into P_LL itself (maps of up to 256 landmarks, pass in place: one workgroup
+ * per filter, k_solo): there is no dense-pass launch to time then -- ekf_flush_profile_read counts the passes and reports the
+ * duration of the launches that contain them (measurement loops included). */
+int ekf_fused_pass(ekf_handle h);
 /* The last `count` decision-log entries of filter `index`, oldest first (synchronises). Returns the number written. */
 int ekf_get_decisions(ekf_handle h, int index, ekf_decision *out, int count);
 int ekf_get_stats(ekf_handle h, ekf_stats *out /*[batch]*/);

@@ -8,7 +8,10 @@ mkdir -p gpurun_out
 bash scripts/profile_r04.sh n4096_w16_overlap --steps 64 --warmup 8 || exit 1
 bash scripts/profile_r04.sh n4096_driver_command --steps 20 --warmup 5 || exit 1
 EKF_OVERLAP=0 bash scripts/profile_r04.sh n4096_w16_inplace --steps 64 --warmup 8 || exit 1
-bash scripts/profile_r04.sh batch256 --workload batch256 --steps 64 --warmup 8 || exit 1
+# the batch folds its windows inside k_solo<true> by default (no pass kernel to count): the HBM counters are taken on the pass as a
+# kernel of its own (EKF_SOLO_FUSE=0), the kernel trace of the default (fused) run beside it
+EKF_SOLO_FUSE=0 bash scripts/profile_r04.sh batch256 --workload batch256 --steps 64 --warmup 8 || exit 1
+bash scripts/profile_r04.sh batch256_fused --workload batch256 --steps 96 --warmup 8 || exit 1
 bash scripts/profile_r04.sh n1024 --workload n1024 --steps 64 --warmup 8 || exit 1
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/prof_r04_features && mkdir -p $R/gpurun_out/prof_r04_features

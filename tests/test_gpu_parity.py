@@ -1295,3 +1295,40 @@ def test_phase_groups_give_the_same_results(pkg, monkeypatch):
         assert np.array_equal(o[0][0], outs[0][0][0]) and np.array_equal(o[0][1], outs[0][0][1])
         for (xa, Pa), (xb, Pb) in zip(o[1], outs[0][1]):
             assert np.array_equal(xa, xb) and np.array_equal(Pa, Pb)
+
+
+@pytest.mark.parametrize("N,max_pending,steps", [(256, 32, 27), (200, 24, 20), (250, 31, 33)])
+def test_the_workgroups_own_dense_pass_equals_the_pass_kernel(pkg, monkeypatch, N, max_pending, steps):
+    """k_solo<true> folds a window it has filled into its own P_LL tiles before it goes on (ChainSeg::self_pass: the tile as accumulator
+    in the accumulation registers that held the window's first half, csrc/solo_pass_agpr.h); EKF_SOLO_FUSE=0 launches k_flush_rb between
+    the windows instead.  Same operands, same order of the pairs over every tile: the states are BITWISE equal -- on a full map (steady
+    script: whole windows and a partial last one) and over a lifecycle from an empty map (New landmarks, masked measurements)."""
+    monkeypatch.setenv("EKF_OVERLAP", "0")
+    M = 4
+    x0, P0 = pkg.scenarios.injected_state(N, seed=20260002)
+    sc = pkg.scenarios.steady_script(x0, steps=steps, M=M, seed=11)
+    script, ctrl, z, R, valid = lifecycle_as_script(pkg, 150, 3)
+    out = []
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("EKF_SOLO_FUSE", fuse)
+        f = pkg.FilterBatch(1, N, max_pending=max_pending)
+        assert f.fused_pass == (fuse == "1") and f.window == max_pending
+        f.set_state(x0, P0)
+        load_script(f, sc)
+        f.script_run(0, steps)
+        f.sync()
+        a = f.get_state()
+        f.close()
+        f = pkg.FilterBatch(1, N, max_pending=max_pending, log_capacity=1024)
+        f.script_load(ctrl, z, R, valid=valid)
+        f.script_run(0, 150)
+        f.sync()
+        b = f.get_state()
+        d = f.decisions(0, min(900, sum(int(v) for v in valid[:, :, 0].ravel())))
+        f.close()
+        out.append((a, b, d))
+    (a1, b1, d1), (a0, b0, d0) = out
+    assert np.array_equal(a1[0], a0[0]) and np.array_equal(a1[1], a0[1])
+    assert np.array_equal(b1[0], b0[0]) and np.array_equal(b1[1], b0[1])
+    assert [(d[0], d[1], d[2]) for d in d1] == [(d[0], d[1], d[2]) for d in d0]
+
