@@ -760,66 +760,86 @@ __global__ __launch_bounds__(256) void k_solo(EkfDev dv, const double *in, const
             for (int m = 0; m < slot; m++) live_all |= (uni(L.sm[m].type) != SLOT_DEAD ? 1u : 0u) << (m >> 1);
             live_all = (unsigned)uni((int)live_all);
             const int npl = __builtin_popcount(live_all);
-            const int nT = (2 * n_lm + 63) >> 6, total = nT * (nT + 1) / 2;
+            const int nT = (2 * n_lm + 63) >> 6;
             const unsigned lo = (unsigned)((lane & 15) * 4 + (lane >> 4));
             const unsigned voff = (unsigned)lane * 16u;
             const size_t slot_stride = (size_t)rows_ * 4;
             const int zero_slot = dv.maxpairs;
-            // (Requesting the operands of sweep s + 1 in front of the MFMAs of sweep s -- two compiler-managed buffers -- starves the
-            // register allocator of this kernel: 144 spills, the requests serialised through them, 6.27 M against 6.53 M filter-steps/s.)
+            // One wave per SIMD: nothing but the wave itself hides a memory trip, and a tile is 6.8 us of MFMAs between trips for its
+            // operands.  Fewer trips: a wave owns whole tile ROWS (row r and row nT - 1 - r together hold nT + 1 tiles: four waves, eight
+            // rows, nine tiles each), the A operands of its current row -- sixteen pairs x 64 rows, 32 KiB -- wait in LDS (the own-row
+            // cache is dead while the pass runs, and exactly that large per wave; they arrive by LDS-DMA, no register), and the B operands
+            // come eight pairs at a time: two trips per tile instead of four.  (The pairs still go over every chain in ascending order:
+            // bitwise the pass kernel's result.)
+            double *const stage = own_rows + (size_t)wave * 4096;  // [pair of the walk through live: 0..15][row-block 0..3][64]
+            const int np8 = (npl + 7) & ~7;                          // pairs the sweeps cover (the all-zero pair behind the live ones)
             if (npl > 0)
-                for (int u = wave; u < total; u += nwaves) {  // (uniform per wave)
-                    int I = 0;
-                    while ((I + 1) * nT - ((I + 1) * I) / 2 <= u) I++;
-                    const int J = I + (u - (I * nT - (I * (I - 1)) / 2));
-                    const bool diag = I == J;
-                    const size_t t = (size_t)I * T_ - ((size_t)I * (I - 1)) / 2 + (size_t)(J - I);
-                    double *tile = dv.Bm[buf_read] + (size_t)b * dv.bm_stride + t * 4096;  // (uniform)
-                    const double *FAt = FAc + (size_t)64 * I * 4, *FBt = FBc + (size_t)64 * J * 4;
-                    unsigned live = live_all;
-#pragma unroll
-                    for (int ch = 0; ch < 16; ch++) {
-                        if (diag && (ch & 3) < (ch >> 2)) continue;  // (a diagonal tile's chains below the diagonal are dead storage)
-                        pt_load(2 * ch, tile + ch * 256, voff);
-                        pt_load(2 * ch + 1, tile + ch * 256 + 128, voff);
-                    }
-#pragma unroll
-                    for (int sweep = 0; sweep < 4; sweep++) {
-                        if (sweep * 4 < npl) {  // (uniform)
-                            size_t mo[4];
-#pragma unroll
-                            for (int p = 0; p < 4; p++) {
-                                const int m = live ? __builtin_ctz(live) : zero_slot;
-                                live &= live - 1;
-                                mo[p] = (size_t)m * slot_stride;
+                for (int rp = wave; rp < (nT + 1) / 2; rp += nwaves) {  // (uniform per wave)
+                    for (int half = 0; half < 2; half++) {
+                        const int I = half == 0 ? rp : nT - 1 - rp;
+                        if (half == 1 && I == rp) break;  // (the middle row of an odd count)
+                        {   // the row's A operands -> LDS
+                            asm volatile("" ::: "memory");
+                            unsigned lv = live_all;
+                            for (int q = 0; q < np8; q++) {
+                                const int m = lv ? __builtin_ctz(lv) : zero_slot;
+                                lv &= lv - 1;
+                                const double *src = FAc + (size_t)m * slot_stride + (size_t)64 * I * 4 + (size_t)lane * 2;
+                                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src, (__attribute__((address_space(3))) void *)(stage + q * 256), 16, 0, 0);
+                                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 128), (__attribute__((address_space(3))) void *)(stage + q * 256 + 128), 16, 0, 0);
                             }
-                            double bq[4][4], a[4][4];
-#pragma unroll
-                            for (int p = 0; p < 4; p++)
-#pragma unroll
-                                for (int cc = 0; cc < 4; cc++) bq[p][cc] = (FBt + mo[p] + cc * 64)[lo];
-#pragma unroll
-                            for (int rc = 0; rc < 4; rc++)
-#pragma unroll
-                                for (int p = 0; p < 4; p++) a[rc][p] = (FAt + mo[p] + rc * 64)[lo];
-                            if (sweep == 0) pt_wait_loads();  // the tile (and, being younger, this sweep's operands) has arrived
-#pragma unroll
-                            for (int rc = 0; rc < 4; rc++)
-#pragma unroll
-                                for (int p = 0; p < 4; p++)
-#pragma unroll
-                                    for (int cc = 0; cc < 4; cc++) {
-                                        if (diag && cc < rc) continue;
-                                        pt_mfma(rc * 4 + cc, a[rc][p], bq[p][cc]);
-                                    }
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                         }
-                    }
-                    pt_settle();
+                        for (int J = I; J < nT; J++) {
+                            const bool diag = I == J;
+                            const size_t t = (size_t)I * T_ - ((size_t)I * (I - 1)) / 2 + (size_t)(J - I);
+                            double *tile = dv.Bm[buf_read] + (size_t)b * dv.bm_stride + t * 4096;  // (uniform)
+                            const double *FBt = FBc + (size_t)64 * J * 4;
+                            unsigned live = live_all;
 #pragma unroll
-                    for (int ch = 0; ch < 16; ch++) {
-                        if (diag && (ch & 3) < (ch >> 2)) continue;
-                        pt_store(2 * ch, tile + ch * 256, voff);
-                        pt_store(2 * ch + 1, tile + ch * 256 + 128, voff);
+                            for (int ch = 0; ch < 16; ch++) {
+                                if (diag && (ch & 3) < (ch >> 2)) continue;  // (a diagonal tile's chains below the diagonal are dead storage)
+                                pt_load(2 * ch, tile + ch * 256, voff);
+                                pt_load(2 * ch + 1, tile + ch * 256 + 128, voff);
+                            }
+#pragma unroll
+                            for (int sweep = 0; sweep < 2; sweep++) {
+                                if (sweep * 8 < npl) {  // (uniform)
+                                    double bq[8][4];
+#pragma unroll
+                                    for (int p = 0; p < 8; p++) {
+                                        const int m = live ? __builtin_ctz(live) : zero_slot;
+                                        live &= live - 1;
+                                        const size_t mo = (size_t)m * slot_stride;
+#pragma unroll
+                                        for (int cc = 0; cc < 4; cc++) bq[p][cc] = (FBt + mo + cc * 64)[lo];
+                                    }
+                                    if (sweep == 0) pt_wait_loads();  // the tile (and, being younger, this sweep's operands) has arrived
+                                    const double *As = stage + (size_t)sweep * 8 * 256 + lo;
+                                    double a_cur = As[0];
+#pragma unroll
+                                    for (int rc = 0; rc < 4; rc++)
+#pragma unroll
+                                        for (int p = 0; p < 8; p++) {
+                                            const int nxt = rc * 8 + p + 1;  // (the next A element leaves LDS under this one's MFMAs)
+                                            const double a_nxt = nxt < 32 ? As[(nxt & 7) * 256 + (nxt >> 3) * 64] : 0.0;
+#pragma unroll
+                                            for (int cc = 0; cc < 4; cc++) {
+                                                if (diag && cc < rc) continue;
+                                                pt_mfma(rc * 4 + cc, a_cur, bq[p][cc]);
+                                            }
+                                            a_cur = a_nxt;
+                                        }
+                                }
+                            }
+                            pt_settle();
+#pragma unroll
+                            for (int ch = 0; ch < 16; ch++) {
+                                if (diag && (ch & 3) < (ch >> 2)) continue;
+                                pt_store(2 * ch, tile + ch * 256, voff);
+                                pt_store(2 * ch + 1, tile + ch * 256 + 128, voff);
+                            }
+                        }
                     }
                 }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tiles are back
