@@ -422,7 +422,9 @@ static int create_impl(ekf_batch *h, int batch, int capacity_landmarks, int devi
     dv.f_stride = (size_t)(dv.maxpairs + 1) * dv.rows * 4;
     dv.vs_cap = cache_slots;
     h->solo_long = h->solo_kernel && maxp > cache_slots;
-    h->solo_fuse = h->solo_long && (getenv("EKF_SOLO_FUSE") ? atoi(getenv("EKF_SOLO_FUSE")) != 0 : true);  // (k_solo<true>: its pass tile lives in the registers of the window's first half)
+    // (the tile of the in-kernel pass lives in a128..a255 -- the registers of a long window's first half, free otherwise --, the A operands of
+    // a tile row in the own-row cache, dead while the pass runs: 2 KiB per pair and wave -- 8 or 16 pairs -- against 2 KiB per cached slot)
+    h->solo_fuse = h->solo_kernel && cache_slots >= ((((maxp + 1) >> 1) + 7) & ~7) && (getenv("EKF_SOLO_FUSE") ? atoi(getenv("EKF_SOLO_FUSE")) != 0 : true);
     h->chain_lds = (size_t)lpw64 * cache_slots * 32;
     HIP_TRY(hipFuncSetAttribute((const void *)k_chain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_budget));  // one setting for every handle
     HIP_TRY(hipFuncSetAttribute((const void *)k_solo<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_budget));

@@ -145,8 +145,8 @@ __global__ __launch_bounds__(256) void k_solo(EkfDev dv, const double *in, const
     const int C = vs_cap;       // slots the own-row cache holds; the window (dv.maxp) may be up to twice that (SOLO_HALF = C then)
     // this landmark's rows of slots [0, C) once the window is in its second half (slot >= C): accumulation registers a128..a255,
     // explicit (solo_agpr.h: oh_set / oh_get with static slot numbers)
+    oh_reserve();  // (both instantiations: the tile of the workgroup's own dense pass lives in the same registers, solo_pass_agpr.h)
     if (LONG) {
-        oh_reserve();
 #pragma unroll
         for (int q = 0; q < SOLO_HALF; q++) oh_set(q, 0.0, 0.0, 0.0, 0.0);
     }
@@ -749,7 +749,7 @@ __global__ __launch_bounds__(256) void k_solo(EkfDev dv, const double *in, const
         // (k_flush_rb's whole-tile form).  No second kernel, no launch gaps, the landmark and the robot block stay in registers across
         // windows -- and the filters of a batch drift apart in phase (ChainSeg::stagger), so that while some stream their tiles the
         // others run their latency-bound measurement loops: HBM sees a steady third of the traffic instead of bursts of all of it.
-        if constexpr (LONG) if (self_pass) {
+        if (self_pass) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's slot rows have left
             __syncthreads();                                  // ... everybody's have
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // (the CU's L1 may hold the rows of the window before, and tiles this workgroup read)
@@ -771,7 +771,9 @@ __global__ __launch_bounds__(256) void k_solo(EkfDev dv, const double *in, const
             // cache is dead while the pass runs, and exactly that large per wave; they arrive by LDS-DMA, no register), and the B operands
             // come eight pairs at a time: two trips per tile instead of four.  (The pairs still go over every chain in ascending order:
             // bitwise the pass kernel's result.)
-            double *const stage = own_rows + (size_t)wave * 4096;  // [pair of the walk through live: 0..15][row-block 0..3][64]
+            // (2 KiB per pair and wave; the host asks for self_pass only where the cache -- 2 KiB per slot and wave -- has that room)
+            const int np8cap = (((dv.maxp + 1) >> 1) + 7) & ~7;  // pairs a full window can hold, in whole sweeps: 8 or 16
+            double *const stage = own_rows + (size_t)wave * np8cap * 256;  // [pair of the walk through live][row-block 0..3][64]
             const int np8 = (npl + 7) & ~7;                          // pairs the sweeps cover (the all-zero pair behind the live ones)
             if (npl > 0)
                 for (int rp = wave; rp < (nT + 1) / 2; rp += nwaves) {  // (uniform per wave)

@@ -54,7 +54,7 @@ def main():
         m = re.match(r"^(_Z\w+):", l)
         if m:
             func = m.group(1)
-        if func is None or "k_soloILb1" not in func or re.match(r"^\s*\.", l):  # (k_solo<true>: the instantiation that uses solo_agpr.h)
+        if func is None or "k_solo" not in func or re.match(r"^\s*\.", l):  # (both instantiations: the tile of the in-kernel pass lives there too)
             continue
         for m in re.finditer(r"\ba\[?(\d+)(?::(\d+))?\]?", l):
             hi = int(m.group(2) or m.group(1))

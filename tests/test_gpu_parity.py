@@ -1297,9 +1297,9 @@ def test_phase_groups_give_the_same_results(pkg, monkeypatch):
             assert np.array_equal(xa, xb) and np.array_equal(Pa, Pb)
 
 
-@pytest.mark.parametrize("N,max_pending,steps", [(256, 32, 27), (200, 24, 20), (250, 31, 33)])
+@pytest.mark.parametrize("N,max_pending,steps", [(256, 32, 27), (200, 24, 20), (250, 31, 33), (256, 16, 19), (50, 16, 30), (100, 32, 21), (120, 9, 13), (64, 8, 11)])
 def test_the_workgroups_own_dense_pass_equals_the_pass_kernel(pkg, monkeypatch, N, max_pending, steps):
-    """k_solo<true> folds a window it has filled into its own P_LL tiles before it goes on (ChainSeg::self_pass: the tile as accumulator
+    """k_solo folds a window it has filled into its own P_LL tiles before it goes on (ChainSeg::self_pass: the tile as accumulator
     in the accumulation registers that held the window's first half, csrc/solo_pass_agpr.h); EKF_SOLO_FUSE=0 launches k_flush_rb between
     the windows instead.  Same operands, same order of the pairs over every tile: the states are BITWISE equal -- on a full map (steady
     script: whole windows and a partial last one) and over a lifecycle from an empty map (New landmarks, masked measurements)."""
@@ -1312,7 +1312,7 @@ def test_the_workgroups_own_dense_pass_equals_the_pass_kernel(pkg, monkeypatch, 
     for fuse in ("1", "0"):
         monkeypatch.setenv("EKF_SOLO_FUSE", fuse)
         f = pkg.FilterBatch(1, N, max_pending=max_pending)
-        assert f.fused_pass == (fuse == "1") and f.window == max_pending
+        assert f.fused_pass == (fuse == "1") and f.window == max_pending  # (long windows: k_solo<true>; windows of 8 to 16 and small maps: k_solo<false>)
         f.set_state(x0, P0)
         load_script(f, sc)
         f.script_run(0, steps)
