@@ -110,7 +110,8 @@ __device__ __forceinline__ void solo_nees_sample(const SoloRobot &R, const doubl
 }
 
 // grid (1, filters of the launch), blockDim = 64 * ceil(capacity / 64) <= 256 threads; arguments as k_chain's (segments with
-// n_prev = 0, need_pass = 0, drop = 0: one slot set, dense passes in place between the launches that fill a window).
+// n_prev = 0, need_pass = 0, drop = 0: one slot set; a segment that fills its window folds it itself when ChainSeg::self_pass says so,
+// else the host launches k_flush_rb in place between the launches).
 // LONG: the window may be longer than the own-row cache (its first half then lives in accumulation registers, solo_agpr.h); the
 // host launches k_solo<true> only for such handles -- windows the cache holds run the kernel without any of that code.
 template <bool LONG>
