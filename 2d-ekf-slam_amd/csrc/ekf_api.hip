@@ -270,7 +270,7 @@ static void read_debug_hooks(ekf_batch *h) {
 extern "C" int ekf_destroy(ekf_handle h);
 
 extern "C" int ekf_batch_create(ekf_handle *out, int batch, int capacity_landmarks, int device_id, const ekf_params *params) {
-    if (!out || batch < 1 || capacity_landmarks < 1 || capacity_landmarks > 16000) return set_error(EKF_ERR_BAD_ARG, "bad batch/capacity");
+    if (!out || batch < 1 || capacity_landmarks < 1 || capacity_landmarks > EKF_MAX_CAPACITY) return set_error(EKF_ERR_BAD_ARG, "bad batch/capacity");
     *out = nullptr;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -688,7 +688,11 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 // ... and a blocking wait in the runtime is never entered at all: once in a few dozen waits of several milliseconds the wake-up
 // came 4-10 ms late on the gpurun boxes (scripts/r04_stall_hunt.py: hipEventSynchronize returned 10-16 ms after the start of a
 // 6.9 ms region; the driver's box showed 54 ms once), which is what a robot loop must not see.  So: spin on the query for 2 ms
-// (short waits: no system call), then keep querying with 20 us naps (one core mostly asleep, wake-up bounded by the nap).
+// (short waits: no system call), then keep querying between naps (one core mostly asleep, wake-up bounded by the nap).
+// The naps back off with the length of the wait -- 20 us up to 10 ms (with the kernel's default 50 us timer slack a nap really lasts
+// about 70 us), 100 us up to 100 ms, 1 ms beyond: with eight ranks on a host and waits of many milliseconds (ekf_sync at the end of a
+// timed region, ekf_reserve) a rank wakes its host thread a few thousand times per second at most instead of tens of thousands, a
+// wait of a second costs about a thousand queries, and a hung GPU is polled a thousand times per second, not spun on.
 template <typename Query>
 static hipError_t poll_wait(Query query) {
     timespec t0, t1;
@@ -702,10 +706,12 @@ static hipError_t poll_wait(Query query) {
         }
         __builtin_ia32_pause();
     }
-    const timespec nap = {0, 20000};
     for (;;) {
         hipError_t e = query();
         if (e != hipErrorNotReady) return e;
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        const long waited_us = (t1.tv_sec - t0.tv_sec) * 1000000L + (t1.tv_nsec - t0.tv_nsec) / 1000L;
+        const timespec nap = {0, waited_us < 10000L ? 20000L : (waited_us < 100000L ? 100000L : 1000000L)};
         nanosleep(&nap, nullptr);
     }
 }
@@ -1586,7 +1592,7 @@ extern "C" int ekf_set_state(ekf_handle h, int index, const double *x, const dou
 // moves over on the device (k_export into a dense staging matrix, k_import from it: the tile numbering depends on the capacity),
 // the counters, the decision log and a loaded script move with it, and the handle keeps its address.
 extern "C" int ekf_reserve(ekf_handle h, int capacity_landmarks) {
-    if (!h || capacity_landmarks < 1 || capacity_landmarks > 16000) return set_error(EKF_ERR_BAD_ARG, "bad handle / capacity");
+    if (!h || capacity_landmarks < 1 || capacity_landmarks > EKF_MAX_CAPACITY) return set_error(EKF_ERR_BAD_ARG, "bad handle / capacity (EKF_MAX_CAPACITY)");
     if (capacity_landmarks <= h->dv.Ncap) return EKF_OK;
     HIP_TRY(hipSetDevice(h->device));
     int rc = settle(h);  // every deferred slot folded, both streams idle
@@ -1598,11 +1604,12 @@ extern "C" int ekf_reserve(ekf_handle h, int capacity_landmarks) {
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, h->device));
     // the old buffers are idle from here on and will not launch again: their CUs are free for the new handle's residency check
-    const int had_claimed = h->claimed_cus;
+    const int had_claimed = h->claimed_cus, had_solo = h->solo_cus;
     {
         std::lock_guard<std::mutex> lk(g_res_mu);
         g_cus_claimed[h->device] -= had_claimed;
-        h->claimed_cus = 0;
+        g_cus_solo[h->device] -= had_solo;  // (not counted twice while both sets of buffers are alive)
+        h->claimed_cus = 0, h->solo_cus = 0;
     }
     ekf_batch *nh = new ekf_batch();
     nh->device = h->device;
@@ -1613,8 +1620,8 @@ extern "C" int ekf_reserve(ekf_handle h, int capacity_landmarks) {
         (void)hipGetLastError();
         g_last_error = keep;
         std::lock_guard<std::mutex> lk(g_res_mu);
-        g_cus_claimed[h->device] += had_claimed;
-        h->claimed_cus = had_claimed;
+        g_cus_claimed[h->device] += had_claimed, g_cus_solo[h->device] += had_solo;
+        h->claimed_cus = had_claimed, h->solo_cus = had_solo;
         return rc;
     }
     hipError_t e = hipSuccess;
@@ -1647,8 +1654,8 @@ extern "C" int ekf_reserve(ekf_handle h, int capacity_landmarks) {
         ekf_destroy(nh);
         (void)hipGetLastError();
         std::lock_guard<std::mutex> lk(g_res_mu);
-        g_cus_claimed[h->device] += had_claimed;
-        h->claimed_cus = had_claimed;
+        g_cus_claimed[h->device] += had_claimed, g_cus_solo[h->device] += had_solo;
+        h->claimed_cus = had_claimed, h->solo_cus = had_solo;
         return set_error(EKF_ERR_HIP, keep.c_str());
     }
     for (int b = 0; b < B; b++) {  // the host mirror's newest decisions and counters (ekf_get_stats / the compat shim read them there)
@@ -1658,6 +1665,23 @@ extern "C" int ekf_reserve(ekf_handle h, int capacity_landmarks) {
     nh->stats_in_mirror = h->stats_in_mirror;
     nh->n_lm_hi = h->n_lm_hi;
     nh->prof_flush = h->prof_flush;
+    // What a caller may hold across the growth keeps working: an open timer (events are time stamps: t0 recorded on the old buffers'
+    // stream pairs with a t1 recorded later), the dense-pass profile collected so far (event pairs and sums), and the stream
+    // ekf_stream() handed out -- both chain streams are idle here, so the two handles simply trade them (and every alias of them).
+    std::swap(nh->t0, h->t0);
+    std::swap(nh->t1, h->t1);
+    nh->prof_pool.swap(h->prof_pool);
+    nh->prof_used = h->prof_used, h->prof_used = 0;
+    nh->prof_ms = h->prof_ms, nh->prof_launches = h->prof_launches;
+    nh->prof_fused_passes = h->prof_fused_passes, nh->prof_solo_pairs = h->prof_solo_pairs;
+    {
+        const hipStream_t s_new = nh->s_chain, s_old = h->s_chain;
+        if (nh->s_flush == s_new) nh->s_flush = s_old;
+        if (h->s_flush == s_old) h->s_flush = s_new;
+        if (!nh->s_grp.empty() && nh->s_grp[0] == s_new) nh->s_grp[0] = s_old;
+        if (!h->s_grp.empty() && h->s_grp[0] == s_old) h->s_grp[0] = s_new;
+        nh->s_chain = s_old, h->s_chain = s_new;
+    }
     // a loaded script is laid out per (operation, filter): independent of the capacity
     std::swap(nh->script_d, h->script_d);
     nh->script_steps = h->script_steps, nh->script_M = h->script_M, nh->script_has_truth = h->script_has_truth;

@@ -724,7 +724,16 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
     } else if (drop > 0) {
         new_mask >>= drop;
     }
-    if (worker && seg == 0) {
+    // Only a measurement ever READS the own-row cache (fold, published rows); Propagate, compass, truth samples and masked slots at
+    // most write their own slot into it.  A launch of a few operations without a measurement -- every doPropagation /
+    // doUpdateCompass of the reference's call pattern (slam.cpp:136,146) -- therefore skips the refill (nothing later in the launch
+    // could miss it: one segment only).  The scan is a handful of LDS reads, so it is only made for launches that short.
+    bool need_cache = true;
+    if (nseg == 1 && nops <= 4) {
+        need_cache = false;
+        for (int q = 0; q < nops; q++) need_cache = need_cache || uni((int)recs[q * 8 + 7]) == OP_MEAS;
+    }
+    if (worker && seg == 0 && need_cache) {
         // eight slots per trip, every load requested before the first LDS write (a dead slot's rows are zeros in HBM too)
         const int n_now = dv.n_lm[b];
         const int hi = own_hi < n_now ? own_hi : n_now;

@@ -272,7 +272,14 @@ __global__ __launch_bounds__(256) void k_solo(EkfDev dv, const double *in, const
             for (int q = 0; q < slot0; q++) new_mask |= (uni(L.sm[q].type) == SLOT_NEW ? 1ull : 0ull) << q;
             // (a launch that continues a window in its second half finds slots [0, C) in registers, [C, slot0) in the cache)
             const int c_lo = LONG && slot0 > C ? C : 0;
-            if (lm0 < n_lm)
+            // only a measurement reads the cached rows (k_chain: need_cache): a short launch without one -- a doPropagation or
+            // doUpdateCompass call -- does not fetch them (one segment only, so nothing later in the launch could miss them)
+            bool need_cache = true;
+            if (nseg == 1 && nops <= 4) {
+                need_cache = false;
+                for (int q = 0; q < nops; q++) need_cache = need_cache || uni((int)recs[q * 8 + 7]) == OP_MEAS;
+            }
+            if (lm0 < n_lm && need_cache)
                 for (int v0 = c_lo; v0 < slot0; v0 += 8) {  // eight slots per trip, every load requested before the first LDS write
                     double2_t lo2[8], hi2[8];
 #pragma unroll
@@ -288,7 +295,7 @@ __global__ __launch_bounds__(256) void k_solo(EkfDev dv, const double *in, const
                             *(double2_t *)cr = lo2[j], *(double2_t *)(cr + 128) = hi2[j];
                         }
                 }
-            if (LONG && slot0 > C && lm0 < n_lm) {
+            if (LONG && slot0 > C && lm0 < n_lm && need_cache) {
 #pragma unroll
                 for (int vs = 0; vs < SOLO_HALF; vs++) {
                     const double *F = ((new_mask >> vs) & 1 ? FAb : FBb) + off_c + pair_offset(rows_, 2 * lm0, vs >> 1) + (vs & 1) * 2;

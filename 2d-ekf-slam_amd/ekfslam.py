@@ -330,12 +330,28 @@ class FilterBatch:
         return self.L.ekf_device_bytes(self.h)
 
 
+MAX_CAPACITY = 16000  # EKF_MAX_CAPACITY of include/ekfslam_c.h
+
+
+def grown_capacity(cap, need, limit=MAX_CAPACITY):
+    """The capacity asked for when `need` landmarks no longer fit `cap` (compat/kalmanfilter.h: grown_capacity): double, but never
+    beyond what the library can hold -- only a map that really needs more than `limit` fails (ekf_reserve then says so)."""
+    want = max(2 * cap, need)
+    if want > limit and need <= limit:
+        want = limit
+    return want
+
+
 class KalmanFilter:
     """Python mirror of the reference's class KalmanFilter (odometry/kalmanfilter.h:21-43): same public
     members X, Y, Phi, Num_Landmarks and the same three methods, forwarding to the C ABI.  The ARIA
     velocity reads of doPropagation (kalmanfilter.cpp:17-20) become the v_mm_s / rotvel_deg_s arguments."""
 
     def __init__(self, capacity_landmarks=1024, device=0, print_decisions=False, **params):
+        # one synchronising call per operation (the mirrors must be current after each): no dense pass ever runs beside a chain
+        # kernel, so the in-place pipeline is the faster one for this class (compat/kalmanfilter.h does the same); overlap=-1 / 1
+        # can still be asked for
+        params.setdefault("overlap", 0)
         self._f = FilterBatch(1, capacity_landmarks, device, **params)
         self.X = self.Y = self.Phi = 0.0
         self.Num_Landmarks = 0
@@ -360,7 +376,7 @@ class KalmanFilter:
         Rm = np.asarray(R_chunk, dtype=np.float64).reshape(2, 2 * n_z)
         R = np.stack([Rm[:, 2 * j:2 * j + 2] for j in range(n_z)])
         if self.Num_Landmarks + n_z > self._f.capacity:  # the reference's state grows without bound (Update.cpp:158-177): make room first
-            self._f.reserve(max(2 * self._f.capacity, self.Num_Landmarks + n_z))
+            self._f.reserve(grown_capacity(self._f.capacity, self.Num_Landmarks + n_z))
         self.last_decisions = self._f.update(z.T.reshape(1, n_z, 2), R.reshape(1, n_z, 2, 2))[0]
         if self.Print_Decisions:
             import sys

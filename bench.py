@@ -194,7 +194,12 @@ def roofline_record(pkg, f, workload, B, N, K, M, window, launches, flush_ms, al
                 r["traffic"] = tj.get("hbm_bytes_per_launch")
                 r["traffic_source"] = "replayed from profiles/%s (separate rocprofv3 --pmc passes of these kernel sources, %s), not measured in this run" % (tname, have)
                 if getattr(f, "fused_pass", False):
-                    r["traffic_source"] += "; counted on the pass as a kernel of its own (EKF_SOLO_FUSE=0): the in-kernel pass issues the same tile and operand accesses"
+                    # the counters were taken on k_flush_rb (EKF_SOLO_FUSE=0), the binary measured here folds inside k_solo: same tiles, but the
+                    # in-kernel pass stages a tile row's A operands ONCE per row (LDS-DMA) and walks the exact landmark count, so it re-reads
+                    # fewer operand bytes than the pass kernel: the replayed figure is an UPPER bound for this run
+                    r["traffic_is_upper_bound"] = True
+                    r["traffic_source"] += ("; counted on the pass as a kernel of its own (EKF_SOLO_FUSE=0): an UPPER BOUND for the in-kernel pass measured here, "
+                                            "which fetches a tile row's A operands once per row instead of once per tile")
                 break
     return r
 
@@ -352,6 +357,51 @@ def immediate_leg(pkg, dev_id):
     return out
 
 
+def propagate_only_leg(pkg, dev_id, K=2048, W=64):
+    """BASELINE.json config 3's "roofline for propagate" (Propagate.cpp:15-75, the row update of :53-60): K scripted steps with NO
+    measurement (M = 0) at N = 4096 and N = 1024.  Propagate touches the 3x3 robot block and the three robot rows only --
+    72 n - 72 algorithmic bytes per step (590 KB at N = 4096: about 0.07 us of HBM time) -- and the chain kernel keeps
+    those rows in registers across the steps of a launch, so the record is a LATENCY figure (dependent fp64 arithmetic of the robot
+    block, sincos, one workgroup barrier per step), not a bandwidth one: `bound` says so, the GB/s figure is there to show how far
+    from a bandwidth question this is.  The pose after K steps is checked against the motion model of Propagate.cpp:33-38."""
+    import math
+    import numpy as np
+    out = {"unit": "us per step (1 Propagate, no measurement)", "reference": "odometry/Propagate.cpp:15-75", "bound": "latency",
+           "byte_model": "72 n - 72 bytes per step: rows 0..2 of P read, rows and columns 0..2 written (SURVEY.md 8d)"}
+    for name in ("n4096", "n1024"):
+        N, _, _, _, seed, extent, _ = WORKLOADS[name]
+        x0, P0 = pkg.scenarios.injected_state(N, seed=seed, extent=extent)
+        f = pkg.FilterBatch(1, N, device=dev_id)
+        f.set_state(x0, P0)
+        del P0
+        v, w, dt = 0.3, 0.05, 0.05
+        ctrl = np.tile(np.array([v, w, dt]), (W + K, 1, 1))
+        f.script_load(ctrl, np.zeros((W + K, 0, 1, 2)), np.zeros((W + K, 0, 1, 4)))
+        f.script_run(0, W)
+        f.sync()
+        t0 = time.perf_counter()
+        f.timer_start()
+        f.script_run(W, K)
+        f.flush()
+        dev_ms = f.timer_stop()
+        f.sync()
+        el = time.perf_counter() - t0
+        pose = f.poses()[0]
+        want = np.array(x0[:3], dtype=np.float64)
+        for _ in range(W + K):  # Propagate.cpp:33-38, no angle wrap
+            want = want + dt * np.array([v * math.cos(want[2]), v * math.sin(want[2]), w])
+        n = 3 + 2 * N
+        nbytes = 72 * n - 72
+        us = el / K * 1e6
+        out[name] = {"N": N, "steps": K, "warmup": W, "us_per_step": us, "device_us_per_step": dev_ms / K * 1e3, "steps_per_s": K / el,
+                     "overlap": int(f.overlap), "algorithmic_bytes_per_step": nbytes, "achieved_GBs": nbytes / (us * 1e-6) / 1e9,
+                     "frac_of_hbm_peak": nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                     "pose_max_abs_err_vs_motion_model": float(np.abs(pose - want).max())}
+        assert out[name]["pose_max_abs_err_vs_motion_model"] < 1e-9, out[name]
+        f.close()
+    return out
+
+
 def config1_leg(pkg, dev_id):
     """BASELINE.json config 1 as stated: one robot, N = 50 landmarks, 1000 steps of synthetic odometry + range/bearing
     measurements (seed 20260001) from x = 0_3, P = 0 (kalmanfilter.cpp:4-12): the GPU as one scripted run, the faithful-dense
@@ -427,6 +477,13 @@ def secondary_in_a_child(args, dev_id):
     return {"error": "the secondary legs ended with rc %d: %s" % (p.returncode, p.stderr[-400:])}
 
 
+def runs_cpu_baseline(rank, world, no_cpu_baseline=False):
+    """The CPU legs (14 s of single-thread faithful-dense work and the OpenMP structured leg) are timed by rank 0 of a ONE-rank run
+    only: a multi-rank launch -- the driver's scaling runs -- must not start N single-thread CPU jobs beside its GPU ranks (nor one:
+    the scaling records are about the GPUs; the baseline rides on the N = 1 line)."""
+    return world == 1 and rank == 0 and not no_cpu_baseline
+
+
 def dry_run(args, rank, world, ekf_env):
     """--dry-run: what a multi-rank run does AROUND the GPU work -- rendezvous, shard_range of both config-5 legs, the equal-size
     all-gather with NaN padding, the max-over-ranks reduction, one line from rank 0 -- on synthetic rows tagged by global filter
@@ -458,6 +515,14 @@ def dry_run(args, rank, world, ekf_env):
         if not ok:
             raise SystemExit("rank %d: the gathered rows of the %s leg are not in global filter order" % (rank, leg))
         c5[leg] = {"filters_total": total, "filters_per_gpu": hi - lo, "value": None, "gathered_rows": int(out.shape[0]), "gather_ms": el * 1e3}
+    # which ranks would time the CPU baselines in a real run of this shape (gathered so that the test sees every rank's answer)
+    mine = 1.0 if runs_cpu_baseline(rank, world, args.no_cpu_baseline) else 0.0
+    cpu_ranks = [mine]
+    if world > 1:
+        tl = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(tl, torch.tensor([mine], dtype=torch.float64))
+        cpu_ranks = [float(t.item()) for t in tl]
+    c5["cpu_baseline_ranks"] = [r for r, v in enumerate(cpu_ranks) if v > 0]
     if rank == 0:
         print(json.dumps({"metric": "EKF steps/sec (propagate+full update) at N landmarks", "value": None, "unit": "steps/s", "n_gpus": world,
                           "steps": 0, "warmup": 0, "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -515,8 +580,12 @@ def main():
     ap.add_argument("--config5-steps", type=int, default=None, help="timed steps of the config-5 legs (default: the batch256 workload's 200)")
     ap.add_argument("--secondary-only", action="store_true", help="(internal) run only the secondary records and print them: bench.py starts itself this way as a child, so that a fault or a hang in a secondary leg cannot cost the headline")
     ap.add_argument("--secondary-budget", type=float, default=420.0, help="wall-clock limit in seconds of the child that measures the secondary records")
+    ap.add_argument("--cpu-structured-child", action="store_true", help="(internal) one timed run of the structured CPU oracle in a process whose OpenMP runtime starts with the pinning variables set")
+    ap.add_argument("--threads", type=int, default=1, help="(internal) OpenMP threads of --cpu-structured-child")
     ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous / shard / all-gather plumbing only, no GPU work: every rank gathers synthetic per-filter rows of its config-5 shards (CPU rehearsal, gloo)")
     args = ap.parse_args()
+    if args.cpu_structured_child:
+        return cpu_structured_child(args.workload, args.M, args.threads)
     ekf_env = ekf_environment()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -585,6 +654,7 @@ def main():
         leg("config3_512_steps", lambda: summarise(measure(pkg, mc, torch, None, coll_device, 0, 1, dev_id, "n4096", 512, 32, M, args.max_pending, False, True, alone=False)))
         leg("config1_n50", lambda: config1_leg(pkg, dev_id))
         leg("immediate_calls", lambda: immediate_leg(pkg, dev_id))
+        leg("propagate_only", lambda: propagate_only_leg(pkg, dev_id))
         print(json.dumps({"secondary": secondary}))
         return
 
@@ -594,9 +664,12 @@ def main():
         return
 
     cpu = cpu_strong = None
-    if world == 1 and not args.no_cpu_baseline:
+    if runs_cpu_baseline(rank, world, args.no_cpu_baseline):
         cpu = cpu_baseline(pkg, N, M, seed, extent, min_sep)
-        cpu_strong = cpu_baseline_structured(pkg, N, M, seed, extent, min_sep)
+        cpu_strong = cpu_baseline_structured(args.workload, M)
+        if cpu and cpu_strong and cpu_strong.get("value"):
+            cpu_strong["gpu_over_cpu"] = {"faithful_dense_1_thread": head["value"] / cpu["value"], "structured_all_cores": head["value"] / cpu_strong["value"],
+                                          "note": "GPU steps/s of this line over the CPU legs' steps/s on the same host; a ratio says nothing about kernel quality (roofline does)"}
 
     if world == 1 and not args.no_secondary and args.workload == "n4096":
         secondary = secondary_in_a_child(args, dev_id)
@@ -666,33 +739,82 @@ def cpu_baseline(pkg, N, M, seed, extent, min_sep):
             "host_cpus": os.cpu_count(), "host": host_cpu_record(), "compiler_flags": "gcc -O3 -march=x86-64-v3 -ffp-contract=off (oracle/Makefile; the reference's Makefile:2 has no -O at all)"}
 
 
-def cpu_baseline_structured(pkg, N, M, seed, extent, min_sep):
-    """The strong CPU baseline of SURVEY.md 8(d): the oracle's structured mode (state advanced in place, only the O(n) rows
-    and the one rank-2 pass over P per update, OpenMP over the element-wise loops) on this GPU's share of the host cores.
-    Not the reference's algorithmic cost -- what a CPU can do with the same restructuring."""
+def cpu_structured_child(workload, M, threads):
+    """(internal: --cpu-structured-child) one timed structured-oracle run in THIS process, whose OpenMP runtime was started with the
+    pinning variables of cpu_baseline_structured in its environment.  Prints one JSON object."""
+    import numpy as np
+    import __graft_entry__ as ge
     from oracle import oracle_c as oc
-
-    threads = min(16, os.cpu_count() or 1)   # (a one-GPU box's CPU share)
+    pkg = ge.load_package()
+    N, _, _, _, seed, extent, min_sep = WORKLOADS[workload]
     sample_steps = {4096: 40, 1024: 400, 256: 2000}.get(N, 20)
     x, P = pkg.scenarios.injected_state(N, seed=seed, extent=extent)
     sc = pkg.scenarios.steady_script(x, steps=sample_steps + 2, M=M, seed=seed + 7919, min_separation=min_sep)
     oc.build()
     oc.set_threads(threads)
-    ses = oc.Session(x, P)
+    ses = oc.Session(x, P, first_touch=True)  # the pages of P are first written inside the parallel region that later updates them
     del P
     t0 = None
+    per_step = []
     for s in range(sample_steps + 2):
+        ts = time.perf_counter()
         if s == 2:
-            t0 = time.perf_counter()   # (two warm-up steps: page faults of the session's buffers, thread start)
+            t0 = ts   # (two warm-up steps: thread start, caches)
         v, w, dt = sc["ctrl"][s]
         ses.propagate(v, w, oc.make_Q(v), dt)
         for m in range(M):
             dec, _, _ = ses.update(sc["z"][s, m].reshape(2, 1), sc["R"][s, m].reshape(2, 2, order="F"))
             assert dec == [oc.OLD]
+        if s >= 2:
+            per_step.append(time.perf_counter() - ts)
     t = time.perf_counter() - t0
-    oc.set_threads(1)
-    return {"value": sample_steps / t, "unit": "steps/s", "cores": threads, "kind": "port",
-            "sample": "%d step(s) of the same workload at N=%d, structured oracle (in place, one rank-2 pass per update), %d OpenMP threads, %.1f s" % (sample_steps, N, threads, t)}
+    ps = np.array(per_step)
+    print(json.dumps({"cpu_structured": {"value": sample_steps / t, "unit": "steps/s", "cores": threads, "kind": "port", "seconds": t, "sample_steps": sample_steps, "N": N,
+                                         "seconds_per_step": {"median": float(np.median(ps)), "p10": float(np.percentile(ps, 10)), "p90": float(np.percentile(ps, 90))},
+                                         "omp": {k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "OMP_PROC_BIND", "OMP_PLACES")}}}))
+
+
+def cpu_baseline_structured(workload, M):
+    """The strong CPU baseline of SURVEY.md 8(d)(ii): the oracle's structured mode (state advanced in place, only the O(n) rows and
+    the one rank-2 pass over P per update, OpenMP over the element-wise loops) on ALL cores this process may use
+    (os.sched_getaffinity), threads pinned (OMP_PROC_BIND=spread, OMP_PLACES=threads) and P first touched inside the parallel region
+    that updates it -- and, beside it, the 16-thread figure of rounds 2-4 (a one-GPU share of the host).  Each run is a child
+    process: the pinning variables are read when the OpenMP runtime starts, which in this process happened long ago (torch).
+    Not the reference's algorithmic cost -- what a CPU can do with the same restructuring."""
+    import subprocess
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        ncpu = os.cpu_count() or 1
+    runs = {}
+    for label, threads in (("all_cores", ncpu), ("threads_16", min(16, ncpu))):
+        if label == "threads_16" and threads == ncpu:
+            runs[label] = runs["all_cores"]
+            continue
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+        env.update({"OMP_NUM_THREADS": str(threads), "OMP_PROC_BIND": "spread", "OMP_PLACES": "threads", "OMP_DYNAMIC": "false"})
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-structured-child", "--workload", workload, "--M", str(M), "--threads", str(threads)]
+        try:
+            p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+        except subprocess.TimeoutExpired:
+            runs[label] = {"error": "timed out"}
+            continue
+        rec = None
+        for l in reversed(p.stdout.splitlines()):
+            if l.startswith('{"cpu_structured"'):
+                rec = json.loads(l)["cpu_structured"]
+                break
+        runs[label] = rec if rec else {"error": "rc %d: %s" % (p.returncode, p.stderr[-300:])}
+    best = runs["all_cores"]
+    if "error" in best:
+        return {"value": None, "unit": "steps/s", "cores": ncpu, "kind": "port", "sample": best["error"], "threads_16": runs.get("threads_16")}
+    return {"value": best["value"], "unit": "steps/s", "cores": best["cores"], "kind": "port",
+            "sample": "%d step(s) of the same workload at N=%d, structured oracle (in place, one rank-2 pass per update), %d OpenMP threads = every CPU of the process's affinity mask, %.1f s"
+                      % (best["sample_steps"], best["N"], best["cores"], best["seconds"]),
+            "seconds_per_step": best["seconds_per_step"],
+            "pinning": {"OMP_PROC_BIND": "spread", "OMP_PLACES": "threads", "first_touch": "P copied into the session inside the parallel region (static schedule, the rows a thread later updates)",
+                        "affinity_cpus": ncpu, "host_cpus": os.cpu_count()},
+            "threads_16": runs.get("threads_16")}
 
 
 if __name__ == "__main__":

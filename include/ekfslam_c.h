@@ -47,6 +47,9 @@ extern "C" {
 #define EKF_DECISION_OLD 2
 #define EKF_DECISION_IGNORE 3
 
+/* Largest capacity_landmarks a handle can have (ekf_create / ekf_batch_create / ekf_reserve reject more with EKF_ERR_BAD_ARG). */
+#define EKF_MAX_CAPACITY 16000
+
 typedef struct ekf_batch *ekf_handle;
 
 /* Tunables; defaults equal the reference's literals. */
@@ -90,7 +93,11 @@ void ekf_default_params(ekf_params *p);
  * staging buffer inside ekf_get_state / ekf_set_state).
  * The sequential part of a filter runs on a few workgroups that exchange their arg-min candidates while they
  * run, so all of them must be resident on the GPU at once: creation fails with EKF_ERR_STATE when this
- * handle's workgroups do not fit beside those of the handles already live on the device (in this process). */
+ * handle's workgroups do not fit beside those of the handles already live on the device (in this process).
+ * The registry behind that check is PER PROCESS: two processes that share one GPU do not see each other's handles, there is no
+ * admission control between them, and a filter whose workgroups cannot all run because another process holds the CUs ends in the
+ * bounded device-side wait (EKF_ERR_TIMEOUT, sticky) instead of a refusal at creation.  One process per GPU -- the layout of the
+ * multi-GPU runs (one rank per device) -- never meets this. */
 int ekf_create(ekf_handle *out, int capacity_landmarks, int device_id, const ekf_params *params);
 int ekf_batch_create(ekf_handle *out, int batch, int capacity_landmarks, int device_id, const ekf_params *params);
 int ekf_destroy(ekf_handle h);
@@ -98,8 +105,10 @@ int ekf_destroy(ekf_handle h);
  * reference grows x and P by two rows and columns with every New landmark (Update.cpp:158-177, the O(n^2) copy of
  * kalmanfilter.cpp:78-84) and never runs out; here all device memory is sized by the capacity, so growth is an explicit, rare
  * step: device buffers of the larger capacity are allocated, the state moves over on the device, counters, decision log and a
- * loaded script are kept, the handle stays valid.  Synchronises; clears a sticky EKF_ERR_CAPACITY.  EKF_ERR_STATE when the
- * larger chain launch would not fit the GPU beside the other live handles (the handle is unchanged then). */
+ * loaded script are kept, the handle stays valid -- and so do ekf_stream() (the handle keeps its stream), a timer started with
+ * ekf_timer_start and the dense-pass profile collected so far (ekf_flush_profile*).  Synchronises; clears a sticky EKF_ERR_CAPACITY.
+ * EKF_ERR_STATE when the larger chain launch would not fit the GPU beside the other live handles, EKF_ERR_BAD_ARG beyond
+ * EKF_MAX_CAPACITY (the handle is unchanged then). */
 int ekf_reserve(ekf_handle h, int capacity_landmarks);
 int ekf_batch_size(ekf_handle h);
 int ekf_capacity(ekf_handle h);

@@ -70,6 +70,8 @@ void ekf_oracle_make_measurement(double fx_mm, double fy_mm, double z[2], double
 /* Threads used by the structured (faithful == 0) mode's element-wise O(n^2) loops; results do not
  * depend on it.  The faithful mode is always single-threaded. */
 void ekf_oracle_set_threads(int threads);
+/* n x n copy by the structured update's row schedule (NUMA first touch of a session's buffer; bench.py's strong CPU baseline) */
+void ekf_oracle_copy_rows(int n, const double *src, double *dst);
 
 #ifdef __cplusplus
 }

@@ -48,6 +48,8 @@ def lib():
         L.ekf_oracle_update_inplace.restype = ctypes.c_int
         L.ekf_oracle_set_threads.argtypes = [ctypes.c_int]
         L.ekf_oracle_set_threads.restype = None
+        L.ekf_oracle_copy_rows.argtypes = [ctypes.c_int, _dp, _dp]
+        L.ekf_oracle_copy_rows.restype = None
         _lib = L
     return _lib
 
@@ -179,7 +181,7 @@ class Session:
     propagate / update / compass above without the by-value copies of x and P on every call, for long test
     runs at large n.  `capacity_landmarks` bounds the growth by New landmarks."""
 
-    def __init__(self, x, P, capacity_landmarks=None):
+    def __init__(self, x, P, capacity_landmarks=None, first_touch=False):
         x = np.asarray(x, dtype=np.float64)
         n = x.size
         N = (n - 3) // 2
@@ -187,9 +189,15 @@ class Session:
         self.cap = 3 + 2 * cap_lm
         self.n = n
         self._x = np.zeros(self.cap)
-        self._P = np.zeros(self.cap * self.cap)
         self._x[:n] = x
-        self._P[:n * n] = np.asarray(P, dtype=np.float64).reshape(n * n)
+        if first_touch:
+            # timed multi-thread runs: the buffer's pages are first written by the threads that will update them (set_threads first)
+            self._P = np.empty(self.cap * self.cap)
+            lib().ekf_oracle_copy_rows(n, _p(np.ascontiguousarray(P, dtype=np.float64).reshape(n * n)), _p(self._P))
+            self._P[n * n:] = 0.0
+        else:
+            self._P = np.zeros(self.cap * self.cap)
+            self._P[:n * n] = np.asarray(P, dtype=np.float64).reshape(n * n)
 
     def propagate(self, v, w, Q, dt):
         Q = np.ascontiguousarray(Q, dtype=np.float64).reshape(4)

@@ -61,13 +61,74 @@ def main():
             agpr_hi = max(agpr_hi, hi)
             if hi >= 128:
                 agpr_bad.append((func, i + 1, l.strip()))
+    # third check (round 5): the hand-written part of k_solo -- solo_agpr.h / solo_pass_agpr.h name a128..a255 literally, which the
+    # register allocator knows nothing about.  (a) the kernel descriptors of both instantiations must grant all 512 registers with the
+    # accumulation half starting at 256 (.amdhsa_next_free_vgpr 512, .amdhsa_accum_offset 256), or a255 does not exist;
+    # (b) a memory instruction must not read an MFMA result for 18 cycles (solo_pass_agpr.h: pt_settle; the compiler inserts such
+    # gaps for its own code, not for inline asm): walking k_solo's listing INCLUDING the asm blocks, every `global_store ... a[` must
+    # be at least 18 wait states behind the last v_mfma in straight-line order (s_nop N = N + 1, any other instruction 1; a label
+    # or branch resets nothing -- the count is conservative: it only ever under-estimates the distance).
+    desc_bad, settle_bad = [], []
+    raw = open(path).read().splitlines()
+    kern = None
+    seen_desc = {}
+    for l in raw:
+        m = re.match(r"^\s*\.amdhsa_kernel\s+(\S+)", l)
+        if m:
+            kern = m.group(1)
+        m = re.match(r"^\s*\.amdhsa_(next_free_vgpr|accum_offset)\s+(\d+)", l)
+        if m and kern and "k_solo" in kern:
+            seen_desc.setdefault(kern, {})[m.group(1)] = int(m.group(2))
+    for k, d in sorted(seen_desc.items()):
+        if d.get("next_free_vgpr") != 512 or d.get("accum_offset") != 256:
+            desc_bad.append((k, d))
+    if len(seen_desc) < 2:
+        desc_bad.append(("k_solo", "expected the kernel descriptors of two instantiations, found %d" % len(seen_desc)))
+    func, since_mfma, min_gap, n_stores = None, None, None, 0
+    for i, l in enumerate(raw):
+        m = re.match(r"^(_Z\w+):", l)
+        if m:
+            func, since_mfma = m.group(1), None
+            continue
+        if func is None or "k_solo" not in func:
+            continue
+        t = l.strip()
+        if not t or t.startswith((";", ".", "//")) or t.endswith(":"):
+            continue
+        op = t.split()[0]
+        if op.startswith("v_mfma"):
+            since_mfma = 0
+            continue
+        if op.startswith("global_store") and re.search(r"\ba\[", t):
+            n_stores += 1
+            if since_mfma is not None:
+                min_gap = since_mfma if min_gap is None else min(min_gap, since_mfma)
+                if since_mfma < 18:
+                    settle_bad.append((func, i + 1, since_mfma))
+        if since_mfma is not None:
+            mm = re.match(r"s_nop\s+(\d+)", t)
+            since_mfma += (int(mm.group(1)) + 1) if mm else 1
+    for k, d in desc_bad:
+        print("%s: kernel descriptor does not grant a128..a255 (want next_free_vgpr 512, accum_offset 256): %s" % (k, d))
+    for f, ln, gap in settle_bad[:10]:
+        print("%s: global_store of an accumulation register only %d wait states behind a v_mfma (line %d; 18 needed: pt_settle)" % (f, gap, ln))
+    print("k_solo: %d stores from accumulation registers, the closest %s wait states behind an MFMA; descriptors: %s" % (
+        n_stores, min_gap, {k.split("ILb")[1][0] if "ILb" in k else k: v for k, v in seen_desc.items()}))
+    if n_stores == 0:
+        desc_bad.append(("k_solo", "no accumulation-register stores found: the listing is not what this check was written for"))
+        print("k_solo: no `global_store ... a[` found -- has the in-kernel pass moved?  (check 3 needs an update)")
+    if desc_bad or settle_bad:
+        bad.append(("k_solo", 0, len(desc_bad) + len(settle_bad)))
     for f, ln, text in agpr_bad[:10]:
         print("%s: compiler-generated use of an accumulation register >= a128 (reserved for solo_agpr.h), line %d: %s" % (f, ln, text))
     print("k_solo: highest accumulation register the compiler itself uses: a%d (a128..a255 are solo_agpr.h's)" % agpr_hi)
     if agpr_bad:
         bad.append(("k_solo", agpr_bad[0][1], len(agpr_bad)))
     for f, ln, n in bad:
-        print("%s: %d register copies directly before an exec-widening s_or_b64 (line %d of the filtered listing)" % (f, n, ln))
+        if ln == 0:
+            print("%s: %d finding(s) of the accumulation-register checks above" % (f, n))
+        else:
+            print("%s: %d register copies directly before an exec-widening s_or_b64 (line %d of the filtered listing)" % (f, n, ln))
     print("%s: %d suspicious site(s)" % (path, len(bad)))
     return 1 if bad else 0
 

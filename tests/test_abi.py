@@ -110,3 +110,56 @@ def test_register_half_of_the_long_window_is_what_the_lint_guards(built):
         assert r.returncode == 1 and "reserved for solo_agpr.h" in r.stdout, r.stdout
     finally:
         os.remove(doctored)
+
+
+def test_lint_checks_the_hand_written_accumulation_register_code(built, tmp_path):
+    """What the register allocator cannot see in k_solo (solo_agpr.h, solo_pass_agpr.h): the kernel descriptors of both instantiations must
+    grant a128..a255 (512 registers, accumulation half from 256), and no `global_store ... a[` may come closer than 18 wait states behind a
+    v_mfma (pt_settle).  The lint reports both; doctored listings -- a shortened settle, a smaller register grant -- must fail it."""
+    import re
+    import subprocess
+    import sys
+    asm = os.path.join(ROOT, "2d-ekf-slam_amd", "lib", "asm", "ekf_kernels.s")
+    lint = [sys.executable, os.path.join(ROOT, "scripts", "check_exec_split.py")]
+    r = subprocess.run(lint + [asm], capture_output=True, text=True)
+    m = re.search(r"k_solo: (\d+) stores from accumulation registers, the closest (\d+) wait states behind an MFMA", r.stdout)
+    assert r.returncode == 0 and m and int(m.group(1)) >= 32 and int(m.group(2)) >= 18, r.stdout
+    text = open(asm).read()
+    for name, doctored in (("settle", text.replace("s_nop 7", "s_nop 0")), ("grant", text.replace(".amdhsa_next_free_vgpr 512", ".amdhsa_next_free_vgpr 300"))):
+        f = tmp_path / (name + ".s")
+        f.write_text(doctored)
+        r = subprocess.run(lint + [str(f)], capture_output=True, text=True)
+        assert r.returncode == 1 and "accumulation-register checks" in r.stdout, (name, r.stdout[-600:])
+
+
+def test_capacity_growth_is_clamped_at_the_library_limit(built, tmp_path):
+    """The KalmanFilter shims double the capacity when a chunk could overflow it (the reference's state grows without bound,
+    Update.cpp:158-177); ekf_reserve refuses more than EKF_MAX_CAPACITY, so doubling must stop THERE instead of failing once the
+    capacity passes half of it (8192 -> 16384 used to throw although 8193 landmarks fit).  Same rule in the Python mirror and in the
+    C++ header (compiled here against the stand-ins: a static function, no GPU)."""
+    import re
+    import subprocess
+    pkg = built
+    hdr = open(os.path.join(ROOT, "include", "ekfslam_c.h")).read()
+    limit = int(re.search(r"#define EKF_MAX_CAPACITY (\d+)", hdr).group(1))
+    g = pkg.ekfslam.grown_capacity
+    lib_dir = os.path.dirname(pkg.ekfslam.LIB_PATH)
+    assert pkg.ekfslam.MAX_CAPACITY == limit
+    cases = [(4, 5), (4, 20), (4096, 4097), (8000, 8001), (8001, 8002), (8192, 8193), (12000, limit), (limit - 1, limit), (limit, limit + 1), (9000, limit + 5)]
+    want = []
+    for cap, need in cases:
+        w = g(cap, need)
+        assert w >= need  # never less than what is needed ...
+        assert w == max(2 * cap, need) or (w == limit and need <= limit)  # ... doubling, or the limit when doubling would pass it
+        if need <= limit:
+            assert w <= limit  # only a map that really needs more than the limit is refused (by ekf_reserve)
+        want.append(w)
+    src = tmp_path / "grow.cpp"
+    src.write_text('#include "%s"\n#include <cstdio>\nint main() { %s return 0; }\n' % (
+        os.path.join(ROOT, "compat", "kalmanfilter.h"),
+        " ".join('std::printf("%%d\\n", KalmanFilter::grown_capacity(%d, %d));' % c for c in cases)))
+    exe = tmp_path / "grow"
+    out = subprocess.run(["g++", "-std=c++17", "-o", str(exe), str(src), "-L" + lib_dir, "-lekfslam_hip", "-Wl,-rpath," + lib_dir], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    got = [int(v) for v in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    assert got == want

@@ -40,6 +40,19 @@ def test_bench_launches_its_own_ranks_dry_run(world):
     assert c5["world_size"] == world
     assert c5["weak"]["filters_total"] == 256 * world and c5["weak"]["gathered_rows"] == 256 * world and c5["weak"]["filters_per_gpu"] == 256
     assert c5["strong"]["filters_total"] == 2048 and c5["strong"]["gathered_rows"] == 2048
+    # no rank of a multi-rank run times the CPU baselines (14 s of single-thread work each): they ride on the one-rank line only
+    assert c5["cpu_baseline_ranks"] == []
+
+
+def test_only_rank_zero_of_a_one_rank_run_times_the_cpu_baselines():
+    """The driver's 8-GPU run must not be eight single-thread CPU jobs beside eight GPU ranks: bench.runs_cpu_baseline is the one
+    rule both the real run and the dry run use."""
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.runs_cpu_baseline(0, 1) is True
+    assert bench.runs_cpu_baseline(0, 1, no_cpu_baseline=True) is False
+    for world in (2, 4, 8):
+        assert [r for r in range(world) if bench.runs_cpu_baseline(r, world)] == []
 
 
 def test_bench_launcher_reports_a_failed_rank():

@@ -269,6 +269,56 @@ def test_strongly_correlated_covariance(pkg, oc, copies, max_pending):
     f.close()
 
 
+def test_strongly_correlated_covariance_at_bench_size(pkg, oc):
+    """The same kind of covariance at the BENCH size: helpers.correlated_state(copies=73) = 56 x 73 = 4088 landmarks (n = 8179,
+    128 x 128 tiles, 32 chain workgroups, both pipeline modes) -- every N = 4096 test besides this one uses the survey's near-diagonal
+    injected P (off-diagonals of 3e-6 beside a diagonal of 1e-2).  Here every tile of P_LL moves by O(diag) per measurement.
+    Eight scripted steps = 32 measurements = two windows of 16 (a multi-segment chain launch and its gated pass in overlap mode),
+    the full state compared; then two more steps = 8 measurements call by call through the immediate API (ekf_propagate /
+    ekf_update, decisions read back after each), the full state compared again.  Against the structured oracle."""
+    copies = 73
+    x0, P0 = cached(("corr", copies), lambda: correlated_state(pkg, oc, copies=copies, rho=0.8))
+    N = (x0.size - 3) // 2
+    assert N >= 4000
+    off = np.abs(P0[3:203, 3 + 2 * (N - 100):])  # a corner far from the diagonal
+    assert np.median(off) > 0.05 * np.median(np.diag(P0)[3:])  # strongly correlated indeed
+    M, scripted, immediate = 4, 8, 2
+    steps = scripted + immediate
+    sc = pkg.scenarios.steady_script(x0, steps=steps, M=M, seed=5, min_separation=1.0)
+    f = pkg.FilterBatch(1, N)  # the library's default window
+    assert f.window == 16
+    f.set_state(x0, P0)
+    load_script(f, [sc])
+    f.script_run(0, scripted)
+    f.sync()
+    refs = oracle_checkpoints(oc, x0, P0, sc, M, (scripted, steps))
+    r = refs[scripted]
+    assert [(d[0], d[1]) for d in f.decisions(0, scripted * M)] == r["decs"]
+    assert sum(d[0] == oc.OLD for d in r["decs"]) >= scripted * M // 2
+    xg, Pg = f.get_state()
+    assert_state_close(xg, Pg, r["x"], r["P"], "correlated N=%d, %d scripted measurements" % (N, scripted * M))
+    assert_bitwise_symmetric(Pg)
+    # the updates moved the far copies' blocks too (they are correlated with the observed landmarks)
+    far = slice(3 + 2 * (N - N // copies), None)
+    assert np.abs(r["P"][far, far] - P0[far, far]).max() > 1e-3 * np.abs(P0[far, far]).max()
+    del xg, Pg
+    # ... and the reference's call pattern on the same state: one call per operation, every decision read back
+    got = []
+    for s_ in range(scripted, steps):
+        v, w, dt = sc["ctrl"][s_]
+        f.propagate(v, w, dt)
+        for m in range(M):
+            d = f.update(sc["z"][s_, m].reshape(1, 1, 2), sc["R"][s_, m].reshape(1, 1, 2, 2, order="F"))[0][0]
+            got.append((d[0], d[1]))
+    r2 = refs[steps]
+    assert got == r2["decs"][scripted * M:]
+    xg, Pg = f.get_state()
+    assert_state_close(xg, Pg, r2["x"], r2["P"], "correlated N=%d, + %d immediate measurements" % (N, immediate * M))
+    assert_bitwise_symmetric(Pg)
+    assert np.abs(r2["P"][far, far] - r["P"][far, far]).max() > 1e-4 * np.abs(P0[far, far]).max()
+    f.close()
+
+
 def test_sweep_nan_behaviour(pkg, oc):
     """Update.cpp:131,140 with NaN: `cond >= 80` is false (the landmark is not skipped) and `Mahal_dist > NaN` is
     false (it is never selected).  A landmark whose 2x2 block is NaN can therefore never be matched: a measurement

@@ -154,3 +154,32 @@ def test_reserve_bad_arguments_and_limits(pkg):
     assert L.ekf_reserve(f.h, 20000) == pkg.ekfslam.ERR_BAD_ARG
     assert L.ekf_reserve(f.h, 8) == pkg.ekfslam.OK and int(L.ekf_capacity(f.h)) == 8
     f.close()
+
+
+def test_reserve_keeps_the_stream_an_open_timer_and_the_pass_profile(pkg):
+    """What a caller may hold across a growth step keeps working (ekfslam_c.h: ekf_reserve): the stream ekf_stream() handed out is
+    still the handle's stream, a timer started BEFORE the growth stops behind it with a sane time that includes the work on both
+    sides, and dense passes profiled before the growth are still counted by ekf_flush_profile_read."""
+    N, M, steps = 300, 4, 24                      # (more than 256 landmarks: k_chain and k_flush_rb launches, a profile of real passes)
+    x0, P0 = pkg.scenarios.injected_state(N, seed=79, extent=20.0)
+    sc = pkg.scenarios.steady_script(x0, steps=steps, M=M, seed=80, min_separation=1.0)
+    f = pkg.FilterBatch(1, N, max_pending=8)
+    f.set_state(x0, P0)
+    f.script_load(sc["ctrl"][:, None, :], sc["z"][:, :, None, :], sc["R"][:, :, None, :])
+    stream = f.L.ekf_stream(f.h)
+    assert stream
+    f.flush_profile(True)
+    f.timer_start()
+    f.script_run(0, steps // 2)                   # 48 measurements: six windows of 8
+    f.sync()
+    f.reserve(2 * N)
+    assert f.capacity == 2 * N
+    assert f.L.ekf_stream(f.h) == stream          # the caller's stream survived the growth
+    f.script_run(steps // 2, steps - steps // 2)  # the script moved over as well
+    f.flush()
+    ms = f.timer_stop()                           # t0 was recorded on the old buffers' stream
+    assert 0.0 < ms < 5000.0, ms
+    launches, total_ms = f.flush_profile_read()
+    assert launches >= (steps * M) // 8 and 0.0 < total_ms < ms, (launches, total_ms, ms)   # passes from BOTH sides of the growth
+    assert all(d[0] == pkg.ekfslam.OLD for d in f.decisions(0, steps * M))
+    f.close()
