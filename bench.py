@@ -739,6 +739,21 @@ def cpu_baseline(pkg, N, M, seed, extent, min_sep):
             "host_cpus": os.cpu_count(), "host": host_cpu_record(), "compiler_flags": "gcc -O3 -march=x86-64-v3 -ffp-contract=off (oracle/Makefile; the reference's Makefile:2 has no -O at all)"}
 
 
+def cgroup_cpu_quota():
+    """CPUs' worth of time the container may use per period (cgroup v2 cpu.max, v1 cfs_quota_us / cfs_period_us), None = unlimited."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_structured_child(workload, M, threads):
     """(internal: --cpu-structured-child) one timed structured-oracle run in THIS process, whose OpenMP runtime was started with the
     pinning variables of cpu_baseline_structured in its environment.  Prints one JSON object."""
@@ -767,6 +782,9 @@ def cpu_structured_child(workload, M, threads):
             assert dec == [oc.OLD]
         if s >= 2:
             per_step.append(time.perf_counter() - ts)
+            if len(per_step) >= 4 and time.perf_counter() - t0 > 15.0:  # (bounded: an oversubscribed host must not hold the bench line for a minute)
+                sample_steps = len(per_step)
+                break
     t = time.perf_counter() - t0
     ps = np.array(per_step)
     print(json.dumps({"cpu_structured": {"value": sample_steps / t, "unit": "steps/s", "cores": threads, "kind": "port", "seconds": t, "sample_steps": sample_steps, "N": N,
@@ -783,9 +801,14 @@ def cpu_baseline_structured(workload, M):
     Not the reference's algorithmic cost -- what a CPU can do with the same restructuring."""
     import subprocess
     try:
-        ncpu = len(os.sched_getaffinity(0))
+        affinity = len(os.sched_getaffinity(0))
     except (AttributeError, OSError):
-        ncpu = os.cpu_count() or 1
+        affinity = os.cpu_count() or 1
+    # "all cores" = every CPU this process may really use: the affinity mask, capped by the container's CPU quota (a one-GPU share of
+    # a 256-thread host shows 256 CPUs in the mask and a cgroup quota of 16: 256 threads on that quota ran at 0.9 steps/s against
+    # 18.9 for 16 -- throttled, not parallel)
+    quota = cgroup_cpu_quota()
+    ncpu = affinity if quota is None else max(1, min(affinity, int(quota + 0.5)))
     runs = {}
     for label, threads in (("all_cores", ncpu), ("threads_16", min(16, ncpu))):
         if label == "threads_16" and threads == ncpu:
@@ -805,15 +828,19 @@ def cpu_baseline_structured(workload, M):
                 rec = json.loads(l)["cpu_structured"]
                 break
         runs[label] = rec if rec else {"error": "rc %d: %s" % (p.returncode, p.stderr[-300:])}
-    best = runs["all_cores"]
-    if "error" in best:
-        return {"value": None, "unit": "steps/s", "cores": ncpu, "kind": "port", "sample": best["error"], "threads_16": runs.get("threads_16")}
-    return {"value": best["value"], "unit": "steps/s", "cores": best["cores"], "kind": "port",
-            "sample": "%d step(s) of the same workload at N=%d, structured oracle (in place, one rank-2 pass per update), %d OpenMP threads = every CPU of the process's affinity mask, %.1f s"
+    ok = {k: v for k, v in runs.items() if v and "error" not in v}
+    if not ok:
+        return {"value": None, "unit": "steps/s", "cores": ncpu, "kind": "port", "sample": str(runs), "all_cores": runs.get("all_cores"), "threads_16": runs.get("threads_16")}
+    # the strong baseline is the FASTER of the two (a host whose cores are shared or throttled without a visible quota can be slower
+    # with every thread it shows than with sixteen); both runs are in the record
+    best = max(ok.values(), key=lambda v: v["value"])
+    return {"value": best["value"], "unit": "steps/s", "cores": best["cores"], "kind": "port", "all_cores": runs.get("all_cores"),
+            "sample": "%d step(s) of the same workload at N=%d, structured oracle (in place, one rank-2 pass per update), %d OpenMP threads = every CPU the process may use (affinity mask, cgroup quota), %.1f s"
                       % (best["sample_steps"], best["N"], best["cores"], best["seconds"]),
             "seconds_per_step": best["seconds_per_step"],
             "pinning": {"OMP_PROC_BIND": "spread", "OMP_PLACES": "threads", "first_touch": "P copied into the session inside the parallel region (static schedule, the rows a thread later updates)",
-                        "affinity_cpus": ncpu, "host_cpus": os.cpu_count()},
+                        "affinity_cpus": affinity, "cgroup_cpu_quota": quota, "host_cpus": os.cpu_count(),
+                        "threads_rule": "min(affinity mask, cgroup CPU quota): every CPU the process can really run on"},
             "threads_16": runs.get("threads_16")}
 
 

@@ -754,6 +754,57 @@ def test_multi_segment_chain_launches_equal_one_launch_per_segment(pkg, monkeypa
         assert {d[0] for d in r1[0][0]} >= {pkg.ekfslam.NEW, pkg.ekfslam.OLD} and (r1[0][1].size - 3) // 2 > 8
 
 
+@pytest.mark.parametrize("case", ["n4096", "n1024", "n2048", "lifecycle_12wg", "lifecycle_3wg", "batch"])
+def test_one_landmark_per_thread_kernel_equals_the_general_kernel(pkg, monkeypatch, pipeline_mode, case):
+    """k_chain<true> -- the instantiation for filters whose worker threads hold one landmark each: no loops over further landmarks, no
+    running-best record in the sweep, every owner wave publishing its own arg-min head and record (no workgroup-level arg-min, one
+    barrier less per measurement) -- against k_chain<false> (EKF_CHAIN_ONE=0), the general kernel, on the same inputs: the same
+    arithmetic in the same order, so decisions, counters and states must be IDENTICAL, bit for bit.  Steady maps on 32 workgroups of
+    two owner waves (N = 4096), 16 workgroups of one owner wave and two helper waves (N = 1024), 32 workgroups of one owner wave
+    (N = 2048); lifecycles from an empty map (New landmarks waking up lanes, Ignore, masked slots, compass) on 12 and on 3 workgroups
+    (three owner waves each); a batch of four filters."""
+    M = 4
+    lifecycle = case.startswith("lifecycle")
+    B, N, steps, max_pending = {"n4096": (1, 4096, 24, 16), "n1024": (1, 1024, 40, 16), "n2048": (1, 2048, 24, 16), "lifecycle_12wg": (1, 700, 150, 6),
+                                "lifecycle_3wg": (1, 500, 150, 5), "batch": (4, 512, 24, 8)}[case]
+    if lifecycle:
+        M = 3
+        monkeypatch.setenv("EKF_CHAIN_WGS", "12" if case == "lifecycle_12wg" else "3")
+        script, ctrl, z, R, valid = lifecycle_as_script(pkg, steps, M)
+    outs = []
+    for one in ("0", "1"):
+        monkeypatch.setenv("EKF_CHAIN_ONE", one)
+        f = pkg.FilterBatch(B, N, max_pending=max_pending, log_capacity=steps * M)
+        if lifecycle:
+            f.script_load(ctrl, z, R, valid=valid)
+            f.script_run(0, steps // 3)
+            f.update_compass(0.02, 0.0005)   # an immediate-mode operation between scripted pieces (a launch without an exchange)
+            f.script_run(steps // 3, steps - steps // 3)
+        else:
+            scripts = []
+            for b in range(B):
+                x0, P0 = pkg.scenarios.injected_state(N, seed=300 + b, extent=12.5 if N <= 256 else 50.0)
+                f.set_state(x0, P0, index=b)
+                scripts.append(pkg.scenarios.steady_script(x0, steps=steps, M=M, seed=400 + b, min_separation=1.0))
+            f.script_load(np.stack([s["ctrl"] for s in scripts], axis=1), np.stack([s["z"] for s in scripts], axis=2), np.stack([s["R"] for s in scripts], axis=2))
+            f.script_run(0, steps // 2)
+            f.script_run(steps // 2, steps - steps // 2)
+        f.sync()
+        res = []
+        for b in sorted({0, B - 1}):
+            n_dec = sum(int(v) for v in valid[:, :, 0].ravel()) if lifecycle else steps * M
+            res.append((f.decisions(b, n_dec),) + f.get_state(b))
+        outs.append((res, f.stats()))
+        f.close()
+    (r0, s0), (r1, s1) = outs
+    assert s0 == s1
+    for (d0, x0, P0), (d1, x1, P1) in zip(r0, r1):
+        assert d0 == d1
+        assert np.array_equal(x0, x1) and np.array_equal(P0, P1)
+    if lifecycle:
+        assert {d[0] for d in r1[0][0]} >= {pkg.ekfslam.NEW, pkg.ekfslam.OLD} and (r1[0][1].size - 3) // 2 > 8
+
+
 def test_multi_segment_launches_with_filters_that_run_ahead(pkg, monkeypatch, pipeline_mode):
     """Regression for the stream gates of multi-segment launches (round-2 advisor finding): workgroups of different filters do not
     wait for each other between segments, so a filter whose measurements are all masked (OP_SKIP_SLOT: no sweep, no exchange,
