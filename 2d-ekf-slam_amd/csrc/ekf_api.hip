@@ -90,6 +90,7 @@ struct ekf_batch {
     int solo_cus = 0;     // one-workgroup handles: CUs their launches occupy while they run (they claim none: g_cus_solo)
     bool flush_masked;    // s_flush is a dedicated CU-masked queue
     size_t chain_lds;     // dynamic LDS of a k_chain launch: the own-row cache
+    bool chain_one = false;  // k_chain<true>: several workgroups per filter, at most one landmark per worker thread (EKF_CHAIN_ONE=0: the general kernel)
     double *bm1_base;     // allocation behind dv.Bm[1] (overlap mode)
     std::vector<int *> tile_maps;  // [nT]: XCD-aware wave -> tile tables of the row-block dense pass, built on demand
     bool xcd_map;         // EKF_XCD_MAP (default on)
@@ -426,7 +427,8 @@ static int create_impl(ekf_batch *h, int batch, int capacity_landmarks, int devi
     // a tile row in the own-row cache, dead while the pass runs: 2 KiB per pair and wave -- 8 or 16 pairs -- against 2 KiB per cached slot)
     h->solo_fuse = h->solo_kernel && cache_slots >= ((((maxp + 1) >> 1) + 7) & ~7) && (getenv("EKF_SOLO_FUSE") ? atoi(getenv("EKF_SOLO_FUSE")) != 0 : true);
     h->chain_lds = (size_t)lpw64 * cache_slots * 32;
-    HIP_TRY(hipFuncSetAttribute((const void *)k_chain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_budget));  // one setting for every handle
+    HIP_TRY(hipFuncSetAttribute((const void *)k_chain<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_budget));  // one setting for every handle
+    HIP_TRY(hipFuncSetAttribute((const void *)k_chain<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_budget));
     HIP_TRY(hipFuncSetAttribute((const void *)k_solo<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_budget));
     HIP_TRY(hipFuncSetAttribute((const void *)k_solo<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_budget));
     int workers = (dv.lpw + 63) / 64 * 64;
@@ -438,9 +440,13 @@ static int create_impl(ekf_batch *h, int batch, int capacity_landmarks, int devi
     if (dv.lpw <= 64 && G > 1 && G <= 16) workers = 192;
     h->chain_threads = 64 + workers;  // wave 0 is the control wave
     if (h->solo_kernel) h->chain_threads = (capacity_landmarks + 63) / 64 * 64;  // k_solo: one landmark per thread, no control wave
+    dv.hpw = (dv.lpw + 63) / 64;
+    h->chain_one = !h->solo_kernel && G > 1 && dv.lpw <= h->chain_threads - 64 && G * dv.hpw <= EKF_CHAIN_MAX_WGS && !(getenv("EKF_CHAIN_ONE") && atoi(getenv("EKF_CHAIN_ONE")) == 0);
+    if (!h->chain_one) dv.hpw = 1;
+    dv.nrec = G * dv.hpw;
     {
         int per_cu = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, h->solo_kernel ? (h->solo_long ? (const void *)k_solo<true> : (const void *)k_solo<false>) : (const void *)k_chain, h->chain_threads, h->chain_lds));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, h->solo_kernel ? (h->solo_long ? (const void *)k_solo<true> : (const void *)k_solo<false>) : (h->chain_one ? (const void *)k_chain<true> : (const void *)k_chain<false>), h->chain_threads, h->chain_lds));
         if (per_cu < 1) return set_error(EKF_ERR_STATE, "the chain kernel does not fit a CU with this capacity / window");
         // (one-workgroup filters wait for nobody: they need no co-residency and claim nothing)
         const int need = h->solo ? 0 : (G * h->chain_filters + per_cu - 1) / per_cu;
@@ -488,7 +494,7 @@ static int create_impl(ekf_batch *h, int batch, int capacity_landmarks, int devi
 #else
     HIP_TRY(dev_alloc_zero(&dv.dbg, 32, &h->device_bytes, s));
 #endif
-    HIP_TRY(dev_alloc_zero(&dv.part, B * 2 * dv.gmax * EKF_REC_DOUBLES, &h->device_bytes, s));
+    HIP_TRY(dev_alloc_zero(&dv.part, B * 2 * dv.nrec * EKF_REC_DOUBLES, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.log, B * dv.logcap, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.log_count, B, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.stats, B, &h->device_bytes, s));
@@ -952,8 +958,16 @@ static int launch_ops(ekf_batch *h, const double *in, const int *cursor, int k0,
     memset(&plan, 0, sizeof plan);
     EnqueueList passes;
     int next_drop = 0;
+    static const bool inline_rec = !(getenv("EKF_INLINE_REC") && atoi(getenv("EKF_INLINE_REC")) == 0);
     auto launch_plan = [&](hipEvent_t stop_ev) -> int {
         if (plan.nseg == 0) return EKF_OK;
+        // one filter, one segment of one operation, its record in the host-mapped ring (an immediate-mode call, slam.cpp:136-170): the
+        // record rides in the kernel arguments -- the kernel's first trip to host memory brings it along, the ring costs a second one
+        plan.inl_n = 0;
+        if (inline_rec && h->dv.B == 1 && plan.nseg == 1 && plan.s[0].nops == 1 && cursor == nullptr && in == h->ring_d) {
+            memcpy(plan.inl, h->ring_h + (size_t)plan.s[0].k0 * 8, 8 * sizeof(double));
+            plan.inl_n = 1;
+        }
         hipEvent_t pe0 = nullptr, pe1 = nullptr;
         if (fuse) {
             int sp = 0;
@@ -981,8 +995,11 @@ static int launch_ops(ekf_batch *h, const double *in, const int *cursor, int k0,
                 hipEvent_t ev0 = b0 == 0 ? pe0 : nullptr, ev1 = last ? (pe1 ? pe1 : stop_ev) : nullptr;
                 if (h->solo_long) hipExtLaunchKernelGGL(k_solo<true>, dim3(1, nb), dim3(h->chain_threads), h->chain_lds, h->s_chain, ev0, ev1, 0, h->dv, in, cursor, plan, b0);
                 else hipExtLaunchKernelGGL(k_solo<false>, dim3(1, nb), dim3(h->chain_threads), h->chain_lds, h->s_chain, ev0, ev1, 0, h->dv, in, cursor, plan, b0);
-            } else
-                hipExtLaunchKernelGGL(k_chain, dim3(h->chain_wgs, nb), dim3(h->chain_threads), h->chain_lds, h->s_chain, nullptr, last ? stop_ev : nullptr, 0, h->dv, in,
+            } else if (h->chain_one)
+                hipExtLaunchKernelGGL(k_chain<true>, dim3(h->chain_wgs, nb), dim3(h->chain_threads), h->chain_lds, h->s_chain, nullptr, last ? stop_ev : nullptr, 0, h->dv, in,
+                                      cursor, plan, b0);
+            else
+                hipExtLaunchKernelGGL(k_chain<false>, dim3(h->chain_wgs, nb), dim3(h->chain_threads), h->chain_lds, h->s_chain, nullptr, last ? stop_ev : nullptr, 0, h->dv, in,
                                       cursor, plan, b0);
         }
         if (plan.signal)
@@ -1121,7 +1138,7 @@ static int launch_ops_grouped(ekf_batch *h, const double *in, int k0, const unsi
             if (nb <= 0) break;
             if (h->solo_kernel && h->solo_long) hipLaunchKernelGGL(k_solo<true>, dim3(1, nb), dim3(h->chain_threads), h->chain_lds, h->s_grp[g], h->dv, in, (const int *)nullptr, plan, b0);
             else if (h->solo_kernel) hipLaunchKernelGGL(k_solo<false>, dim3(1, nb), dim3(h->chain_threads), h->chain_lds, h->s_grp[g], h->dv, in, (const int *)nullptr, plan, b0);
-            else hipLaunchKernelGGL(k_chain, dim3(1, nb), dim3(h->chain_threads), h->chain_lds, h->s_grp[g], h->dv, in, (const int *)nullptr, plan, b0);
+            else hipLaunchKernelGGL(k_chain<false>, dim3(1, nb), dim3(h->chain_threads), h->chain_lds, h->s_grp[g], h->dv, in, (const int *)nullptr, plan, b0);
             if (!do_pass) continue;
             hipEvent_t e0 = nullptr, e1 = nullptr;
             if (h->prof_flush && h->prof_used + 2 <= h->prof_pool.size()) e0 = h->prof_pool[h->prof_used++], e1 = h->prof_pool[h->prof_used++];  // (created above)

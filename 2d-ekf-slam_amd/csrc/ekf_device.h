@@ -86,8 +86,12 @@ struct ChainSeg {
 struct ChainPlan {
     int nseg;
     int signal;                     // != 0: every workgroup counts segment i in dv.seg_count[i] when it has finished it
-    unsigned long long reserved_;
+    int inl_n;                      // != 0: the launch's one operation record (one filter, one operation: an immediate-mode call) travels in inl[]
+                                    // with the kernel arguments instead of the host-mapped input ring: the kernel's first trip to host memory
+                                    // (its arguments) brings the record along, where the ring costs a second, dependent one
+    int reserved_;
     ChainSeg s[EKF_PLAN_MAX];
+    double inl[8];
 };
 
 struct EkfDev {
@@ -102,6 +106,8 @@ struct EkfDev {
     int rows;  // 64*T: rows of one slot in FA / FB
     int lpw;   // landmarks owned by one k_chain workgroup
     int gmax;  // k_chain workgroups per filter
+    int hpw;   // k_chain<true>: arg-min heads (and records) a workgroup publishes per exchange = its owner waves, ceil(lpw / 64); else 1
+    int nrec;  // gmax * hpw <= 64: records per filter and exchange parity in `part`
     size_t bm_stride;  // doubles per filter in one Bm buffer: T(T+1)/2 * 4096
     size_t f_stride;   // doubles per (filter, set) in FA / FB: (maxpairs + 1) * rows * 4
     double *x, *R, *D;
@@ -119,7 +125,7 @@ struct EkfDev {
                                     // hipStreamWaitValue64(seg_count[i] >= ChainSeg::gate)
     int *bar;          // [B][2]: [0] = cross-workgroup exchanges done so far (tags of the records continue from it)
     long long *dbg;    // [32] diagnostics: tick counters of the control lane [0..7] and of the first worker [16..23] (EKF_CHAIN_STAMPS), first bad index [8..11] (EKF_CHAIN_CHECK)
-    double *part;      // [B][2][gmax][EKF_REC_DOUBLES]: per-workgroup arg-min records, double-buffered by exchange parity
+    double *part;      // [B][2][nrec][EKF_REC_DOUBLES]: arg-min records (per workgroup; k_chain<true>: per owner wave), double-buffered by exchange parity
     ekf_decision *log;
     long long *log_count;
     ekf_stats *stats;

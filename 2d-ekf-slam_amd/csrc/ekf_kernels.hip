@@ -152,6 +152,7 @@ struct ChainLds {
     // the helper wave's share of the fold: component-major partial sums for up to 128 landmarks, and the number of the fold they belong to
     double hp[4 * 128];
     int hflag, hflag2;  // (hflag2: the second helper wave of a workgroup of at most 64 landmarks)
+    int pubflag;        // k_chain<true>: tag of the exchange whose head this workgroup's first owner wave has published (the polling wave starts then)
 };
 
 // Header of the Old branch (Update.cpp:181-189): a pure function of the heading the sweep ran with and of the
@@ -208,6 +209,9 @@ __device__ __forceinline__ void old_robot_row(const OldHdr &h, const double *Pro
         stamp_acc[slot_] += (long long)(now_ - stamp_t);                                              \
         stamp_t = now_;                                                                               \
     } while (0)
+#elif defined(EKF_CHAIN_MARKS)
+// (-DEKF_CHAIN_MARKS: the phase boundaries as comments in the generated assembly, for counting instructions per phase)
+#define STAMP(slot_) asm volatile("; ##MARK " #slot_)
 #else
 #define STAMP(slot_) do { } while (0)
 #endif
@@ -352,6 +356,46 @@ __device__ __forceinline__ void sweep_one(int lm, const LmState &st, double z0, 
     }
 }
 
+// The same landmark of the same sweep for the kernel instantiation that holds ONE landmark per worker thread (k_chain<true>): a lane has
+// one candidate at most, so there is no running best to keep -- the winner record's entries are this lane's own sweep values
+// (res, S, h) and its landmark's state (P_R,Li and the 2x2 block: r0 itself), used only if the lane turns out to own the filter-wide
+// winner.  Expression for expression sweep_one; d = EKF_INF when the landmark is skipped (condition number) or cannot win (NaN).
+struct SweepOne {
+    double d;
+    double res0, res1, S00, S01, S11, h0, h1;
+};
+__device__ __forceinline__ SweepOne sweep_single(const LmState &st, double z0, double z1, const SweepConst &k, double cond_k2) {
+    const double c = k.c, s = k.s;
+    double dp0 = st.x0 - k.px, dp1 = st.x1 - k.py;
+    double res0 = z0 - (c * dp0 + s * dp1);
+    double res1 = z1 - (-s * dp0 + c * dp1);
+    double h0 = -s * dp0 + c * dp1;
+    double h1 = -c * dp0 - s * dp1;
+    const double *A = st.rc;
+    double b00 = c * A[0] + s * A[2], b01 = c * A[1] + s * A[3];
+    double b10 = -s * A[0] + c * A[2], b11 = -s * A[1] + c * A[3];
+    double v00 = b00 * c + b01 * s, v01 = -b00 * s + b01 * c;
+    double v10 = b10 * c + b11 * s, v11 = -b10 * s + b11 * c;
+    double w0 = A[4] * c + A[5] * s, w1 = -A[4] * s + A[5] * c;
+    double x00 = h0 * w0 - v00, x01 = h0 * w1 - v01, x10 = h1 * w0 - v10, x11 = h1 * w1 - v11;
+    double l00 = c * st.dxx + s * st.dxy, l01 = c * st.dxy + s * st.dyy;
+    double l10 = -s * st.dxx + c * st.dxy, l11 = -s * st.dxy + c * st.dyy;
+    double q00 = l00 * c + l01 * s, q01 = -l00 * s + l01 * c;
+    double q10 = l10 * c + l11 * s, q11 = -l10 * s + l11 * c;
+    double S00 = (k.M0[0] - 2.0 * k.u0 * h0 + k.pff * h0 * h0) + 2.0 * x00 + q00 + k.R00;
+    double S11 = (k.M0[2] - 2.0 * k.u1 * h1 + k.pff * h1 * h1) + 2.0 * x11 + q11 + k.R11;
+    double S01 = (k.M0[1] - k.u0 * h1 - k.u1 * h0 + k.pff * h0 * h1) + (x01 + x10) + 0.5 * (q01 + q10) + 0.5 * (k.R01 + k.R10);
+    double e = 0.5 * (S00 + S11), f = 0.5 * (S00 - S11);
+    double q2 = e * e, r2 = f * f + S01 * S01, sum = q2 + r2;
+    SweepOne o;
+    o.res0 = res0, o.res1 = res1, o.S00 = S00, o.S01 = S01, o.S11 = S11, o.h0 = h0, o.h1 = h1;
+    const bool kept = !(q2 * r2 >= cond_k2 * (sum * sum));  // Update.cpp:131 (NaN: not skipped)
+    double det = S00 * S11 - S01 * S01;
+    double d = (res0 * (S11 * res0 - S01 * res1) + res1 * (S00 * res1 - S01 * res0)) / det;  // :135-136
+    o.d = (kept && EKF_INF > d) ? d : EKF_INF;  // :140 (false for NaN)
+    return o;
+}
+
 // ---- the fold of the unflushed slots, software-pipelined by hand ---------------------------------------------------------
 // p[a][e] += sum over the virtual slots of (own cached row a of the slot) . (column e of the slot's 2x2 matrix M).  Per slot a
 // thread reads its own four components (two ds_read_b128, conflict-free) and the slot's M (two ds_read_b128 broadcasts) and
@@ -402,7 +446,7 @@ __device__ __forceinline__ unsigned lds_off(const void *p) { return (unsigned)(s
         "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240",     \
         "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255"
 
-static_assert(sizeof(ChainSeg) == 56 && sizeof(ChainPlan) == 16 + EKF_PLAN_MAX * 56, "the segment table is read from the kernel-argument segment by offset");
+static_assert(sizeof(ChainSeg) == 56 && sizeof(ChainPlan) == 16 + EKF_PLAN_MAX * 56 + 64, "the segment table is read from the kernel-argument segment by offset");
 struct ChainKArgs {  // k_chain's arguments as they lie in the kernel-argument segment
     EkfDev dv;
     const double *in;
@@ -410,6 +454,16 @@ struct ChainKArgs {  // k_chain's arguments as they lie in the kernel-argument s
     ChainPlan plan;
     int b_off;
 };
+// ONE: every worker thread holds at most one landmark (lpw <= blockDim.x - 64) AND the filter has more than one workgroup -- the shape
+// of every multi-workgroup filter the host builds unless a batch or an override leaves fewer workgroups than landmarks / 192.  That
+// instantiation carries none of the loops over a thread's further landmarks (sweep, gain, Propagate rows, New, compass, refill),
+// none of their memory round trips through x / R / D, no running-best record of the sweep, no one-workgroup path, and no workgroup-level
+// arg-min: every owner wave publishes its own record, the first owner wave the workgroup's head (one barrier and one LDS round trip less
+// per measurement).  Same expressions in the same order; the compiler contracts them into fused multiply-adds differently in the two
+// instantiations, so results agree with k_chain<false> up to rounding (tests: decisions identical, states within 1e-11 / 1e-12).
+// Measured (round 5, same-box A/B): N = 1024 (16 workgroups of one owner wave) 39.2 k -> 42.3 k steps/s; N = 4096 (32 workgroups of two owner
+// waves) unchanged -- its measurements are paced by the two memory trips beside the streaming pass, not by what happens between them.
+template <bool ONE>
 __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, const double *in, const int *cursor, ChainPlan plan, int b_off) {
     __shared__ ChainLds L;
     __shared__ double recs[EKF_CHAIN_MAX_OPS * 8];
@@ -432,7 +486,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
     double *R0 = dv.R + (size_t)b * 3 * xs;
     double *Dx = dv.D + (size_t)b * 3 * dv.dn;
     int *bar = dv.bar + (size_t)b * 2;
-    double *part = dv.part + (size_t)b * 2 * dv.gmax * EKF_REC_DOUBLES;
+    double *part = dv.part + (size_t)b * 2 * dv.nrec * EKF_REC_DOUBLES;
     int epoch = 0;  // cross-workgroup exchanges done in this launch
     const int ebase = bar[0];  // exchanges done by earlier launches: tags never repeat
 #ifdef EKF_CHAIN_STAMPS
@@ -462,7 +516,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
     typedef __attribute__((address_space(4))) const ChainSeg *SegPtr;
     const SegPtr segs = (SegPtr)((__attribute__((address_space(4))) const char *)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(ChainKArgs, plan) + offsetof(ChainPlan, s));
     const long long last_seq = segs[nseg - 1].seq;
-    if (tid == 0) L.abort = 0, L.hflag = -1, L.hflag2 = -1;
+    if (tid == 0) L.abort = 0, L.hflag = -1, L.hflag2 = -1, L.pubflag = 0;
     int fold_no = 0;  // Old measurements whose fold the helper wave shared (wave-uniform, kept by every thread)
     // Launches without a measurement (Propagate, compass, truth samples) have no exchange, hence nothing that keeps the filter's
     // workgroups in step: workgroup 0 could finish the whole launch and write the new robot state, landmark count and counters
@@ -536,7 +590,11 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
     // a slot that changes nothing (Ignore, masked, no room) still writes zeros: its pair partner may be live
     auto zero_slot_rows = [=](int slot, int n_now) {
         const int hi = own_hi < n_now ? own_hi : n_now;
-        for (int lm = lm0; lm < hi; lm += nw) write_slot(lm, slot, 0, 0, 0, 0, 0, 0, 0, 0, false);  // zeros in HBM for the dense pass, zeros in LDS for the fold
+        if constexpr (ONE) {
+            if (lm0 < hi) write_slot(lm0, slot, 0, 0, 0, 0, 0, 0, 0, 0, false);
+        } else {
+            for (int lm = lm0; lm < hi; lm += nw) write_slot(lm, slot, 0, 0, 0, 0, 0, 0, 0, 0, false);  // zeros in HBM for the dense pass, zeros in LDS for the fold
+        }
     };
     // Old branch for one landmark (Update.cpp:186-188,193-194): K rows, x += K res, robot rows and own block of
     // P, the slot.  p = P[rows of lm, columns of the matched landmark]; Prr and wv are the robot block the sweep
@@ -573,7 +631,8 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
         st.dxx -= sym_u(Tt[0][0], Tt[0][1], K[0][0], K[0][1], Tt[0][0], Tt[0][1], K[0][0], K[0][1]);
         st.dxy -= sym_u(Tt[0][0], Tt[0][1], K[0][0], K[0][1], Tt[1][0], Tt[1][1], K[1][0], K[1][1]);
         st.dyy -= sym_u(Tt[1][0], Tt[1][1], K[1][0], K[1][1], Tt[1][0], Tt[1][1], K[1][0], K[1][1]);
-        if (lm != lm0) lm_store(lm, st);  // (the register-resident landmark goes back to memory once, at the end of the launch)
+        if constexpr (!ONE)
+            if (lm != lm0) lm_store(lm, st);  // (the register-resident landmark goes back to memory once, at the end of the launch)
         // slot: P_LL -= T K^T (rank 2; K S K^T is symmetric, only one triangle is stored).  A = -T, B = K.
         write_slot(lm, slot, -Tt[0][0], -Tt[0][1], -Tt[1][0], -Tt[1][1], K[0][0], K[0][1], K[1][0], K[1][1], false);
     };
@@ -592,7 +651,8 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
         st.dxx -= sym_u(Tt[0], 0, K[0], 0, Tt[0], 0, K[0], 0);
         st.dxy -= sym_u(Tt[0], 0, K[0], 0, Tt[1], 0, K[1], 0);
         st.dyy -= sym_u(Tt[1], 0, K[1], 0, Tt[1], 0, K[1], 0);
-        if (lm != lm0) lm_store(lm, st);
+        if constexpr (!ONE)
+            if (lm != lm0) lm_store(lm, st);
         write_slot(lm, slot, -Tt[0], -0.0, -Tt[1], -0.0, K[0], 0, K[1], 0, false);
     };
     // New branch, an existing landmark lm < ln: its slot rows carry the new covariance column pair
@@ -615,7 +675,8 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
         st.x0 = L.newx[0], st.x1 = L.newx[1];
         for (int i = 0; i < 6; i++) st.rc[i] = L.newrc[i];
         st.dxx = L.newdd[0], st.dxy = L.newdd[1], st.dyy = L.newdd[2];
-        if (lm != lm0) lm_store(lm, st);
+        if constexpr (!ONE)
+            if (lm != lm0) lm_store(lm, st);
         for (int sl = 0; sl < n_prev + slot; sl++)  // the landmark did not exist in the earlier slots of the open windows
             for (int cmp = 0; cmp < 4; cmp++) own_rows[own_at(sl, cmp, lm - own_lo)] = 0.0;
         write_slot(lm, slot, 0, 0, 0, 0, 1, 0, 0, 1, true);  // (its own P_xL rows are zero: the 2x2 block lives in D)
@@ -681,14 +742,20 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
     // pass has finished leave in front and the set just closed moves down into their place (source and destination do not
     // overlap: the host only plans drop = 0 or drop >= n_prev) -- all by the workers, while the control lane waits above.
     if (seg == 0) {
-        for (int q = tid; q < nops * 8; q += bd) recs[q] = op_record(in, cursor, k0 + (q >> 3), dv.B, b)[q & 7];
+        if (plan.inl_n) {  // (an immediate-mode call of one operation: the record came with the kernel arguments)
+            typedef __attribute__((address_space(4))) const double *InlPtr;
+            const InlPtr inl = (InlPtr)((__attribute__((address_space(4))) const char *)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(ChainKArgs, plan) + offsetof(ChainPlan, inl));
+            if (tid < 8) recs[tid] = inl[tid];
+        } else {
+            for (int q = tid; q < nops * 8; q += bd) recs[q] = op_record(in, cursor, k0 + (q >> 3), dv.B, b)[q & 7];
+        }
         for (int q = tid; q < n_prev + slot0; q += bd)
             L.sm[q] = dv.slot_meta[((size_t)b * 2 + (q < n_prev ? (set ^ 1) : set)) * dv.maxp + (q < n_prev ? q : q - n_prev)];
     } else if (worker) {
         for (int q = wtid; q < nops * 8; q += nw) recs[q] = op_record(in, cursor, k0 + (q >> 3), dv.B, b)[q & 7];
         if (drop > 0) {
             for (int q = wtid; q < n_prev + slot0; q += nw) L.sm[q] = L.sm[q + drop];
-            for (int lm = lm0; lm < own_hi; lm += nw)
+            for (int lm = lm0; lm < own_hi; lm += (ONE ? 0x10000000 : nw))  // (ONE: a single trip)
                 for (int v0 = 0; v0 < n_prev + slot0; v0 += 4) {  // four slots per trip, every read requested before the first write
                     double2_t t[8];
 #pragma unroll
@@ -738,7 +805,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
         const int n_now = dv.n_lm[b];
         const int hi = own_hi < n_now ? own_hi : n_now;
         const int nv0 = n_prev + slot0;
-        for (int lm = lm0; lm < hi; lm += nw)
+        for (int lm = lm0; lm < hi; lm += (ONE ? 0x10000000 : nw))  // (ONE: a single trip)
             for (int v0 = 0; v0 < nv0; v0 += 8) {
                 double2_t lo2[8], hi2[8];
 #pragma unroll
@@ -872,7 +939,8 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                         r0.rc[2 + e] = r0.rc[2 + e] + pb * r0.rc[4 + e];
                     }
                 }
-                for (int lm = lm0 + nw; lm < hi; lm += nw)
+                if constexpr (!ONE)
+                  for (int lm = lm0 + nw; lm < hi; lm += nw)
                     for (int e = 0; e < 2; e++) {
                         double *Rj = R0 + 3 + 2 * lm + e;
                         double p2 = Rj[2 * (size_t)xs];
@@ -916,35 +984,135 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
             const int sweep_hi = own_hi < n_sweep ? own_hi : n_sweep;
             const int n_lm_before = uni(RS.n_lm);
 
-            SweepBest best;
-            best.d = EKF_INF, best.lm = 0x7fffffff;
-            for (int i = 0; i < 16; i++) best.w[i] = 0;
-            if (worker) {
-                double Prr[9];
-                for (int i = 0; i < 9; i++) Prr[i] = RS.Prr[i];
-                const SweepConst kc = sweep_const(RS.c, RS.s, RS.pose[0], RS.pose[1], Prr, Rm);
-                if (lm0 < sweep_hi) sweep_one(lm0, r0, z0, z1, kc, dv.cond_k2, best);
-                for (int lm = lm0 + nw; lm < sweep_hi; lm += nw) {
-                    LmState st = lm_load(lm);
-                    sweep_one(lm, st, z0, z1, kc, dv.cond_k2, best);
+            SweepBest best;  // (k_chain<false>: the running best over a thread's landmarks)
+            SweepOne so;     // (k_chain<true>: the one landmark's sweep values)
+            int my_lm = 0x7fffffff;  // the landmark this lane offers as a candidate
+            if constexpr (ONE) {
+                so.d = EKF_INF;
+                // (a whole wave without landmarks in the sweep -- the helper waves, the control wave -- skips it; inside an owner wave
+                // every lane computes, lanes beyond the sweep on whatever their registers hold, and the select below drops them)
+                if (worker && uni(own_lo + (wtid & ~63)) < sweep_hi) {
+                    double Prr[9];
+                    for (int i = 0; i < 9; i++) Prr[i] = RS.Prr[i];
+                    const SweepConst kc = sweep_const(RS.c, RS.s, RS.pose[0], RS.pose[1], Prr, Rm);
+                    so = sweep_single(r0, z0, z1, kc, dv.cond_k2);
+                    if (!(lm0 < sweep_hi)) so.d = EKF_INF;
+                    my_lm = so.d < EKF_INF ? lm0 : 0x7fffffff;
                 }
+            } else {
+                best.d = EKF_INF, best.lm = 0x7fffffff;
+                for (int i = 0; i < 16; i++) best.w[i] = 0;
+                if (worker) {
+                    double Prr[9];
+                    for (int i = 0; i < 9; i++) Prr[i] = RS.Prr[i];
+                    const SweepConst kc = sweep_const(RS.c, RS.s, RS.pose[0], RS.pose[1], Prr, Rm);
+                    if (lm0 < sweep_hi) sweep_one(lm0, r0, z0, z1, kc, dv.cond_k2, best);
+                    for (int lm = lm0 + nw; lm < sweep_hi; lm += nw) {
+                        LmState st = lm_load(lm);
+                        sweep_one(lm, st, z0, z1, kc, dv.cond_k2, best);
+                    }
+                }
+                my_lm = best.lm;
             }
             // workgroup arg-min with first-index tie-break
-            double rd = best.d;
-            int ri = best.lm, rwho = 0;
+            double rd = ONE ? so.d : best.d;
+            int ri = my_lm, rwho = 0;
+            double gd = EKF_INF;
+            int gi = 0x7fffffff;
+            int src = g;   // workgroup that owns the winner (k_chain<true>: the winner's record, below)
+            if constexpr (ONE) {
+                // ---- k_chain<true>: every OWNER WAVE publishes for itself.  A wave's arg-min is complete in its own registers (DPP), its
+                // winner's rows of the open slots are its own landmarks' (the LDS chunk only its lanes write), so head and record leave
+                // without any hand-off inside the workgroup: no LDS candidates, no workgroup barrier, no combine -- the filter-wide arg-min
+                // takes the heads of all owner waves (workgroups x owner waves <= 64: one lane of the polling wave each; the order
+                // (d, landmark) is total, so the pick is the same).  Granule protocol and double buffering as described below.
+                const int hpw = dv.hpw, nrec = dv.nrec;
+                const unsigned long long tag = (unsigned long long)(unsigned)(ebase + epoch + 1) << 32;
+                const int lane = tid & 63;
+                if (worker && uni(wtid >> 6) < hpw) {
+                    wave_argmin(rd, ri, rwho);
+                    unsigned long long *rec = (unsigned long long *)(part + ((size_t)(epoch & 1) * nrec + (size_t)g * hpw + uni(wtid >> 6)) * EKF_REC_DOUBLES);
+                    auto put = [=](unsigned long long *at, double v) {
+                        st_sc1_b128(at, (uint4_t){(unsigned)__double2loint(v), (unsigned)(tag >> 32), (unsigned)__double2hiint(v), (unsigned)(tag >> 32)});
+                    };
+#ifdef EKF_CHAIN_STAMPS
+                    if (tid == 64 && b == 0 && ebase + epoch < 2048) {
+                        unsigned long long now_;
+                        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");
+                        dv.dbg[32 + (size_t)g * 2048 + (ebase + epoch)] = (long long)now_;
+                    }
+#endif
+                    if (lane == 0) {
+                        put(rec + 2 * EKF_REC_HEAD, rd);
+                        __hip_atomic_store(rec + 2 * EKF_REC_HEAD + 2, tag | (unsigned)ri, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (wtid == 0) __hip_atomic_store(&L.pubflag, (int)(tag >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                    if (ri != 0x7fffffff && rd < dv.gamma_min) {  // (wave-uniform) only a candidate that passes the Old gate publishes a record
+                        if (ri == my_lm) {
+                            const double wv_[16] = {so.res0, so.res1, so.S00, so.S01, so.S11, so.h0, so.h1, r0.rc[0], r0.rc[1], r0.rc[2], r0.rc[3], r0.rc[4], r0.rc[5], r0.dxx, r0.dxy, r0.dyy};
+                            for (int i = 0; i < 16; i++) put(rec + 2 * i, wv_[i]);
+                        }
+                        for (int q = lane; q < slot * 4; q += 64) put(rec + 2 * (16 + q), own_rows[own_at(n_prev + (q >> 2), q & 3, ri - own_lo)]);  // the open set's cached rows (dead slots hold zeros)
+                    }
+                }
+                STAMP(1);  // sweep + wave arg-min + publish
+                if (!worker) {
+                    const unsigned long long *hd = (const unsigned long long *)(part + ((size_t)(epoch & 1) * nrec + (lane < nrec ? lane : 0)) * EKF_REC_DOUBLES) + 2 * EKF_REC_HEAD;
+                    unsigned long long h0 = 0, h1 = 0, h2 = 0;
+                    long spins = 0;
+                    bool ok = lane >= nrec;
+                    // (nothing holds this wave back while the workers sweep: it stays off the memory system -- every poll lengthens
+                    // everybody's -- until its own workgroup has published, which is when the others are about to)
+                    while (__hip_atomic_load(&L.pubflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != (int)(tag >> 32)) __builtin_amdgcn_s_sleep(1);
+                    for (;;) {
+                        if (!ok) {  // (a lane whose head has arrived does not read it again: every poll lengthens everybody's)
+                            h0 = __hip_atomic_load(hd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            h1 = __hip_atomic_load(hd + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            h2 = __hip_atomic_load(hd + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            ok = ((h0 ^ tag) >> 32) == 0 && ((h1 ^ tag) >> 32) == 0 && ((h2 ^ tag) >> 32) == 0;
+                        }
+                        if (__all(ok)) break;
+                        if (++spins > (1L << 22)) {  // bounded: a workgroup that is not running must not hang the GPU
+                            if (lane == 0) dv.status[b] = EKF_ERR_TIMEOUT, dv.mirror[b].status = EKF_ERR_TIMEOUT, L.abort = 1;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+#ifdef EKF_CHAIN_STAMPS
+                    if (lane == 0 && b == 0 && lead && ebase + epoch < 2048) {
+                        unsigned long long now_;
+                        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");
+                        dv.dbg[32 + (size_t)64 * 2048 + (ebase + epoch)] = (long long)now_;
+                    }
+#endif
+                    double d = EKF_INF;
+                    int i = 0x7fffffff;
+                    src = lane;
+                    if (lane < nrec) {
+                        d = __longlong_as_double((long long)((h1 << 32) | (h0 & 0xffffffffull)));
+                        i = (int)(unsigned)(h2 & 0xffffffffull);
+                    }
+                    wave_argmin(d, i, src);
+                    if (lane == 0) L.xd = d, L.xi = i, L.xsrc = src;  // (src: the winner's record = its owner wave's)
+                }
+                __syncthreads();  // (X) the pick is known to every wave
+                if (L.abort) goto finish;  // (uniform: read behind the barrier)
+                gd = L.xd, gi = uni(L.xi), src = uni(L.xsrc);
+                epoch++;
+                STAMP(2);  // poll + pick
+            } else {
             wave_argmin(rd, ri, rwho);
             if ((tid & 63) == 0) {
                 L.wd[tid >> 6] = rd;
                 L.wi[tid >> 6] = ri;
             }
             __syncthreads();  // (1)
-            double gd = L.wd[0];
-            int gi = L.wi[0];
+            gd = L.wd[0];
+            gi = L.wi[0];
             for (int wv = 1; wv < (bd >> 6); wv++)
                 if (cand_better(L.wd[wv], L.wi[wv], gd, gi)) gd = L.wd[wv], gi = L.wi[wv];
             gi = uni(gi);  // every thread of the workgroup holds the same local winner
             STAMP(1);      // sweep + workgroup arg-min
-            int src = g;   // workgroup that owns the winner
             if (G > 1) {
                 // ---- arg-min over the filter's workgroups, without fences, drains or counters.  Every handed-off byte
                 // travels in a self-validating 8-byte granule {32 payload bits, 32-bit tag of this exchange} written by
@@ -954,7 +1122,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                 // the window, and the head {d, landmark}.  Records are double-buffered by exchange parity: a workgroup
                 // cannot publish exchange e+2 before every workgroup has read e.
                 const unsigned long long tag = (unsigned long long)(unsigned)(ebase + epoch + 1) << 32;
-                unsigned long long *rec = (unsigned long long *)(part + ((size_t)(epoch & 1) * dv.gmax + g) * EKF_REC_DOUBLES);
+                unsigned long long *rec = (unsigned long long *)(part + ((size_t)(epoch & 1) * dv.nrec + g) * EKF_REC_DOUBLES);
                 auto put = [=](unsigned long long *at, double v) {  // a double = two granules, written by one 16-byte store (each half validates itself)
                     st_sc1_b128(at, (uint4_t){(unsigned)__double2loint(v), (unsigned)(tag >> 32), (unsigned)__double2hiint(v), (unsigned)(tag >> 32)});
                 };
@@ -972,7 +1140,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                 // (only a workgroup whose candidate passes the Old gate publishes a record: the record is read in the Old branch only,
                 // and the filter-wide winner of an Old decision is such a candidate -- 31 of 32 records used to be written for nothing)
                 if (gi != 0x7fffffff && gd < dv.gamma_min) {
-                    if (gi == best.lm)  // the lane that owns the local winner
+                    if (gi == my_lm)  // the lane that owns the local winner
                         for (int i = 0; i < 16; i++) put(rec + 2 * i, best.w[i]);
                     for (int q = tid; q < slot * 4; q += bd) put(rec + 2 * (16 + q), own_rows[own_at(n_prev + (q >> 2), q & 3, gi - own_lo)]);  // the open set's cached rows (dead slots hold zeros)
                 }
@@ -981,7 +1149,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                 // control wave has nothing else to do here.
                 const int lane = tid & 63;
                 if (!worker) {
-                    const unsigned long long *hd = (const unsigned long long *)(part + ((size_t)(epoch & 1) * dv.gmax + (lane < G ? lane : 0)) * EKF_REC_DOUBLES) + 2 * EKF_REC_HEAD;
+                    const unsigned long long *hd = (const unsigned long long *)(part + ((size_t)(epoch & 1) * dv.nrec + (lane < G ? lane : 0)) * EKF_REC_DOUBLES) + 2 * EKF_REC_HEAD;
                     unsigned long long h0 = 0, h1 = 0, h2 = 0;
                     long spins = 0;
                     bool ok = lane >= G;
@@ -1022,6 +1190,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                 epoch++;
                 STAMP(2);  // publish + poll + pick
             }
+            }  // (k_chain<false>)
             // ---- gate, Update.cpp:152,181,191: a pure function of the winner, evaluated by every thread ----------
             const int w_lo = gi;
             const bool have = (w_lo != 0x7fffffff);
@@ -1079,7 +1248,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                 {
                     const bool slot_thread = tid < nvs;
                     double c4[4] = {0, 0, 0, 0};
-                    if (G > 1) {
+                    if (ONE || G > 1) {
                       if (!worker) {
                         // the winner data too is read by the control wave (lanes 0..15: one value each, two more granules): a worker wave has its
                         // P_LL entries in flight, loads return in order, and the sixteen worker threads that used to read the winner data
@@ -1090,7 +1259,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                             const double *F = (L.sm[tid].type == SLOT_NEW ? FAb : FBb) + CK(off_p + pair_offset(rows_, 2 * w_lo, tid >> 1), lim_F - 7) + (tid & 1) * 2;
                             c4[0] = F[0], c4[1] = F[1], c4[2] = F[4], c4[3] = F[5];  // (written in an earlier segment or launch: behind an acquire)
                         }
-                        const unsigned long long *wrec = (const unsigned long long *)(part + ((size_t)((epoch - 1) & 1) * dv.gmax + src) * EKF_REC_DOUBLES);
+                        const unsigned long long *wrec = (const unsigned long long *)(part + ((size_t)((epoch - 1) & 1) * dv.nrec + src) * EKF_REC_DOUBLES);
                         const unsigned long long tag = (unsigned long long)(unsigned)(ebase + epoch) << 32;
                         const unsigned long long *gp = wrec + 2 * (16 + (cur_thread ? tid - n_prev : 0) * 4), *gw = wrec + 2 * (tid & 15);
                         const int ng = cur_thread ? 8 : 0, nwg = w_thread ? 2 : 0;
@@ -1120,10 +1289,12 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                         if (w_thread) L.w[tid] = __longlong_as_double((long long)((g[9] << 32) | (g[8] & 0xffffffffull)));
                       }
                     } else {
-                        if (w_lo == best.lm)
-                            for (int i = 0; i < 16; i++) L.w[i] = best.w[i];
-                        if (slot_thread)
-                            for (int j = 0; j < 4; j++) c4[j] = own_rows[own_at(tid, j, w_lo - own_lo)];
+                        if constexpr (!ONE) {
+                            if (w_lo == best.lm)
+                                for (int i = 0; i < 16; i++) L.w[i] = best.w[i];
+                            if (slot_thread)
+                                for (int j = 0; j < 4; j++) c4[j] = own_rows[own_at(tid, j, w_lo - own_lo)];
+                        }
                     }
                     if (slot_thread) {
                         const SlotMeta m = L.sm[tid];
@@ -1231,10 +1402,11 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                         apply_old(lm, st, p, slot, h, RS.Prr, L.w);
                     };
                     if (lm0 < hi) gain_one(lm0, r0, true);
-                    for (int lm = lm0 + nw; lm < hi; lm += nw) {
-                        LmState stm = lm_load(lm);
-                        gain_one(lm, stm, false);
-                    }
+                    if constexpr (!ONE)
+                        for (int lm = lm0 + nw; lm < hi; lm += nw) {
+                            LmState stm = lm_load(lm);
+                            gain_one(lm, stm, false);
+                        }
                 } else if (tid == 0) {
                     // robot block: x_R += K_R res (:187), P_RR -= sym(K_R S K_R^T) (:188,193-194)
                     const OldHdr h = old_header(RS.c, RS.s, L.w);
@@ -1318,7 +1490,8 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                         const int hi = own_hi < ln ? own_hi : ln;
                         if (lm0 < hi) apply_new_column(lm0, r0, slot, c, s);
                         else if (lm0 == ln && lm0 < own_hi) apply_new_self(lm0, r0, slot);
-                        for (int lm = lm0 + nw; lm < own_hi && lm <= ln; lm += nw) {
+                        if constexpr (!ONE)
+                          for (int lm = lm0 + nw; lm < own_hi && lm <= ln; lm += nw) {
                             if (lm < ln) {
                                 LmState st = lm_load(lm);
                                 apply_new_column(lm, st, slot, c, s);
@@ -1384,10 +1557,11 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                 const int n_lm = uni(RS.n_lm);
                 const int hi = own_hi < n_lm ? own_hi : n_lm;
                 if (lm0 < hi) apply_compass(lm0, r0, slot);
-                for (int lm = lm0 + nw; lm < hi; lm += nw) {
-                    LmState stm = lm_load(lm);
-                    apply_compass(lm, stm, slot);
-                }
+                if constexpr (!ONE)
+                    for (int lm = lm0 + nw; lm < hi; lm += nw) {
+                        LmState stm = lm_load(lm);
+                        apply_compass(lm, stm, slot);
+                    }
             }
             __syncthreads();
             cur ^= 1;

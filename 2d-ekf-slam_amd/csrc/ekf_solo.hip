@@ -26,8 +26,15 @@
 // landmark's rows, for the slot matrices M -- travels like the winner record: the wave's winner lane leaves them in LDS before the
 // measurement's one barrier.  One dense pass per 32 measurements instead of 16.
 #define SOLO_HALF 16
+#ifndef SOLO_DERIVE_A
+#define SOLO_DERIVE_A 1  // the workgroup's own dense pass forms A = -(K S) from the B side and the slot's S (0: reads FA, as rounds 3-4 did)
+#endif
 #include "solo_agpr.h"
 #include "solo_pass_agpr.h"
+#include "solo_pipe_agpr.h"
+#ifndef SOLO_PIPE
+#define SOLO_PIPE 0  // (round 5, being validated: 1 =) full windows of 32 take the software-pipelined tile of solo_pipe_agpr.h (0: the form of round 4 for every window)
+#endif
 
 struct SoloLds {
     ekf_stats st;
@@ -219,21 +226,31 @@ __global__ __launch_bounds__(256) void k_solo(EkfDev dv, const double *in, const
         // 36 us per window of 16 / 32 for 256 filters at once: 134 MB leaving 256 CUs).  Issued here, four stores per measurement drain
         // under the next measurement's sweep; the one dependent memory trip of a measurement (the P_LL entries of the matched landmark)
         // is waited for 3 us later, when they have long been acknowledged.
+        // Round 5: a segment that folds the window it fills itself (self_pass) does not write the A side of an Old, compass or dead slot at
+        // all: A = -(K S) is a function of B = K and of the slot's S, and the workgroup's own pass forms it when it stages a tile row's A
+        // operands (below) -- half of the slot traffic of a batch never reaches memory (67 of 134 MB per window of 32 for 256 filters),
+        // and the measurement loop loses two stores and six operations per measurement.  FA is still written where a pass KERNEL may
+        // read it (a window the launch leaves open: k_flush_rb folds it if the host flushes) and for New slots (P_xL rows: not derivable).
         auto emit_slot = [=](int slot, int type, bool appended_self, double c0, double c1, double c2, double c3, double S00, double S01, double S11) {
 #pragma clang fp contract(off)
             double a[4] = {0, 0, 0, 0}, bq[4] = {0, 0, 0, 0};
+            const bool with_a = !SOLO_DERIVE_A || !self_pass || type == SLOT_NEW;  // (uniform)
             if (type == SLOT_OLD) {  // A = -(K S), B = K
                 bq[0] = c0, bq[1] = c1, bq[2] = c2, bq[3] = c3;
-                a[0] = -(c0 * S00 + c1 * S01), a[1] = -(c0 * S01 + c1 * S11);
-                a[2] = -(c2 * S00 + c3 * S01), a[3] = -(c2 * S01 + c3 * S11);
+                if (with_a) {
+                    a[0] = -(c0 * S00 + c1 * S01), a[1] = -(c0 * S01 + c1 * S11);
+                    a[2] = -(c2 * S00 + c3 * S01), a[3] = -(c2 * S01 + c3 * S11);
+                }
             } else if (type == SLOT_NEW) {  // A = P_xL rows, B = unit rows at the appended landmark
                 a[0] = c0, a[1] = c1, a[2] = c2, a[3] = c3;
                 if (appended_self) bq[0] = 1.0, bq[3] = 1.0;
             }
             const size_t at = pair_offset(rows_, 2 * lm0, slot >> 1) + (slot & 1) * 2;  // two slots share a row: slot 2p in [0..1], slot 2p+1 in [2..3]
             double *fa = FAc + at, *fb = FBc + at;
-            *(double2_t *)fa = (double2_t){a[0], a[1]};
-            *(double2_t *)(fa + 4) = (double2_t){a[2], a[3]};
+            if (with_a) {
+                *(double2_t *)fa = (double2_t){a[0], a[1]};
+                *(double2_t *)(fa + 4) = (double2_t){a[2], a[3]};
+            }
             *(double2_t *)fb = (double2_t){bq[0], bq[1]};
             *(double2_t *)(fb + 4) = (double2_t){bq[2], bq[3]};
         };
@@ -245,7 +262,13 @@ __global__ __launch_bounds__(256) void k_solo(EkfDev dv, const double *in, const
         };
 
         // ---- segment prologue: operation records and, for a launch that continues a window, the open slots' kinds and own rows
-        for (int q = tid; q < nops * 8; q += bd) recs[q] = op_record(in, cursor, k0 + (q >> 3), dv.B, b)[q & 7];
+        if (plan.inl_n) {  // (an immediate-mode call of one operation: the record came with the kernel arguments, k_chain)
+            typedef __attribute__((address_space(4))) const double *InlPtr;
+            const InlPtr inl = (InlPtr)((__attribute__((address_space(4))) const char *)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(ChainKArgs, plan) + offsetof(ChainPlan, inl));
+            if (tid < 8) recs[tid] = inl[tid];
+        } else {
+            for (int q = tid; q < nops * 8; q += bd) recs[q] = op_record(in, cursor, k0 + (q >> 3), dv.B, b)[q & 7];
+        }
         if (seg == 0) {
             for (int q = tid; q < slot0; q += bd) L.sm[q] = dv.slot_meta[((size_t)b * 2 + set) * dv.maxp + q];
             // (the landmark's state is requested beside the landmark count that decides whether it exists -- one memory trip at the start
@@ -783,23 +806,88 @@ __global__ __launch_bounds__(256) void k_solo(EkfDev dv, const double *in, const
             const int np8cap = (((dv.maxp + 1) >> 1) + 7) & ~7;  // pairs a full window can hold, in whole sweeps: 8 or 16
             double *const stage = own_rows + (size_t)wave * np8cap * 256;  // [pair of the walk through live][row-block 0..3][64]
             const int np8 = (npl + 7) & ~7;                          // pairs the sweeps cover (the all-zero pair behind the live ones)
-            if (npl > 0)
+            auto stage_row = [&](int I) {
+                        // the row's A operands -> LDS.  Round 5: FORMED here for Old / compass slots -- A[row][k] = -(K[row][.] S[.][k]), the very
+                            // expression emit_slot used to write (contraction off: bit for bit the pass kernel's operand), from the B side's K rows
+                            // (which this pass reads anyway, as B operands: they are in L2) and the slot's S in LDS (L.sm) -- and read from FA only
+                            // for a New slot's P_xL rows; a dead slot is zeros.  A lane holds element (row r = lane & 15 of the row-block, k = lane >> 4:
+                            // slot 2m + (k >> 1), component e = k & 1), i.e. the MFMA's own A fragment: four row-blocks per pair and trip.
+#pragma clang fp contract(off)
+                            asm volatile("" ::: "memory");
+                            unsigned lv = live_all;
+                            const int r_ = lane & 15, k_ = lane >> 4, e_ = k_ & 1;
+                            for (int q = 0; q < np8; q++) {
+                                const int m = lv ? __builtin_ctz(lv) : zero_slot;
+                                lv &= lv - 1;
+                                const int sl = 2 * m + (k_ >> 1);  // (per lane: the pair's first or second slot)
+                                int ty = SLOT_DEAD;
+                                double s0 = 0, s1 = 0;
+                                if (m != zero_slot && sl < slot) {
+                                    const SlotMeta mt = L.sm[sl];
+                                    ty = mt.type;
+                                    s0 = e_ ? mt.S01 : mt.S00, s1 = e_ ? mt.S11 : mt.S01;  // column e of S
+                                }
+                                const size_t row0 = (size_t)m * slot_stride + ((size_t)64 * I + r_) * 4;
+                                double2_t kk[4];
+                                double av[4];
+#pragma unroll
+                                for (int rb = 0; rb < 4; rb++) kk[rb] = *(const double2_t *)(FBc + row0 + (size_t)rb * 64 + (k_ & 2));
+#pragma unroll
+                                for (int rb = 0; rb < 4; rb++) av[rb] = ty == SLOT_NEW ? FAc[row0 + (size_t)rb * 64 + k_] : 0.0;
+#pragma unroll
+                                for (int rb = 0; rb < 4; rb++) {
+                                    const double d_ = -(kk[rb].x * s0 + kk[rb].y * s1);
+                                    stage[q * 256 + rb * 64 + lo] = ty == SLOT_OLD ? d_ : av[rb];
+                                }
+                            }
+                            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            };
+            // Round 5: a full window of 32 whose sixteen pairs are all live takes the software-pipelined tile (solo_pipe_agpr.h: one asm statement
+            // per tile; the B operands two pairs at a time through a ring of buffers in v208..v255, requested two sub-sweeps ahead; the next
+            // tile's chains requested as this tile's row-blocks are stored).  The walk is the same -- row rp, then row nT - 1 - rp, every tile of a
+            // row left to right -- but flat, so that every tile knows its successor.  Other windows (dead pairs, shorter windows, k_solo<false>)
+            // keep the form below.
+            const bool piped = LONG && npl == 16 && live_all == 0xffffu && !(SOLO_PIPE == 0);
+            if (piped) {
+                const int nrows2 = (nT + 1) / 2;
+                int rp = wave, half = 0, I = wave, J = wave;
+                if (rp < nrows2) {
+                    const unsigned lob = lo * 8u, as_ = lds_off(stage) + lo * 8u, ssb = (unsigned)(slot_stride * 8);
+                    auto tile_at = [&](int I_, int J_) { return dv.Bm[buf_read] + (size_t)b * dv.bm_stride + ((size_t)I_ * T_ - ((size_t)I_ * (I_ - 1)) / 2 + (size_t)(J_ - I_)) * 4096; };
+                    stage_row(I);
+                    pp_prologue(nullptr, tile_at(I, J), nullptr, FBc + (size_t)64 * J * 4, ssb, voff, lob, as_);  // (drained inside)
+                    for (;;) {
+                        // the successor: the next tile of the row, else the first tile of the wave's next row
+                        int nrp = rp, nhalf = half, nI = I, nJ = J + 1;
+                        if (nJ >= nT) {
+                            if (half == 0 && nT - 1 - rp != rp) nhalf = 1, nI = nT - 1 - rp;
+                            else nrp = rp + nwaves, nhalf = 0, nI = nrp;
+                            nJ = nI;
+                        }
+                        const bool has_next = nrp < nrows2;
+                        const double *tile = tile_at(I, J);
+                        const double *next = has_next ? tile_at(nI, nJ) : tile;  // (no successor: the requests go to this tile again and are dropped)
+                        const double *fb = FBc + (size_t)64 * J * 4, *fbn = has_next ? FBc + (size_t)64 * nJ * 4 : fb;
+                        if (I == J) {
+                            pp_tile_dg(tile, next, fb, fbn, ssb, voff, lob, as_);
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (a diagonal tile leaves fewer stores in flight than the next block assumes: drain)
+                        } else {
+                            pp_tile_nd(tile, next, fb, fbn, ssb, voff, lob, as_);
+                        }
+                        if (!has_next) break;
+                        if (nI != I) {
+                            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                            stage_row(nI);  // a new row: its A operands (ends with a drain)
+                        }
+                        rp = nrp, half = nhalf, I = nI, J = nJ;
+                    }
+                }
+            } else if (npl > 0)
                 for (int rp = wave; rp < (nT + 1) / 2; rp += nwaves) {  // (uniform per wave)
                     for (int half = 0; half < 2; half++) {
                         const int I = half == 0 ? rp : nT - 1 - rp;
                         if (half == 1 && I == rp) break;  // (the middle row of an odd count)
-                        {   // the row's A operands -> LDS
-                            asm volatile("" ::: "memory");
-                            unsigned lv = live_all;
-                            for (int q = 0; q < np8; q++) {
-                                const int m = lv ? __builtin_ctz(lv) : zero_slot;
-                                lv &= lv - 1;
-                                const double *src = FAc + (size_t)m * slot_stride + (size_t)64 * I * 4 + (size_t)lane * 2;
-                                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src, (__attribute__((address_space(3))) void *)(stage + q * 256), 16, 0, 0);
-                                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 128), (__attribute__((address_space(3))) void *)(stage + q * 256 + 128), 16, 0, 0);
-                            }
-                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        }
+                        stage_row(I);
                         for (int J = I; J < nT; J++) {
                             const bool diag = I == J;
                             const size_t t = (size_t)I * T_ - ((size_t)I * (I - 1)) / 2 + (size_t)(J - I);

@@ -759,7 +759,9 @@ def test_one_landmark_per_thread_kernel_equals_the_general_kernel(pkg, monkeypat
     """k_chain<true> -- the instantiation for filters whose worker threads hold one landmark each: no loops over further landmarks, no
     running-best record in the sweep, every owner wave publishing its own arg-min head and record (no workgroup-level arg-min, one
     barrier less per measurement) -- against k_chain<false> (EKF_CHAIN_ONE=0), the general kernel, on the same inputs: the same
-    arithmetic in the same order, so decisions, counters and states must be IDENTICAL, bit for bit.  Steady maps on 32 workgroups of
+    expressions in the same order (the compiler contracts them into fused multiply-adds differently in the two instantiations, as it
+    does between k_solo and k_chain), so decisions, matched landmarks and counters must be IDENTICAL and Mahalanobis distances and
+    states equal up to rounding (1e-9 / 1e-11 / 1e-12 relative: five orders inside the parity tolerance).  Steady maps on 32 workgroups of
     two owner waves (N = 4096), 16 workgroups of one owner wave and two helper waves (N = 1024), 32 workgroups of one owner wave
     (N = 2048); lifecycles from an empty map (New landmarks waking up lanes, Ignore, masked slots, compass) on 12 and on 3 workgroups
     (three owner waves each); a batch of four filters."""
@@ -797,10 +799,15 @@ def test_one_landmark_per_thread_kernel_equals_the_general_kernel(pkg, monkeypat
         outs.append((res, f.stats()))
         f.close()
     (r0, s0), (r1, s1) = outs
-    assert s0 == s1
+    for a, b_ in zip(s0, s1):
+        assert all(a[k] == b_[k] for k in ("nis_count", "nees_count", "n_new", "n_old", "n_ignore"))
+        assert abs(a["nis_sum"] - b_["nis_sum"]) <= 1e-9 * max(1.0, abs(a["nis_sum"]))
     for (d0, x0, P0), (d1, x1, P1) in zip(r0, r1):
-        assert d0 == d1
-        assert np.array_equal(x0, x1) and np.array_equal(P0, P1)
+        assert [(d[0], d[1]) for d in d0] == [(d[0], d[1]) for d in d1]
+        assert all(abs(a[2] - b_[2]) <= 1e-9 * max(1.0, abs(a[2])) for a, b_ in zip(d0, d1))  # (Mahalanobis distances: rounding only)
+        assert x0.shape == x1.shape
+        assert np.abs(x0 - x1).max() <= 1e-11 * max(1.0, np.abs(x0).max()) and np.abs(P0 - P1).max() <= 1e-12 * np.abs(P0).max()
+        assert_bitwise_symmetric(P1)
     if lifecycle:
         assert {d[0] for d in r1[0][0]} >= {pkg.ekfslam.NEW, pkg.ekfslam.OLD} and (r1[0][1].size - 3) // 2 > 8
 
