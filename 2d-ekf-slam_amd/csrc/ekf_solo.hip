@@ -31,10 +31,6 @@
 #endif
 #include "solo_agpr.h"
 #include "solo_pass_agpr.h"
-#include "solo_pipe_agpr.h"
-#ifndef SOLO_PIPE
-#define SOLO_PIPE 0  // (round 5, being validated: 1 =) full windows of 32 take the software-pipelined tile of solo_pipe_agpr.h (0: the form of round 4 for every window)
-#endif
 
 struct SoloLds {
     ekf_stats st;
@@ -842,47 +838,7 @@ __global__ __launch_bounds__(256) void k_solo(EkfDev dv, const double *in, const
                             }
                             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             };
-            // Round 5: a full window of 32 whose sixteen pairs are all live takes the software-pipelined tile (solo_pipe_agpr.h: one asm statement
-            // per tile; the B operands two pairs at a time through a ring of buffers in v208..v255, requested two sub-sweeps ahead; the next
-            // tile's chains requested as this tile's row-blocks are stored).  The walk is the same -- row rp, then row nT - 1 - rp, every tile of a
-            // row left to right -- but flat, so that every tile knows its successor.  Other windows (dead pairs, shorter windows, k_solo<false>)
-            // keep the form below.
-            const bool piped = LONG && npl == 16 && live_all == 0xffffu && !(SOLO_PIPE == 0);
-            if (piped) {
-                const int nrows2 = (nT + 1) / 2;
-                int rp = wave, half = 0, I = wave, J = wave;
-                if (rp < nrows2) {
-                    const unsigned lob = lo * 8u, as_ = lds_off(stage) + lo * 8u, ssb = (unsigned)(slot_stride * 8);
-                    auto tile_at = [&](int I_, int J_) { return dv.Bm[buf_read] + (size_t)b * dv.bm_stride + ((size_t)I_ * T_ - ((size_t)I_ * (I_ - 1)) / 2 + (size_t)(J_ - I_)) * 4096; };
-                    stage_row(I);
-                    pp_prologue(nullptr, tile_at(I, J), nullptr, FBc + (size_t)64 * J * 4, ssb, voff, lob, as_);  // (drained inside)
-                    for (;;) {
-                        // the successor: the next tile of the row, else the first tile of the wave's next row
-                        int nrp = rp, nhalf = half, nI = I, nJ = J + 1;
-                        if (nJ >= nT) {
-                            if (half == 0 && nT - 1 - rp != rp) nhalf = 1, nI = nT - 1 - rp;
-                            else nrp = rp + nwaves, nhalf = 0, nI = nrp;
-                            nJ = nI;
-                        }
-                        const bool has_next = nrp < nrows2;
-                        const double *tile = tile_at(I, J);
-                        const double *next = has_next ? tile_at(nI, nJ) : tile;  // (no successor: the requests go to this tile again and are dropped)
-                        const double *fb = FBc + (size_t)64 * J * 4, *fbn = has_next ? FBc + (size_t)64 * nJ * 4 : fb;
-                        if (I == J) {
-                            pp_tile_dg(tile, next, fb, fbn, ssb, voff, lob, as_);
-                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (a diagonal tile leaves fewer stores in flight than the next block assumes: drain)
-                        } else {
-                            pp_tile_nd(tile, next, fb, fbn, ssb, voff, lob, as_);
-                        }
-                        if (!has_next) break;
-                        if (nI != I) {
-                            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                            stage_row(nI);  // a new row: its A operands (ends with a drain)
-                        }
-                        rp = nrp, half = nhalf, I = nI, J = nJ;
-                    }
-                }
-            } else if (npl > 0)
+            if (npl > 0)
                 for (int rp = wave; rp < (nT + 1) / 2; rp += nwaves) {  // (uniform per wave)
                     for (int half = 0; half < 2; half++) {
                         const int I = half == 0 ? rp : nT - 1 - rp;
@@ -943,6 +899,7 @@ __global__ __launch_bounds__(256) void k_solo(EkfDev dv, const double *in, const
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tiles are back
             __syncthreads();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // (the next window reads P_LL entries: not from lines the L1 kept)
+            STAMP(7);  // the workgroup's own dense pass
         }
 #ifdef EKF_CHAIN_STAMPS
         if (tid == 0 && b == 0)

@@ -18,7 +18,9 @@ Here ONE asm statement carries a whole tile, so that registers and waits can be 
     which is why the non-diagonal block's entry assumption is exactly its own exit state and the caller drains everywhere else.
 The A operands come from the wave's LDS stage (one ds_read_b64 per pair and row-block, one element ahead), pairs are applied to every
 chain in ascending order: bitwise the pass kernel's result.  NP = 16 pairs (windows of 32); other windows keep the older form.
-CPU; usage: python3 scripts/r05_gen_solo_pipe.py [--check]."""
+DROPPED (round 5): parity-green at the first run and no faster -- the pass is bound by the MFMA rate and by HBM, not by the latencies this form
+hides.  Kept with scripts/dropped/r05_in_kernel_pass_software_pipelined.patch (the glue in ekf_solo.hip).
+CPU; usage: python3 scripts/dropped/r05_gen_solo_pipe.py [--check]."""
 import os
 import sys
 
@@ -199,7 +201,7 @@ def main():
     text += c_block("pp_tile_nd", "%d instructions" % len(nd.lines), nd)
     text += c_block("pp_tile_dg", "%d instructions" % len(dg.lines), dg)
     text += c_block("pp_prologue", "%d instructions" % len(p.lines), p)
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "2d-ekf-slam_amd", "csrc", "solo_pipe_agpr.h")
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "2d-ekf-slam_amd", "csrc", "solo_pipe_agpr.h")
     if "--check" in sys.argv:
         same = os.path.exists(path) and open(path).read() == text
         print("solo_pipe_agpr.h %s the generator's output" % ("is" if same else "DIFFERS from"))

@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import __graft_entry__ as ge
 pkg = ge.load_package()
-NAMES = ["between measurements", "sweep+argmin+barrier", "pick+gate+slot matrices", "wait P_LL", "fold", "gain+robot block", "emit (per window)"]
+NAMES = ["between measurements", "sweep+argmin+barrier", "pick+gate+slot matrices", "wait P_LL", "fold", "gain+robot block", "emit (per window)", "own dense pass (per window)"]
 
 def run(B, N, maxp=int(os.environ.get("MAXP", "16")), steps=64, warm=8, M=4):
     f = pkg.FilterBatch(B, N, max_pending=maxp)
@@ -25,7 +25,7 @@ def run(B, N, maxp=int(os.environ.get("MAXP", "16")), steps=64, warm=8, M=4):
     assert all(s["n_old"] == (steps + warm) * M for s in st), st[0]
     nm = steps * M
     print("B=%d N=%d window=%d: %.1f us/step; per measurement (us): " % (B, N, f.window, ms / steps * 1e3) +
-          ", ".join("%s %.2f" % (NAMES[i], buf[i] * 0.01 / (nm if i < 6 else nm / f.window)) for i in range(7)) + " | sum %.2f" % (sum(buf[i] for i in range(7)) * 0.01 / nm), flush=True)
+          ", ".join("%s %.2f" % (NAMES[i], buf[i] * 0.01 / (nm if i < 6 else nm / f.window)) for i in range(8)) + " | sum %.2f" % (sum(buf[i] for i in range(7)) * 0.01 / nm), flush=True)
     f.close()
 
 for B, N in ((1, 256), (256, 256)):
