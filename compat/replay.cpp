@@ -54,16 +54,21 @@ int main(int argc, char **argv) {
     std::vector<std::string> pos;
     const char *state_in = nullptr, *state_out = nullptr;
     bool timing = false, detect = false, quiet = false;  // --quiet: without slam.cpp's stdout chatter ("Compass: ...", "Update: New 12")
+    // digits of the data files.  The reference's streams are never given a precision (slam.cpp:177,181,200; kalmanfilter.cpp:51,58), so it
+    // writes the default 6 significant digits: that is the default here too -- a replay's files compare byte for byte with a reference run's on
+    // the same values.  --precision 17 writes round-trip digits (the parity tests compare the files with oracle values to the last bit).
+    int precision = 6;
     for (int i = 1; i < argc; i++) {
         if (!std::strcmp(argv[i], "--state") && i + 1 < argc) state_in = argv[++i];
         else if (!std::strcmp(argv[i], "--dump-state") && i + 1 < argc) state_out = argv[++i];
         else if (!std::strcmp(argv[i], "--timing")) timing = true;
         else if (!std::strcmp(argv[i], "--detect")) detect = true;
         else if (!std::strcmp(argv[i], "--quiet")) quiet = true;
+        else if (!std::strcmp(argv[i], "--precision") && i + 1 < argc) precision = std::atoi(argv[++i]);
         else pos.push_back(argv[i]);
     }
     if (pos.size() < 2) {
-        std::fprintf(stderr, "usage: %s <records.txt> <output-dir> [capacity_landmarks] [--state f] [--dump-state f] [--timing] [--detect] [--quiet]\n", argv[0]);
+        std::fprintf(stderr, "usage: %s <records.txt> <output-dir> [capacity_landmarks] [--state f] [--dump-state f] [--timing] [--detect] [--quiet] [--precision digits (default 6, as the reference's streams)]\n", argv[0]);
         return 2;
     }
     std::ifstream in(pos[0]);
@@ -76,7 +81,7 @@ int main(int argc, char **argv) {
         featuresFile(dir + "/data/features/featuresRun.txt"), knownfeaturesFile(dir + "/data/features/knownfeaturesRun.txt"),
         covFile(dir + "/data/cov/covRun.txt"), decisionFile(dir + "/data/decisionsRun.txt"), compassFile(dir + "/data/compassRun.txt");  // slam.cpp:21-50
     if (!odomFile || !scanFile || !featuresFile || !knownfeaturesFile || !covFile) return std::fprintf(stderr, "cannot create the data files under %s\n", dir.c_str()), 2;
-    for (std::ofstream *f : {&odomFile, &scanFile, &featuresFile, &knownfeaturesFile, &covFile, &decisionFile, &compassFile}) f->precision(17);
+    for (std::ofstream *f : {&odomFile, &scanFile, &featuresFile, &knownfeaturesFile, &covFile, &decisionFile, &compassFile}) f->precision(precision > 0 ? precision : 6);
     // --timing measures the filter calls: the O(N) text lines of knownfeaturesRun.txt (kalmanfilter.cpp:56-59) would be what
     // is timed at large N, so that file stays empty in a timing run (a failed stream ignores its insertions)
     if (timing) knownfeaturesFile.setstate(std::ios::badbit);

@@ -90,7 +90,7 @@ def test_replay_against_the_oracle_trajectory_and_reference_file_layout(replay_b
     dump = tmp_path / "final.bin"
     # capacity 4 for a map that ends with 17 landmarks: the reference's state simply grows (Update.cpp:158-177), so the shim
     # must grow its device buffers on the way (ekf_reserve, doubling) -- without a visible effect on any result
-    out = subprocess.run([replay_bin, str(rec), str(tmp_path), "4", "--dump-state", str(dump)], capture_output=True, text=True)
+    out = subprocess.run([replay_bin, str(rec), str(tmp_path), "4", "--dump-state", str(dump), "--precision", "17"], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
 
     # the oracle, driven the same way
@@ -158,6 +158,19 @@ def test_replay_against_the_oracle_trajectory_and_reference_file_layout(replay_b
         rows = [r for r in open(str(tmp_path / rel)).read().split("\n") if r != ""]
         assert rows and all(len(r.split(" ")) >= 2 and float(r.split(" ")[0]) == float(r.split(" ")[0]) for r in rows)
     assert os.path.isdir(str(tmp_path / "maps"))  # plot.py:8 saves into ./maps/
+    # without --precision the files carry what the reference's streams write: their precision is never set (slam.cpp:177,181,200,
+    # kalmanfilter.cpp:51,58), i.e. the default 6 significant digits ("%g"): the same run again, every number of every file the "%g" of the
+    # round-trip value above -- byte for byte what a reference run prints for these values
+    ref_dir = tmp_path / "as_reference"
+    ref_dir.mkdir()
+    out6 = subprocess.run([replay_bin, str(rec), str(ref_dir), "4", "--quiet"], capture_output=True, text=True)
+    assert out6.returncode == 0, out6.stderr
+    for rel in ("data/odom/odomRun.txt", "data/cov/covRun.txt", "data/features/featuresRun.txt", "data/features/knownfeaturesRun.txt", "data/scan/scanRun.txt"):
+        full = open(str(tmp_path / rel)).read().split("\n")
+        six = open(str(ref_dir / rel)).read().split("\n")
+        assert len(full) == len(six) and len(full) > 1, rel
+        for lf, l6 in zip(full, six):
+            assert l6.split(" ") == [("%g" % float(v)) if v else v for v in lf.split(" ")], (rel, lf, l6)
 
 
 @pytest.mark.gpu
@@ -242,7 +255,7 @@ def test_replay_detect_runs_perception_and_filter_end_to_end_like_the_oracle(rep
             f.write("scan %d %s\n" % (r.size, " ".join("%r %r %r" % (float(a), float(b), float(c)) for a, b, c in zip(r, lx, ly))))
             f.write("%r %r %r nan 0\n" % (float(it["dt"]), float(it["v_mm_s"]), float(it["rot_deg_s"])))
     dump = tmp_path / "final.bin"
-    out = subprocess.run([replay_bin, str(rec), str(tmp_path), "64", "--detect", "--quiet", "--dump-state", str(dump)], capture_output=True, text=True)
+    out = subprocess.run([replay_bin, str(rec), str(tmp_path), "64", "--detect", "--quiet", "--dump-state", str(dump), "--precision", "17"], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
 
     x, P = np.zeros(3), np.zeros((3, 3))
