@@ -30,6 +30,8 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/s
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/scripts/profile_batch_fused.py > $OUT/run_write.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma -- python3 $R/scripts/profile_batch_fused.py > $OUT/run_mfma.log 2>&1
 if grep -rqE "Memory access fault|GPU core dump" $R/gpurun_out/prof_r05_*/*.log $R/gpurun_out/prof_r05_*/*.err 2>/dev/null; then echo "GPU FAULT in a profiling pass"; exit 9; fi
+# the costing of a two-level arg-min: a tagged hand-off within an XCC against one across XCCs, idle and beside a stream
+cd $R && mkdir -p scripts/micro/bin && /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o scripts/micro/bin/xcc_lab scripts/micro/xcc_lab.hip > gpurun_out/r05_xcc_lab_build.log 2>&1 && timeout -k 10 150 scripts/micro/bin/xcc_lab > gpurun_out/r05_xcc_lab.log 2>&1; echo "xcc_lab rc=$?"
 echo "collect_r05 fused done"
 fi
 if [ "$WHAT" = bench ]; then
