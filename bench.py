@@ -182,7 +182,11 @@ def roofline_record(pkg, f, workload, B, N, K, M, window, launches, flush_ms, al
     # PMC-derived HBM bytes per launch: NOT measured by this run -- replayed from the committed rocprofv3 --pmc passes of this very
     # command (scripts/profile_r0x.sh -> profiles/traffic_*.json); null when no committed pass matches the configuration
     have = kernel_source_digest()
-    for tname in ("traffic_%s.json" % workload, "traffic_%s_inplace.json" % workload):
+    # (a handle that folds its windows inside the chain kernel has counters of its own: whole k_solo<true> windows, scripts/profile_batch_fused.py)
+    names = ("traffic_%s.json" % workload, "traffic_%s_inplace.json" % workload)
+    if getattr(f, "fused_pass", False):
+        names = ("traffic_%s_fused.json" % workload,) + names
+    for tname in names:
         tfile = os.path.join(ROOT, "profiles", tname)
         if os.path.exists(tfile):
             tj = json.load(open(tfile))
@@ -193,7 +197,11 @@ def roofline_record(pkg, f, workload, B, N, K, M, window, launches, flush_ms, al
                     continue
                 r["traffic"] = tj.get("hbm_bytes_per_launch")
                 r["traffic_source"] = "replayed from profiles/%s (separate rocprofv3 --pmc passes of these kernel sources, %s), not measured in this run" % (tname, have)
-                if getattr(f, "fused_pass", False):
+                if tj.get("fused_pass"):
+                    r["traffic_source"] += ("; counted on whole windows of k_solo<true> (the measurement loop's own traffic included: the B side of the slots, %d bytes, "
+                                            "written once per window, and the matched landmarks' P_LL entries); without the slot emit the ratio to the tile bytes is %.3f"
+                                            % (tj.get("algorithmic_slot_emit_bytes", 0), tj.get("ratio_without_the_slot_emit", float("nan"))))
+                elif getattr(f, "fused_pass", False):
                     # the counters were taken on k_flush_rb (EKF_SOLO_FUSE=0), the binary measured here folds inside k_solo: same tiles, but the
                     # in-kernel pass stages a tile row's A operands ONCE per row (LDS-DMA) and walks the exact landmark count, so it re-reads
                     # fewer operand bytes than the pass kernel: the replayed figure is an UPPER bound for this run
