@@ -28,5 +28,5 @@ def run(B, N, maxp=int(os.environ.get("MAXP", "16")), steps=64, warm=8, M=4):
           ", ".join("%s %.2f" % (NAMES[i], buf[i] * 0.01 / (nm if i < 6 else nm / f.window)) for i in range(8)) + " | sum %.2f" % (sum(buf[i] for i in range(7)) * 0.01 / nm), flush=True)
     f.close()
 
-for B, N in ((1, 256), (256, 256)):
-    run(B, N)
+for B in [int(v) for v in os.environ.get("STAMP_B", "1,256").split(",")]:
+    run(B, 256)

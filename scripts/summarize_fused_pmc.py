@@ -67,6 +67,23 @@ if "FETCH_SIZE" in per_disp and "WRITE_SIZE" in per_disp:
                  "algorithmic_slot_emit_bytes) is IN these counters; ratio_without_the_slot_emit is the figure comparable with traffic_batch256.json, "
                  "which counted the pass kernel alone (its operand reads, not the writes that produced them).  A per-launch = per-window figure.",
          "source": "profiles/r05_batch256_fusedpmc_summary.json"}
+    # the measurement loop alone (scripts/r05_collect_looponly_and_bench.sh: the debug library with the dense passes skipped): what is left
+    # after subtracting its reads is the in-kernel pass's own read traffic (tiles + operands); the pass writes the tiles and nothing else
+    lo_dir = sys.argv[2] if len(sys.argv) > 2 else "gpurun_out/prof_r05_batch256_looponly"
+    lf = newest(os.path.join(lo_dir, "pmc_fetch", "*/*_counter_collection.csv"))
+    lw = newest(os.path.join(lo_dir, "pmc_write", "*/*_counter_collection.csv"))
+    if lf and lw:
+        def mean_solo(path, counter):
+            vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(path)) if kname(r["Kernel_Name"]).startswith("k_solo") and r["Counter_Name"] == counter]
+            return sum(vals) / len(vals) * 1024.0 / win_per_disp
+        loop_fetch, loop_write = mean_solo(lf, "FETCH_SIZE"), mean_solo(lw, "WRITE_SIZE")
+        pass_read = read_est - loop_fetch  # (the loop's reads are 8-byte gathers and 16-byte row loads: taken as reported)
+        t.update({"loop_only_fetch_bytes_per_window": loop_fetch, "loop_only_write_bytes_per_window": loop_write,
+                  "pass_only_read_bytes_per_window": pass_read, "pass_only_bytes_per_window": pass_read + tile_bytes,
+                  "pass_only_ratio": (pass_read + tile_bytes) / (2.0 * tile_bytes),
+                  "pass_only_note": "read traffic of the full run minus that of the same windows with the dense passes skipped (debug library; that run also writes the A side "
+                                    "of the slots, which the product run does not: loop_only_write is not comparable) + the tiles written once: the figure comparable with "
+                                    "traffic_batch256.json's hbm_bytes_per_launch / algorithmic (the pass as a kernel of its own, round 4: 1.127)"})
     out["traffic"] = t
     json.dump(t, open("profiles/traffic_batch256_fused.json", "w"), indent=1)
 json.dump(out, open("profiles/r05_batch256_fusedpmc_summary.json", "w"), indent=1)
