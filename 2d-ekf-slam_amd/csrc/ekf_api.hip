@@ -438,6 +438,10 @@ static int create_impl(ekf_batch *h, int batch, int capacity_landmarks, int devi
     // 38.0 k -> 39.5 k; with 32 workgroups -- N = 2048 -- the two extra waves at every barrier cost more than the shorter fold gives:
     // 37.0 k -> 35.8 k, so only up to 16 workgroups)
     if (dv.lpw <= 64 && G > 1 && G <= 16) workers = 192;
+    // ... and, whatever the number of workgroups, where the fold is long: 48 virtual slots and more (round 5: N = 4096 as 64 workgroups of 64 landmarks
+    // with two windows of 32 in LDS: 36.6 k steps/s with the helper waves, 32.9 k without)
+    if (dv.lpw <= 64 && G > 1 && cache_slots >= 48) workers = 192;
+    if (getenv("EKF_CHAIN_HELPERS") && dv.lpw <= 64 && G > 1) workers = atoi(getenv("EKF_CHAIN_HELPERS")) != 0 ? 192 : (dv.lpw + 63) / 64 * 64;  // (experiments: force / forbid the two helper waves)
     h->chain_threads = 64 + workers;  // wave 0 is the control wave
     if (h->solo_kernel) h->chain_threads = (capacity_landmarks + 63) / 64 * 64;  // k_solo: one landmark per thread, no control wave
     dv.hpw = (dv.lpw + 63) / 64;

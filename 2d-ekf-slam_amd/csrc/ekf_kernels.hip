@@ -1665,6 +1665,9 @@ finish:  // (also the way out when a bounded wait ran out: the sticky status say
 #if !defined(EKF_FLUSH_NT)
 #define EKF_FLUSH_NT 1
 #endif
+#if !defined(EKF_FLUSH16_PIPE)
+#define EKF_FLUSH16_PIPE 1  // (round 5: default; 0 = the four sweeps of four of round 4) nine to sixteen pairs take the software-pipelined whole-tile form (flush_tile_whole_pipe)
+#endif
 // bit 0: nontemporal stores, bit 1: nontemporal loads (experiments; the default is 1)
 #if EKF_FLUSH_NT & 2
 #define TILE_LD(p) __builtin_nontemporal_load((const double2_t *)(p))
@@ -1808,6 +1811,74 @@ __device__ __forceinline__ void flush_tile_whole(const double *tp, double *tq, c
     }
 }
 
+// The same pass over nine to sixteen pairs, software-pipelined (round 4 built it for the batch, where it did not pay -- that pass is bound by the
+// chip's fp64 MFMA rate --, round 5 re-measured it for a single N = 4096 filter beside its chain kernel, whose window of 32 makes this the pass of the
+// default bench line): eight sweeps of two pairs, the operands of sweep s + 1 requested in front of the MFMAs of sweep s (two static buffers of 32
+// registers).  Loads return in order, so the first sweep's operands are requested IN FRONT of the tile -- waiting for them does not mean waiting for
+// the tile -- and that sweep runs row-block by row-block behind the tile's loads; the last sweep stores each row-block behind its last MFMA, under the
+// MFMAs of the next.  A sweep past the live pairs is skipped whole.  Pairs ascending on every chain: the same sums as flush_tile_whole.
+template <bool DIAG>
+__device__ __forceinline__ void flush_tile_whole_pipe(const double *tp, double *tq, const double *FA, const double *FB, unsigned lo, unsigned live, int npl, int zero_slot, size_t slot_stride) {
+    double4_t acc[16];
+    double bq[2][2][4], a[2][4][2];  // [buffer][pair][column-block], [buffer][row-block][pair]
+    auto request = [&](int buf) {
+        size_t mo[2];
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            const int m = live ? __builtin_ctz(live) : zero_slot;
+            live &= live - 1;
+            mo[p] = (size_t)m * slot_stride;
+        }
+#pragma unroll
+        for (int p = 0; p < 2; p++)
+#pragma unroll
+            for (int cc = 0; cc < 4; cc++) bq[buf][p][cc] = (FB + mo[p] + cc * 64)[lo];
+#pragma unroll
+        for (int rc = 0; rc < 4; rc++)
+#pragma unroll
+            for (int p = 0; p < 2; p++) a[buf][rc][p] = (FA + mo[p] + rc * 64)[lo];
+    };
+    request(0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ch = 0; ch < 16; ch++) {
+        if (DIAG && (ch & 3) < (ch >> 2)) continue;
+        double2_t l2 = TILE_LD(tp + ch * 256);
+        double2_t h2 = TILE_LD(tp + ch * 256 + 128);
+        acc[ch] = (double4_t){l2.x, l2.y, h2.x, h2.y};
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int sweep = 0; sweep < 8; sweep++) {
+        const bool on = sweep * 2 < npl;  // (uniform)
+        if (sweep + 1 < 8 && (sweep + 1) * 2 < npl) request((sweep + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int rc = 0; rc < 4; rc++) {
+            if (on) {
+#pragma unroll
+                for (int p = 0; p < 2; p++)
+#pragma unroll
+                    for (int cc = 0; cc < 4; cc++) {
+                        if (DIAG && cc < rc) continue;
+                        acc[rc * 4 + cc] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[sweep & 1][rc][p], bq[sweep & 1][p][cc], acc[rc * 4 + cc], 0, 0, 0);
+                    }
+            }
+            if (sweep == 7) {
+#pragma unroll
+                for (int cc = 0; cc < 4; cc++) {
+                    if (DIAG && cc < rc) continue;
+                    const int ch = rc * 4 + cc;
+                    TILE_ST(tq + ch * 256, ((double2_t){acc[ch].x, acc[ch].y}));
+                    TILE_ST(tq + ch * 256 + 128, ((double2_t){acc[ch].z, acc[ch].w}));
+                }
+            }
+            if (sweep == 0 || sweep == 7) __builtin_amdgcn_sched_barrier(0);  // (keep the row-block order of the first and the last sweep)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // Row-block form: the contraction runs row-block by row-block (16 rows x 64 columns = 4 chains) over ALL live
 // slot pairs, so that a row-block is stored as soon as it is finished: the stores of row-block r overlap the
 // MFMAs of r+1 instead of waiting behind the whole tile's contraction.  The B operands of up to 8 pairs stay in
@@ -1884,8 +1955,13 @@ __global__ __launch_bounds__(256, 2) void k_flush_rb(EkfDev dv, int nT_hi, int s
         return;
     }
     if (npl <= 16) {  // windows of 17 to 32
+#if EKF_FLUSH16_PIPE
+        if (uni(I) == uni(J)) flush_tile_whole_pipe<true>(tp, tq, FA, FB, lo, live, npl, zero_slot, slot_stride);
+        else flush_tile_whole_pipe<false>(tp, tq, FA, FB, lo, live, npl, zero_slot, slot_stride);
+#else
         if (uni(I) == uni(J)) flush_tile_whole<true>(tp, tq, FA, FB, lo, live, npl, zero_slot, slot_stride);
         else flush_tile_whole<false>(tp, tq, FA, FB, lo, live, npl, zero_slot, slot_stride);
+#endif
         return;
     }
     // more than sixteen pairs (does not occur: EKF_MAX_PENDING = 32): slot-major walk (whole tile loaded, all pairs, then stored), two pairs per iteration

@@ -52,11 +52,14 @@ WORKLOADS = {
 }
 
 def window_for(workload, asked):
-    """measurements per dense pass: --max-pending when given, else 16 -- and 32 for batch256, whose one-workgroup filters (k_solo) keep the
-    first half of a long window in accumulation registers: the chain and the pass are serial there, so half as many passes pay"""
+    """measurements per dense pass: --max-pending when given, else the workload's best (the library's own default is 16): 32 for batch256, whose
+    one-workgroup filters (k_solo) keep the first half of a long window in accumulation registers -- the chain and the pass are serial there, so
+    half as many passes pay -- and, since round 5, 32 for N = 4096 and beyond: the library then shapes the filter as 64 workgroups of one owner
+    wave (two windows of 32 fit their LDS), the dense pass runs half as often and stops co-limiting the window (31.2 k -> 36.5 k steps/s over 512
+    steps); N = 1024, whose pass is a tenth of its window, is fastest at 16 (42.7 k against 41.9 k at 32)."""
     if asked:
         return asked
-    return 32 if workload == "batch256" else 16
+    return 16 if workload == "n1024" else 32
 
 
 def make_filters(pkg, mc, workload, lo, hi, steps, M, dev_id, max_pending, log_entries, tail_windows=0):

@@ -56,7 +56,7 @@ int main(int argc, char **argv) {
     bool timing = false, detect = false, quiet = false;  // --quiet: without slam.cpp's stdout chatter ("Compass: ...", "Update: New 12")
     // digits of the data files.  The reference's streams are never given a precision (slam.cpp:177,181,200; kalmanfilter.cpp:51,58), so it
     // writes the default 6 significant digits: that is the default here too -- a replay's files compare byte for byte with a reference run's on
-    // the same values.  --precision 17 writes round-trip digits (the parity tests compare the files with oracle values to the last bit).
+    // the same values.  --precision 17 writes round-trip digits (the parity tests compare the files value for value).
     int precision = 6;
     for (int i = 1; i < argc; i++) {
         if (!std::strcmp(argv[i], "--state") && i + 1 < argc) state_in = argv[++i];

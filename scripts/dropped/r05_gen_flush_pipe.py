@@ -1,26 +1,24 @@
 #!/usr/bin/env python3
-"""Writes 2d-ekf-slam_amd/csrc/solo_pipe_agpr.h: the software-pipelined tile of k_solo's own dense pass (round 5).
+"""Writes 2d-ekf-slam_amd/csrc/flush_pipe_agpr.h: one 64 x 64 tile of the 16-pair dense pass as ONE software-pipelined asm statement (round 5).
 
-One wave per SIMD hides nothing but what the wave itself overlaps, and the pass of rounds 3-4 (solo_pass_agpr.h + compiler-managed B
-operands) spent 12 us per tile on 6.8 us of MFMAs: the tile's trip to HBM, then one trip for each half of the B operands, all exposed.
-Here ONE asm statement carries a whole tile, so that registers and waits can be owned by hand:
-  * the tile lives in a128..a255 as before (16 chains of 8 registers);
-  * the B operands travel two pairs (one "sub-sweep": 2 pairs x 4 column blocks = 8 loads of 8 bytes per lane) at a time through a ring
-    of three buffers in v208..v255 -- the registers the fold's asm keeps free of long-lived values anyway (ekf_kernels.hip: FOLD_CLOBBERS) --
-    requested two sub-sweeps (64 MFMAs, 1.7 us) ahead of their use;
-  * in the LAST sub-sweep a row-block's chains are stored as soon as its MFMAs are done and the NEXT tile's chains are requested into
-    the same registers at once: the next tile's trip to HBM runs under this tile's remaining MFMAs (and its first two sub-sweeps of B
-    operands are requested here too);
-  * every wait is an `s_waitcnt vmcnt(N)` computed by this generator from the issue order (vector memory operations complete in
-    order): N = the operations issued after the youngest one that is needed.  A block may be entered with everything it assumes in
-    flight already complete (after the prologue, after a tile row's A stage, after a diagonal tile: the caller drains) -- waits then
-    pass at once; it must never be entered with FEWER younger operations in flight than assumed but the needed ones still pending,
-    which is why the non-diagonal block's entry assumption is exactly its own exit state and the caller drains everywhere else.
-The A operands come from the wave's LDS stage (one ds_read_b64 per pair and row-block, one element ahead), pairs are applied to every
-chain in ascending order: bitwise the pass kernel's result.  NP = 16 pairs (windows of 32); other windows keep the older form.
-DROPPED (round 5): parity-green at the first run and no faster -- the pass is bound by the MFMA rate and by HBM, not by the latencies this form
-hides.  Kept with scripts/dropped/r05_in_kernel_pass_software_pipelined.patch (the glue in ekf_solo.hip).
-CPU; usage: python3 scripts/dropped/r05_gen_solo_pipe.py [--check]."""
+Used by k_flush_rows (ekf_flush_rows.hip): the dense pass of a full window of 32 measurements for a single large filter, one wave per SIMD, a wave
+owning a run of consecutive tiles of one tile row.  At one wave per SIMD nothing but the wave itself hides a memory trip, so registers and waits are
+owned by hand:
+  * the tile lives in a128..a255 (16 chains of 8 registers), loaded, contracted (v_mfma_f64_16x16x4_f64, the chain as C and D) and stored from there;
+  * the B operands travel two pairs (one "sub-sweep": 2 pairs x 4 column blocks = 8 loads of 8 bytes per lane) at a time through a ring of three
+    buffers in v208..v255, requested two sub-sweeps (64 MFMAs) ahead of their use;
+  * in the LAST sub-sweep a row-block's chains are stored as soon as its MFMAs are done (18 wait states) and the NEXT tile's chains are requested
+    into the same registers at once: the next tile's trip to HBM runs under this tile's remaining MFMAs (its first two sub-sweeps of B operands
+    are requested here too).  Loads come from `next`, stores go to `tile`: a pass from buffer to buffer needs nothing else;
+  * every wait is an `s_waitcnt vmcnt(N)` computed by this generator from the issue order (vector memory operations complete in order): N = the
+    operations issued after the youngest one that is needed.  A block may be entered with everything it assumes in flight already complete (after
+    the prologue, after a diagonal tile: the caller drains) -- waits then pass at once; it must never be entered with FEWER younger operations in
+    flight than assumed while the needed ones are pending, which is why the non-diagonal block's entry assumption is exactly its own exit state
+    (asserted as a fixed point) and the caller drains everywhere else.
+The A operands come from the wave's LDS stage (one ds_read_b64 per pair and row-block, one element ahead); pairs are applied to every chain in
+ascending order, as k_flush_rb applies them.  First built for k_solo's own pass (scripts/dropped/r05_in_kernel_pass_software_pipelined.patch), where
+it was bitwise equal at the first run and no faster -- that pass is MFMA-bound; the pass of a single N = 4096 filter beside its chain kernel is not.
+CPU; usage: python3 scripts/r05_gen_flush_pipe.py [--check]."""
 import os
 import sys
 
@@ -190,7 +188,7 @@ def main():
                 p.vmem("global_load_dwordx2 v[%d:%d], %%[vbn], %%[fbn] offset:%d" % (b_reg(s_, pl, cc), b_reg(s_, pl, cc) + 1, cc * 512), "B")
             p.ins("v_add_u32 %[vbn], %[ss], %[vbn]")
     p.ins("s_waitcnt vmcnt(0)")
-    head = ("// solo_pipe_agpr.h -- generated by scripts/r05_gen_solo_pipe.py: one tile of k_solo's own dense pass as ONE software-pipelined asm statement\n"
+    head = ("// flush_pipe_agpr.h -- generated by scripts/r05_gen_flush_pipe.py: one tile of the 16-pair dense pass (k_flush_rows) as ONE software-pipelined asm statement\n"
             "// (tile in a128..a255; B operands two pairs at a time through a ring of three buffers in v208..v255, requested two sub-sweeps ahead; the\n"
             "// next tile's chains requested as this tile's row-blocks are stored; every s_waitcnt vmcnt computed from the issue order).  %d pairs.\n"
             "// pp_tile_nd: a non-diagonal tile; its entry assumption is its own exit state.  pp_tile_dg: a diagonal tile (chains below the diagonal\n"
@@ -201,10 +199,10 @@ def main():
     text += c_block("pp_tile_nd", "%d instructions" % len(nd.lines), nd)
     text += c_block("pp_tile_dg", "%d instructions" % len(dg.lines), dg)
     text += c_block("pp_prologue", "%d instructions" % len(p.lines), p)
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "2d-ekf-slam_amd", "csrc", "solo_pipe_agpr.h")
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "2d-ekf-slam_amd", "csrc", "flush_pipe_agpr.h")
     if "--check" in sys.argv:
         same = os.path.exists(path) and open(path).read() == text
-        print("solo_pipe_agpr.h %s the generator's output" % ("is" if same else "DIFFERS from"))
+        print("flush_pipe_agpr.h %s the generator's output" % ("is" if same else "DIFFERS from"))
         return 0 if same else 1
     open(path, "w").write(text)
     if "--dump" in sys.argv:

@@ -8,7 +8,7 @@ import __graft_entry__ as ge
 pkg = ge.load_package()
 NAMES = ["other ops", "sweep+wg argmin", "exchange", "gate+bookkeeping", "stage+barrier", "apply | robot block", "end barrier", "prologue (per measurement)"]
 
-def run(N, maxp, steps=32, warm=8, M=int(os.environ.get("MEAS", "4"))):
+def run(N, maxp, steps=64, warm=16, M=int(os.environ.get("MEAS", "4"))):
     f = pkg.FilterBatch(1, N, max_pending=maxp)
     x0, P0 = pkg.scenarios.injected_state(N, seed=1)
     sc = pkg.scenarios.steady_script(x0, steps=steps + warm, M=M, seed=2)
@@ -27,5 +27,5 @@ def run(N, maxp, steps=32, warm=8, M=int(os.environ.get("MEAS", "4"))):
           + "; segment prologue per window (us): end of the segment before + waits %.2f, records + slot kinds %.2f, LDS refill / shift + state %.2f" % (buf[26] * 0.01 / (nm / maxp), buf[27] * 0.01 / (nm / maxp), buf[23] * 0.01 / (nm / maxp)) + "; control lane: record read %.2f of its stage" % (buf[12] * 0.01 / nm), flush=True)
     f.close()
 
-for N, maxp in [(int(v), 16) for v in os.environ.get("STAMP_N", "4096").split(",")]:
+for N, maxp in [(int(v), int(os.environ.get("MAXP", "16"))) for v in os.environ.get("STAMP_N", "4096").split(",")]:
     run(N, maxp)

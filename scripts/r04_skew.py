@@ -37,7 +37,9 @@ prev_owner = np.roll(owner, 1)
 print("the last publisher is: workgroup 0 in %.0f %% of the exchanges, the previous measurement's winner-owner in %.0f %%, this measurement's winner-owner in %.0f %%" %
       (100 * np.mean(last[sel] == 0), 100 * np.mean(last[sel] == prev_owner[sel]), 100 * np.mean(last[sel] == owner[sel])))
 per = np.diff(done)[sel]
-print("exchange to exchange: median %.2f us" % np.median(per))
+print("exchange to exchange: median %.2f us, mean %.2f, p10 %.2f, p90 %.2f, p99 %.2f, max %.2f (every fourth follows a Propagate)" % (np.median(per), per.mean(), np.percentile(per, 10), np.percentile(per, 90), np.percentile(per, 99), per.max()))
+pos = (np.arange(n - 1)[sel]) % 16
+print("mean period by slot in the window:", " ".join("%.2f" % per[pos == q].mean() for q in range(16)))
 hist = np.bincount(last[sel], minlength=G)
 print("last-publisher histogram:", hist.tolist())
 # lateness of the previous winner-owner relative to the median workgroup

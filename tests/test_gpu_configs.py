@@ -126,16 +126,18 @@ def test_config1_as_stated_1000_steps(pkg, oc):
     f.close()
 
 
-def test_config3_benchmarked_configuration_vs_oracle(pkg, oc, pipeline_mode):
-    """N = 4096 (dense P 8195 x 8195), window 16, the pipeline mode under test: the configuration BENCH_rNN times.
-    Oracle check after step 1 and after step 5 (20 measurements: one full window folded by a dense pass that, in
-    overlap mode, runs beside the chain kernels of the second window, plus a partly filled window)."""
+@pytest.mark.parametrize("max_pending", [32, 16])
+def test_config3_benchmarked_configuration_vs_oracle(pkg, oc, pipeline_mode, max_pending):
+    """N = 4096 (dense P 8195 x 8195), the pipeline mode under test, window 32 -- the configuration BENCH_rNN times since round 5: in overlap
+    mode 64 chain workgroups of one owner wave and two helper waves, two windows of 32 in LDS, 16-pair dense passes -- and window 16 (rounds
+    1-4: 32 workgroups of two owner waves).  Oracle check after steps 1, 5 and 9 (36 measurements: with the window of 32 one full window folded
+    by a dense pass that, in overlap mode, runs beside the chain kernels of the second, plus a partly filled one; two and a quarter windows of 16)."""
     M = 4
-    N, x0, P0, sc = bench_inputs(pkg, "n4096", 5)
-    ref = cached("config3", lambda: oracle_checkpoints(oc, x0, P0, sc, M, (1, 5)))
-    for steps in (1, 5):
-        f = pkg.FilterBatch(1, N, max_pending=16)
-        assert f.window == 16 and f.overlap == (pipeline_mode == "overlap")
+    N, x0, P0, sc = bench_inputs(pkg, "n4096", 9)
+    ref = cached("config3", lambda: oracle_checkpoints(oc, x0, P0, sc, M, (1, 5, 9)))
+    for steps in (1, 5, 9):
+        f = pkg.FilterBatch(1, N, max_pending=max_pending)
+        assert f.window == max_pending and f.overlap == (pipeline_mode == "overlap")
         f.set_state(x0, P0)
         load_script(f, [sc])
         f.script_run(0, steps)
@@ -150,16 +152,16 @@ def test_config3_benchmarked_configuration_vs_oracle(pkg, oc, pipeline_mode):
         del xg, Pg
 
 
-def test_config3_sixty_steps_across_several_multi_segment_launches(pkg, oc, pipeline_mode):
-    """The benchmarked configuration for 60 steps = 15 windows: in overlap mode two multi-segment chain launches (12 + 3
-    windows, LDS caches shifted at every window boundary, 14 gated dense passes and a terminal one), fed in two script_run
-    calls so that the second starts on a window the first left open.  Decisions and the full 8195 x 8195 state against the
-    oracle (structured mode, OpenMP)."""
+@pytest.mark.parametrize("max_pending", [32, 16])
+def test_config3_sixty_steps_across_several_multi_segment_launches(pkg, oc, pipeline_mode, max_pending):
+    """The benchmarked configuration for 60 steps = 15 windows of 16 or seven and a half of 32: in overlap mode multi-segment chain launches
+    (LDS caches shifted at every window boundary, gated dense passes and a terminal one), fed in two script_run calls so that the second starts
+    on a window the first left open.  Decisions and the full 8195 x 8195 state against the oracle (structured mode, OpenMP)."""
     M, steps = 4, 60
     N, x0, P0, sc = bench_inputs(pkg, "n4096", steps)
     ref = cached("config3_60", lambda: oracle_checkpoints(oc, x0, P0, sc, M, (steps,)))[steps]
-    f = pkg.FilterBatch(1, N, max_pending=16)
-    assert f.window == 16 and f.overlap == (pipeline_mode == "overlap")
+    f = pkg.FilterBatch(1, N, max_pending=max_pending)
+    assert f.window == max_pending and f.overlap == (pipeline_mode == "overlap")
     f.set_state(x0, P0)
     load_script(f, [sc])
     f.script_run(0, 26)
