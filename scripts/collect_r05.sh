@@ -8,9 +8,11 @@ cd $R
 mkdir -p gpurun_out
 WHAT=${1:?profiles | fused | bench}
 if [ "$WHAT" = profiles ]; then
-bash scripts/profile_r05.sh n4096_w16_overlap --steps 64 --warmup 8 || exit 1
+# (the bench's default window for N = 4096 is 32 since round 5 -- 64 chain workgroups --; the window of 16 of rounds 1-4 is profiled beside it)
+bash scripts/profile_r05.sh n4096_w16_overlap --steps 64 --warmup 8 --max-pending 16 || exit 1
+bash scripts/profile_r05.sh n4096_w32_overlap --steps 64 --warmup 8 || exit 1
 bash scripts/profile_r05.sh n4096_driver_command --steps 20 --warmup 5 || exit 1
-EKF_OVERLAP=0 bash scripts/profile_r05.sh n4096_w16_inplace --steps 64 --warmup 8 || exit 1
+EKF_OVERLAP=0 bash scripts/profile_r05.sh n4096_w32_inplace --steps 64 --warmup 8 || exit 1
 EKF_SOLO_FUSE=0 bash scripts/profile_r05.sh batch256 --workload batch256 --steps 64 --warmup 8 || exit 1
 bash scripts/profile_r05.sh batch256_fused --workload batch256 --steps 96 --warmup 8 || exit 1
 bash scripts/profile_r05.sh n1024 --workload n1024 --steps 64 --warmup 8 || exit 1

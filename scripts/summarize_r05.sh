@@ -3,9 +3,11 @@
 # (profiles/ on the GPU box is not merged back, so this runs here)
 cd "$(dirname "$0")/.."
 A="--no-cpu-baseline --no-secondary"
-python3 scripts/summarize_profile.py gpurun_out/prof_r05_n4096_w16_overlap r05_n4096_w16_overlap "$A --steps 64 --warmup 8" | tail -1
+# (the window of 16 first: profiles/traffic_n4096.json is then left by the default configuration, window 32, which bench.py replays)
+python3 scripts/summarize_profile.py gpurun_out/prof_r05_n4096_w16_overlap r05_n4096_w16_overlap "$A --steps 64 --warmup 8 --max-pending 16" | tail -1
+python3 scripts/summarize_profile.py gpurun_out/prof_r05_n4096_w32_overlap r05_n4096_w32_overlap "$A --steps 64 --warmup 8" | tail -1
 python3 scripts/summarize_profile.py gpurun_out/prof_r05_n4096_driver_command r05_n4096_driver_command "$A --steps 20 --warmup 5" | tail -1
-EKF_OVERLAP=0 python3 scripts/summarize_profile.py gpurun_out/prof_r05_n4096_w16_inplace r05_n4096_w16_inplace "$A --steps 64 --warmup 8" | tail -1
+EKF_OVERLAP=0 python3 scripts/summarize_profile.py gpurun_out/prof_r05_n4096_w32_inplace r05_n4096_w32_inplace "$A --steps 64 --warmup 8" | tail -1
 EKF_SOLO_FUSE=0 python3 scripts/summarize_profile.py gpurun_out/prof_r05_batch256 r05_batch256 "$A --workload batch256 --steps 64 --warmup 8 (EKF_SOLO_FUSE=0)" | tail -1
 python3 scripts/summarize_profile.py gpurun_out/prof_r05_batch256_fused r05_batch256_fused "$A --workload batch256 --steps 96 --warmup 8" | tail -1
 python3 scripts/summarize_profile.py gpurun_out/prof_r05_n1024 r05_n1024 "$A --workload n1024 --steps 64 --warmup 8" | tail -1
@@ -15,7 +17,7 @@ import json, sys
 sys.path.insert(0, ".")
 import bench
 print("kernel digest", bench.kernel_source_digest())
-for t in ("n4096_w16_overlap", "n4096_driver_command", "n4096_w16_inplace", "batch256", "batch256_fused", "n1024"):
+for t in ("n4096_w16_overlap", "n4096_w32_overlap", "n4096_driver_command", "n4096_w32_inplace", "batch256", "batch256_fused", "n1024"):
     j = json.load(open("profiles/r05_%s_summary.json" % t))
     ks = {k: (v["calls"], round(v["avg_us"], 1)) for k, v in j["kernels"].items() if k.startswith(("k_chain", "k_flush", "k_solo"))}
     print(t, ks, "traffic/algorithmic %.3f" % (j["traffic"]["hbm_bytes_per_launch"] / j["traffic"]["algorithmic_bytes_per_launch"]) if "traffic" in j else "")
