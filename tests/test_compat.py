@@ -238,6 +238,38 @@ def test_compat_featuredetector_header_keeps_the_reference_interface():
     assert out.returncode == 0, out.stderr
 
 
+REFERENCE = "/root/reference"
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REFERENCE, "slam.cpp")), reason="the reference tree is not on this machine (it never travels to the GPU box)")
+def test_the_reference_slam_cpp_type_checks_unchanged_against_the_compat_headers(tmp_path):
+    """north_star: "so slam.cpp ... feed it unchanged".  The compiler's front end (g++ -fsyntax-only: nothing is built, linked or run)
+    goes over the reference's own slam.cpp -- reached through a symbolic link, so that its quoted includes resolve in a directory of
+    ours -- with compat/kalmanfilter.h at odometry/kalmanfilter.h and compat/featuredetector.h at features/featuredetector.h
+    (slam.cpp:11,13), the two declaration-only test doubles at Aria.h and Eigen/Dense (slam.cpp:5,10; this image has neither), and the
+    reference's own movement/movementcontroller.h and features/houghtransform.h (slam.cpp:12,14: declarations slam.cpp needs, out of
+    this path's scope) where they are.  Every use slam.cpp makes of KalmanFilter and FeatureDetector -- the constructors :110,:127, doPropagation
+    :136, getFeatures :141, NO_COMPASS :144, doUpdateCompass :146, doUpdate with Eigen matrices :170, the public mirrors :171-181 --
+    must type-check, or the drop-in claim is false."""
+    tu = tmp_path / "tu"
+    for d in ("odometry", "features", "movement", "Eigen"):
+        (tu / d).mkdir(parents=True)
+    os.symlink(os.path.join(REFERENCE, "slam.cpp"), tu / "slam.cpp")
+    (tu / "odometry" / "kalmanfilter.h").write_text('#include "%s"\n' % os.path.join(ROOT, "compat", "kalmanfilter.h"))
+    (tu / "features" / "featuredetector.h").write_text('#include "%s"\n' % os.path.join(ROOT, "compat", "featuredetector.h"))
+    (tu / "Aria.h").write_text('#include "%s"\n' % os.path.join(ROOT, "compat", "standin", "aria_standin.h"))
+    (tu / "Eigen" / "Dense").write_text('#include "%s"\n' % os.path.join(ROOT, "compat", "standin", "eigen_standin.h"))
+    os.symlink(os.path.join(REFERENCE, "movement", "movementcontroller.h"), tu / "movement" / "movementcontroller.h")
+    os.symlink(os.path.join(REFERENCE, "features", "houghtransform.h"), tu / "features" / "houghtransform.h")
+    out = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-w", "-I", str(tu), str(tu / "slam.cpp")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    # the check bites: without doUpdateCompass the same translation unit must fail
+    broken = open(os.path.join(ROOT, "compat", "kalmanfilter.h")).read().replace("void doUpdateCompass(", "void doUpdateCompass_gone(")
+    (tu / "odometry" / "kalmanfilter.h").write_text(broken.replace('"../include/', '"%s/' % os.path.join(ROOT, "include")).replace('"standin/', '"%s/' % os.path.join(ROOT, "compat", "standin")))
+    out = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-w", "-I", str(tu), str(tu / "slam.cpp")], capture_output=True, text=True)
+    assert out.returncode != 0 and "doUpdateCompass" in out.stderr
+
+
 @pytest.mark.gpu
 def test_replay_detect_runs_perception_and_filter_end_to_end_like_the_oracle(replay_bin, pkg, oc, tmp_path):
     """The whole slam.cpp:130-204 loop with perception in it: every iteration a new sweep -> FeatureDetector::getFeatures
