@@ -488,7 +488,7 @@ static int create_impl(ekf_batch *h, int batch, int capacity_landmarks, int devi
     HIP_TRY(dev_alloc_zero(&dv.n_lm_sweep, B, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.n_lm_flush, B * 2, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.status, B, &h->device_bytes, s));
-    HIP_TRY(dev_alloc_zero(&dv.slot_active, B * 2 * dv.maxp, &h->device_bytes, s));
+    HIP_TRY(dev_alloc_zero(&dv.slot_active, B * 2 * dv.maxp + EKF_MAX_PENDING, &h->device_bytes, s));  // (+ EKF_MAX_PENDING: k_flush_rb reads that many entries of a row unconditionally)
     HIP_TRY(dev_alloc_zero(&dv.slot_meta, B * 2 * dv.maxp, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.pass_flag, 1, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.seg_count, EKF_PLAN_MAX, &h->device_bytes, s));
@@ -1020,12 +1020,27 @@ static int launch_ops(ekf_batch *h, const double *in, const int *cursor, int k0,
         passes.clear();
         return check_launch();
     };
+    // Balanced tail (round 5; multi-workgroup filters in the overlapped multi-segment mode, EKF_BALANCED_TAIL=0 switches it off): when between one
+    // and two windows' worth of measurements are left in this call, the window that begins is closed at HALF of them (rounded up to a whole
+    // slot pair) instead of at max_pending.  A scripted run of 20 steps x 4 measurements at a window of 32 ran 32 | 32 | 16: the pass of the
+    // second window (16 pairs, 165 us beside the chain kernel) outlasted the 16 measurements after it (100 us) and the last window's pass
+    // waited behind it -- 170 us exposed after the chain kernel's end; 32 | 24 | 24 hides the second pass under the third segment and leaves
+    // one 12-pair pass exposed.  Nothing changes for a run whose length is a multiple of the window, nor in the steady state of a long one.
+    static const bool balanced_tail = !(getenv("EKF_BALANCED_TAIL") && atoi(getenv("EKF_BALANCED_TAIL")) == 0);
+    int slots_left = 0;  // slot-consuming operations of this call from op i on
+    for (int q = 0; q < nops; q++) slots_left += consumes[q] ? 1 : 0;
+    int limit = h->dv.maxp;  // where the window being filled closes (a window carried over from an earlier call: max_pending)
     while (i < nops) {
         int start = i, used = h->pending;
+        if (used == 0) {
+            limit = h->dv.maxp;
+            if (balanced_tail && persist && !solo && slots_left > h->dv.maxp && slots_left < 2 * h->dv.maxp) limit = ((slots_left + 1) / 2 + 1) & ~1;
+        }
         while (i < nops && i - start < EKF_CHAIN_MAX_OPS) {
             if (consumes[i]) {
-                if (used == h->dv.maxp) break;
+                if (used == limit) break;
                 used++;
+                slots_left--;
             }
             i++;
         }
@@ -1035,7 +1050,7 @@ static int launch_ops(ekf_batch *h, const double *in, const int *cursor, int k0,
             continue;
         }
         // overlap: the launch that fills the set signals ev_chain from its own dispatch packet (no marker packet)
-        const bool closes = h->overlap && used == h->dv.maxp;
+        const bool closes = h->overlap && used == limit;
         ChainSeg sg;
         sg.k0 = k0 + start, sg.nops = i - start, sg.slot0 = h->pending, sg.set = h->cur_set, sg.buf_read = h->buf_in, sg.n_prev = h->prev_pending;
         if (next_drop > 0 && next_drop < h->prev_pending) {  // (the LDS shift moves whole windows: start a new launch instead)
@@ -1045,7 +1060,7 @@ static int launch_ops(ekf_batch *h, const double *in, const int *cursor, int k0,
         sg.need_pass = h->need_pass, sg.drop = next_drop;
         sg.seq = ++h->chain_seq;  // (one number per segment: every filter's mirror reaches it)
         sg.gate = h->seg_count_base[plan.nseg] + (unsigned long long)h->chain_wgs * h->dv.B;  // every workgroup of the launch has finished this segment
-        sg.self_pass = (fuse && used == h->dv.maxp && !h->dbg_skip_flush) ? 1 : 0;
+        sg.self_pass = (fuse && used == limit && !h->dbg_skip_flush) ? 1 : 0;
         sg.stagger = 0;
         next_drop = 0;
         plan.s[plan.nseg++] = sg;
@@ -1060,12 +1075,12 @@ static int launch_ops(ekf_batch *h, const double *in, const int *cursor, int k0,
             h->chain_signalled = closes;
         } else {
             h->chain_signalled = false;
-            if (persist && used == h->dv.maxp) h->open_set_gate = sg.gate, h->open_gate_idx = plan.nseg - 1;
+            if (persist && used == limit) h->open_set_gate = sg.gate, h->open_gate_idx = plan.nseg - 1;
         }
         if (sg.self_pass) {
             h->cur_set ^= 1;  // folded by the launch itself: the next segment starts an empty window
             h->pending = 0;
-        } else if (used == h->dv.maxp && !(defer_last_close && i == nops)) {
+        } else if (used == limit && !(defer_last_close && i == nops)) {
             int rc = close_set(h, false, persist ? &passes : nullptr);
             if (rc) return rc;
             next_drop = sg.n_prev;  // the next segment starts a window: the set whose pass has finished leaves the LDS caches

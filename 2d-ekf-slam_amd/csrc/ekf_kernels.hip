@@ -1907,10 +1907,13 @@ __global__ __launch_bounds__(256, 2) void k_flush_rb(EkfDev dv, int nT_hi, int s
     }
     b += b_off;
     int lane = threadIdx.x & 63;
-    int u = wg * 4 + (threadIdx.x >> 6);
+    // (round 5) the wave's number as a scalar: the tile table, the live list and the landmark count then arrive by SCALAR loads -- through the
+    // scalar cache, not in the queue of the other waves' tile traffic.  As a per-lane load the table entry was a trip through the vector memory
+    // path in front of everything else the wave does, and the live list a loop of 16 scalar loads, each waited for.
+    const int u = wg * 4 + uni((int)(threadIdx.x >> 6));
     int I, J;
     if (tile_map) {
-        const int packed = uni(tile_map[u]);
+        const int packed = tile_map[u];
         if (packed < 0) return;
         I = packed >> 16, J = packed & 0xffff;
     } else {
@@ -1938,7 +1941,15 @@ __global__ __launch_bounds__(256, 2) void k_flush_rb(EkfDev dv, int nT_hi, int s
     const int zero_slot = dv.maxpairs;
 
     unsigned live = 0;  // slot PAIRS with at least one live slot (a dead half holds zeros)
-    for (int m = 0; m < nslots; m++) live |= (active[m] ? 1u : 0u) << (m >> 1);
+    {
+        // all EKF_MAX_PENDING entries at once (the array is padded by that many, create_impl), masked to the first nslots afterwards: four wide
+        // scalar loads and one wait instead of a loop
+        int av[EKF_MAX_PENDING];
+#pragma unroll
+        for (int m = 0; m < EKF_MAX_PENDING; m++) av[m] = active[m];
+#pragma unroll
+        for (int m = 0; m < EKF_MAX_PENDING; m++) live |= ((m < nslots && av[m]) ? 1u : 0u) << (m >> 1);
+    }
     live = (unsigned)uni((int)live);  // wave-uniform: pair offsets live in SGPRs
     const int npl = __builtin_popcount(live);
 
