@@ -107,6 +107,9 @@ struct ekf_batch {
     // Test / experiment hooks.  They exist only in the debug variant of the library (make debug: -DEKF_DEBUG_HOOKS,
     // libekfslam_hip_debug.so); in the product build the fields keep these values and no environment variable can change them.
     bool dbg_skip_flush = false;        // EKF_DEBUG_SKIP_FLUSH=1: timing experiments only, results are wrong
+    bool balanced_tail = true;          // EKF_BALANCED_TAIL=0 (read at create): windows always close at max_pending (launch_ops)
+    long long windows_closed = 0;       // windows handed to a dense pass by close_set since create (ekf_debug_windows: tests)
+    int last_window_slots = 0;          // ... and the slots of the last one
     int dbg_drop_marks_from = 0;        // EKF_DEBUG_DROP_MARKS_FROM=k (and ..._TO=m, exclusive): dense passes k .. m-1 never report completion (tests of the bounded waits)
     int dbg_drop_marks_to = 0x7fffffff;
     // immediate-mode input ring (host-mapped pinned)
@@ -522,6 +525,7 @@ static int create_impl(ekf_batch *h, int batch, int capacity_landmarks, int devi
     }
     HIP_TRY(hipEventCreate(&h->t0));
     HIP_TRY(hipEventCreate(&h->t1));
+    h->balanced_tail = !(getenv("EKF_BALANCED_TAIL") && atoi(getenv("EKF_BALANCED_TAIL")) == 0);
     h->prof_flush = false;
     h->prof_used = 0;
     h->prof_launches = 0;
@@ -843,6 +847,8 @@ static int close_set(ekf_batch *h, bool terminal = false, EnqueueList *defer = n
     const int *tmap = (do_pass && !interleave && h->dv.B == 1) ? tile_map_for(h, nT_hi) : (const int *)nullptr;
     const EkfDev dv = h->dv;
     const int set = h->cur_set, nslots = h->pending, B = h->dv.B;
+    h->windows_closed++;
+    h->last_window_slots = nslots;
     bool mark = false, record_done = false, wait_done_on_chain = false, serial = false;
     int mark_value = 0;
     hipEvent_t done_ev = nullptr;
@@ -1026,7 +1032,7 @@ static int launch_ops(ekf_batch *h, const double *in, const int *cursor, int k0,
     // second window (16 pairs, 165 us beside the chain kernel) outlasted the 16 measurements after it (100 us) and the last window's pass
     // waited behind it -- 170 us exposed after the chain kernel's end; 32 | 24 | 24 hides the second pass under the third segment and leaves
     // one 12-pair pass exposed.  Nothing changes for a run whose length is a multiple of the window, nor in the steady state of a long one.
-    static const bool balanced_tail = !(getenv("EKF_BALANCED_TAIL") && atoi(getenv("EKF_BALANCED_TAIL")) == 0);
+    const bool balanced_tail = h->balanced_tail;
     int slots_left = 0;  // slot-consuming operations of this call from op i on
     for (int q = 0; q < nops; q++) slots_left += consumes[q] ? 1 : 0;
     int limit = h->dv.maxp;  // where the window being filled closes (a window carried over from an earlier call: max_pending)
@@ -1894,6 +1900,14 @@ extern "C" int ekf_script_run(ekf_handle h, int first_step, int n_steps, int use
 }
 
 // Diagnostic tick counters of EKF_CHAIN_STAMPS builds (not declared in the public header).
+// (tests) windows closed since create and the slot count of the last one: how launch_ops cut a scripted run
+extern "C" int ekf_debug_windows(ekf_handle h, long long *closed, int *last_slots) {
+    if (!h || !closed || !last_slots) return set_error(EKF_ERR_BAD_ARG, "null argument");
+    *closed = h->windows_closed;
+    *last_slots = h->last_window_slots;
+    return EKF_OK;
+}
+
 extern "C" int ekf_debug_stamps(ekf_handle h, long long *out16, int reset) {
     if (!h || !out16) return EKF_ERR_BAD_ARG;
     HIP_TRY(hipSetDevice(h->device));

@@ -812,6 +812,55 @@ def test_one_landmark_per_thread_kernel_equals_the_general_kernel(pkg, monkeypat
         assert {d[0] for d in r1[0][0]} >= {pkg.ekfslam.NEW, pkg.ekfslam.OLD} and (r1[0][1].size - 3) // 2 > 8
 
 
+@pytest.mark.parametrize("case", ["n1024_w16", "n4096_w32"])
+def test_balanced_tail_halves_what_is_left_and_changes_nothing_else(pkg, monkeypatch, pipeline_mode, case):
+    """launch_ops (round 5): a scripted run in the overlapped multi-segment mode that has between one and two windows' worth of
+    measurements left closes the window it begins at HALF of them (a whole slot pair) -- 40 measurements at a window of 16 run 16 | 12 | 12
+    instead of 16 | 16 | 8, the driver's 20 steps x 4 at a window of 32 run 32 | 24 | 24 instead of 32 | 32 | 16 -- so that the second-last
+    pass hides under the last segment.  EKF_BALANCED_TAIL=0 against the default: the windows are cut as described (ekf_debug_windows), a
+    run that is a multiple of the window is cut the same either way, and nothing else changes: decisions identical, distances and states
+    equal up to the rounding of a different fold order (as between any two window sizes)."""
+    import ctypes
+    if pipeline_mode != "overlap":
+        pytest.skip("overlap mode only")
+    N, max_pending, steps, cut = {"n1024_w16": (1024, 16, 10, ((3, 8), (3, 12))), "n4096_w32": (4096, 32, 20, ((3, 16), (3, 24)))}[case]
+    M = 4
+    monkeypatch.setenv("EKF_OVERLAP", "1")
+    x0, P0 = pkg.scenarios.injected_state(N, seed=11, extent=50.0 * (N / 4096.0) ** 0.5)
+    sc = pkg.scenarios.steady_script(x0, steps=steps + 2 * max_pending // M, M=M, seed=12, min_separation=1.0)
+    outs = []
+    for bt in ("0", "1"):
+        monkeypatch.setenv("EKF_BALANCED_TAIL", bt)
+        f = pkg.FilterBatch(1, N, max_pending=max_pending, log_capacity=(steps + 2 * max_pending // M) * M)
+        f.L.ekf_debug_windows.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_int)]
+        closed, last = ctypes.c_longlong(), ctypes.c_int()
+
+        def windows():
+            assert f.L.ekf_debug_windows(f.h, ctypes.byref(closed), ctypes.byref(last)) == 0
+            return closed.value, last.value
+
+        f.set_state(x0, P0)
+        f.script_load(sc["ctrl"][:, None, :], sc["z"][:, :, None, :], sc["R"][:, :, None, :])
+        f.script_run(0, steps)
+        f.flush()
+        f.sync()
+        w_tail = windows()
+        # ... and a piece that is a whole number of windows: cut at max_pending either way
+        f.script_run(steps, 2 * max_pending // M)
+        f.flush()
+        f.sync()
+        w_even = windows()
+        outs.append((w_tail, w_even, f.decisions(0, (steps + 2 * max_pending // M) * M)) + f.get_state(0))
+        f.close()
+    (wt0, we0, d0, xa, Pa), (wt1, we1, d1, xb, Pb) = outs
+    assert wt0 == cut[0] and wt1 == cut[1], (wt0, wt1)
+    assert we0 == (wt0[0] + 2, max_pending) and we1 == (wt1[0] + 2, max_pending), (we0, we1)
+    assert [(d[0], d[1]) for d in d0] == [(d[0], d[1]) for d in d1]
+    assert all(abs(a[2] - b[2]) <= 1e-9 * max(1.0, abs(a[2])) for a, b in zip(d0, d1))
+    assert np.abs(xa - xb).max() <= 1e-11 * max(1.0, np.abs(xa).max()) and np.abs(Pa - Pb).max() <= 1e-11 * np.abs(Pa).max()
+    assert_bitwise_symmetric(Pb)
+
+
 def test_multi_segment_launches_with_filters_that_run_ahead(pkg, monkeypatch, pipeline_mode):
     """Regression for the stream gates of multi-segment launches (round-2 advisor finding): workgroups of different filters do not
     wait for each other between segments, so a filter whose measurements are all masked (OP_SKIP_SLOT: no sweep, no exchange,
