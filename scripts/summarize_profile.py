@@ -45,6 +45,24 @@ for n in ("trace", "fetch", "write", "mfma"):
         d = json.loads(open(p).read().strip().splitlines()[-1])
         line = line or d
         summary["bench_lines"][n] = {"value": d["value"], "flush_avg_launch_us_events": d["roofline"]["avg_launch_us"], "frac": d["roofline"]["frac"]}
+# The dense-pass launches of the profiled run one by one, in launch order, from the kernel trace -- and among them the ones of the bench's TIMED
+# region.  The --stats average is over every launch of the process (warm-up passes, the timed region, the four `alone` launches behind it), and
+# since the passes of one run no longer fold the same number of pairs (window 32: 16 pairs; a balanced tail: 12; a terminal pass in place) that
+# average is not the timed region's.  The bench line of the same run says how many launches it timed and how many `alone` launches followed.
+kt = newest(os.path.join(src, "trace/*/*_kernel_trace.csv"))
+if kt and line:
+    rows = sorted((r for r in csv.DictReader(open(kt[0])) if kname(r["Kernel_Name"]).startswith("k_flush_rb")), key=lambda r: int(r["Start_Timestamp"]))
+    durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows]
+    n_timed = int(line["roofline"].get("launches", 0))
+    n_alone = int(line["roofline"].get("alone", {}).get("launches", 0))
+    timed = durs[len(durs) - n_alone - n_timed:len(durs) - n_alone] if 0 < n_timed <= len(durs) - n_alone else []
+    alone = durs[len(durs) - n_alone:] if n_alone else []
+    summary["dense_pass_launches"] = {"per_launch_us_in_launch_order": [round(d, 1) for d in durs],
+                                      "timed_region": {"launches": len(timed), "avg_us": sum(timed) / len(timed) if timed else None,
+                                                       "bench_events_avg_us_same_run": line["roofline"]["avg_launch_us"]},
+                                      "alone": {"launches": len(alone), "avg_us": sum(alone) / len(alone) if alone else None,
+                                                "bench_events_avg_us_same_run": line["roofline"].get("alone", {}).get("avg_launch_us")},
+                                      "note": "timed_region = the launches the bench line of this run counts in roofline.launches, i.e. the ones in front of its `alone` launches"}
 # the dense pass: k_flush_rb<false> (windows up to 16) or k_flush_rb<true> (k_solo's long windows) -- the instantiation the timed region used
 passes = [k for k in summary["kernels"] if k.startswith("k_flush_rb")]
 fl = summary["kernels"][max(passes, key=lambda k: summary["kernels"][k]["calls"])] if passes else {}
