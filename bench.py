@@ -154,11 +154,19 @@ def roofline_record(pkg, f, workload, B, N, K, M, window, launches, flush_ms, al
     chains = tiles * 16 - nT * 6
     bytes_per_launch = filters_per_launch * chains * 256 * 8 * 2
     slots_per_launch = min(window, K * M)
-    flops_per_launch = filters_per_launch * chains * ((slots_per_launch + 1) // 2) * 2048  # one v_mfma_f64_16x16x4_f64 per chain and PAIR of measurements
+    if launches:
+        # what a launch of THIS run folded on average: a balanced tail (32 | 24 | 24 for the driver's 20 steps) and the terminal pass of a run
+        # that is not a whole number of windows fold fewer measurements than the window
+        slots_per_launch = min(float(window), K * M * groups / float(launches))
+    flops_per_launch = filters_per_launch * chains * (slots_per_launch / 2.0) * 2048  # one v_mfma_f64_16x16x4_f64 per chain and PAIR of measurements
     r = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
-         "kernel": "k_flush_rb", "byte_model": "scheme C (one triangle authoritative): every live 16x16 chain of the upper-triangle tiles (2 KiB) read + written per pass -- %d tiles = %d chains, the %d dead chains below the diagonals of the diagonal tiles left out; %d measurements folded per pass" % (tiles, chains, nT * 6, slots_per_launch),
+         "kernel": "k_flush_rb", "byte_model": "scheme C (one triangle authoritative): every live 16x16 chain of the upper-triangle tiles (2 KiB) read + written per pass -- %d tiles = %d chains, the %d dead chains below the diagonals of the diagonal tiles left out; %.4g measurements folded per pass (window %d)" % (tiles, chains, nT * 6, slots_per_launch, window),
          "bytes_per_launch": bytes_per_launch, "launches": int(launches), "avg_launch_us": None, "measurements_per_launch": slots_per_launch,
          "mfma": {"achieved": None, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None, "flops_per_launch": flops_per_launch}}
+    if window > 16 and B == 1:
+        r["window_note"] = ("window %d: a launch folds up to %d slot pairs into the same bytes that rounds 1-4 folded 8 pairs into (window 16: frac 0.61-0.64, still profiled: "
+                            "profiles/r05_n4096_w16_overlap_summary.json) -- half the passes and half the HBM bytes per folded measurement, twice the fp64 MFMA work per byte "
+                            "(roofline.mfma); DESIGN.md 4.2 'The 16-pair pass' has the lab measurements of what that mix reaches" % (window, window // 2))
     if launches:
         avg_s = flush_ms / 1e3 / launches
         r["avg_launch_us"] = avg_s * 1e6
