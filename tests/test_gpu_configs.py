@@ -271,24 +271,27 @@ def test_strongly_correlated_covariance(pkg, oc, copies, max_pending):
     f.close()
 
 
-def test_strongly_correlated_covariance_at_bench_size(pkg, oc):
+@pytest.mark.parametrize("max_pending", [16, 32])
+def test_strongly_correlated_covariance_at_bench_size(pkg, oc, max_pending):
     """The same kind of covariance at the BENCH size: helpers.correlated_state(copies=73) = 56 x 73 = 4088 landmarks (n = 8179,
-    128 x 128 tiles, 32 chain workgroups, both pipeline modes) -- every N = 4096 test besides this one uses the survey's near-diagonal
+    128 x 128 tiles, both pipeline modes) -- every N = 4096 test besides this one uses the survey's near-diagonal
     injected P (off-diagonals of 3e-6 beside a diagonal of 1e-2).  Here every tile of P_LL moves by O(diag) per measurement.
-    Eight scripted steps = 32 measurements = two windows of 16 (a multi-segment chain launch and its gated pass in overlap mode),
-    the full state compared; then two more steps = 8 measurements call by call through the immediate API (ekf_propagate /
-    ekf_update, decisions read back after each), the full state compared again.  Against the structured oracle."""
+    At the library's default window of 16 (32 chain workgroups of two owner waves) and at the window of 32 bench.py asks for (64
+    workgroups of one owner wave + two helper waves, the 16-pair dense pass): two windows of scripted measurements (a multi-segment
+    chain launch and its gated pass in overlap mode), the full state compared; then two more steps = 8 measurements call by call
+    through the immediate API (ekf_propagate / ekf_update, decisions read back after each), the full state compared again.
+    Against the structured oracle."""
     copies = 73
     x0, P0 = cached(("corr", copies), lambda: correlated_state(pkg, oc, copies=copies, rho=0.8))
     N = (x0.size - 3) // 2
     assert N >= 4000
     off = np.abs(P0[3:203, 3 + 2 * (N - 100):])  # a corner far from the diagonal
     assert np.median(off) > 0.05 * np.median(np.diag(P0)[3:])  # strongly correlated indeed
-    M, scripted, immediate = 4, 8, 2
+    M, scripted, immediate = 4, 2 * max_pending // 4, 2
     steps = scripted + immediate
     sc = pkg.scenarios.steady_script(x0, steps=steps, M=M, seed=5, min_separation=1.0)
-    f = pkg.FilterBatch(1, N)  # the library's default window
-    assert f.window == 16
+    f = pkg.FilterBatch(1, N, max_pending=max_pending)  # (16 is the library's default window)
+    assert f.window == max_pending
     f.set_state(x0, P0)
     load_script(f, [sc])
     f.script_run(0, scripted)
