@@ -8,7 +8,7 @@ import numpy as np
 import __graft_entry__ as ge
 pkg = ge.load_package()
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 180.0
-cases = [(4096, 16, 1), (4096, 16, 0), (2048, 16, 1), (1000, 5, 1), (300, 4, 1), (4096, 8, 1), (2048, 1, 1), (700, 16, 0)]
+cases = [(4096, 32, 1), (4096, 16, 1), (4096, 16, 0), (4096, 32, 0), (2048, 16, 1), (2048, 32, 1), (1000, 5, 1), (300, 4, 1), (4096, 8, 1), (4096, 24, 1), (2048, 1, 1), (700, 16, 0)]  # (window 32: 64 workgroups of 1 + 2 waves at N = 4096, round 5)
 data = {}
 t_end = time.time() + budget
 it = 0
