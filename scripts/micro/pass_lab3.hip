@@ -143,7 +143,7 @@ int main(int argc, char **argv) {
     const int iters = 40;
     const int nwg = (tiles + 3) / 4;
     const size_t real_stride = (size_t)dv.rows * 4;
-    for (int rep = 0; rep < 2; rep++)
+    for (int rep = 0; rep < 1; rep++)
         for (int nslots : {32, 16}) {
             for (int inplace = 0; inplace < 2; inplace++) {
                 char nm[200];
@@ -168,6 +168,33 @@ int main(int argc, char **argv) {
                 report(nm, time_us([&](int i) { hipLaunchKernelGGL((k_lab<1, false>), dim3(nwg), dim3(256), 0, 0, dv, nT, 0, nslots, S(i), D(i), idmap, i & 1, real_stride, live_all, nT); }, iters));
             }
         }
+    // Isolated launches: the same library kernel, each launch bracketed by its own events (as the library's pass profile brackets them), with
+    // `gap` microseconds of an otherwise idle GPU (one waiting thread) in front of it -- is a pass that starts on a quiet memory system slower
+    // than one of forty back to back?
+    {
+        hipEvent_t e0[24], e1[24];
+        for (int i = 0; i < 24; i++) {
+            CK(hipEventCreate(&e0[i]));
+            CK(hipEventCreate(&e1[i]));
+        }
+        for (int nslots : {32, 16})
+            for (int gap : {0, 20, 60, 200, 1000}) {
+                for (int i = 0; i < 24; i++) {
+                    if (gap) hipLaunchKernelGGL(k_delay, dim3(1), dim3(64), 0, 0, (long long)gap * 100);
+                    hipExtLaunchKernelGGL(k_flush_rb, dim3(nwg, 1), dim3(256), 0, 0, e0[i], e1[i], 0, dv, nT, 0, nslots, i & 1, (i & 1) ^ 1, tmap, 0, i & 1, 0, 1);
+                }
+                CK(hipDeviceSynchronize());
+                double sum = 0;
+                for (int i = 4; i < 24; i++) {
+                    float ms;
+                    CK(hipEventElapsedTime(&ms, e0[i], e1[i]));
+                    sum += ms * 1e3;
+                }
+                char nm[200];
+                snprintf(nm, sizeof nm, "library k_flush_rb a<->b, slots=%d, own events, %d us idle in front of every launch", nslots, gap);
+                report(nm, sum / 20);
+            }
+    }
     ekf_destroy(h);
     return 0;
 }
