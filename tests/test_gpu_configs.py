@@ -174,6 +174,63 @@ def test_config3_sixty_steps_across_several_multi_segment_launches(pkg, oc, pipe
     f.close()
 
 
+@pytest.mark.parametrize("max_pending", [32, 16])
+def test_large_map_n8192_vs_oracle(pkg, oc, pipeline_mode, max_pending):
+    """Twice the benchmarked map: N = 8192 (dense P 16387 x 16387 = 2.1 GB, 257 x 257 tiles = 33 153 upper-triangle tiles per buffer; the
+    reference's state grows without bound, slam.cpp:152-170) with bench.py's n8192 inputs, in both pipeline modes, at the window bench.py asks
+    for (32) and at the library's default (16).  Eight scripted steps = 32 measurements (one window of 32, or two of 16 with the second pass
+    terminal), decisions and the full state against the structured oracle."""
+    M, steps = 4, 8
+    N, x0, P0, sc = bench_inputs(pkg, "n8192", steps)
+    ref = cached("n8192", lambda: oracle_checkpoints(oc, x0, P0, sc, M, (steps,)))[steps]
+    f = pkg.FilterBatch(1, N, max_pending=max_pending)
+    assert f.overlap == (pipeline_mode == "overlap") and f.window >= 16
+    f.set_state(x0, P0)
+    load_script(f, [sc])
+    f.script_run(0, steps)
+    f.sync()
+    assert [(d[0], d[1]) for d in f.decisions(0, steps * M)] == ref["decs"]
+    assert all(d[0] == oc.OLD for d in ref["decs"])
+    del P0
+    xg, Pg = f.get_state()
+    f.close()
+    assert_state_close(xg, Pg, ref["x"], ref["P"], "N=8192 after step %d" % steps)
+    assert_bitwise_symmetric(Pg)
+
+
+def test_maximum_capacity_n16000_vs_oracle(pkg, oc, pipeline_mode):
+    """The largest map the library takes (EKF_MAX_CAPACITY = 16 000 landmarks: n = 32 003, dense P 8.2 GB, 501 x 501 tiles): a steady map of
+    exactly that size, five scripted steps = 20 measurements (a full window and a part of the next; the window is what the library grants at
+    this size), both pipeline modes, decisions and the full state against the structured oracle.  Host memory: about 60 GB at the peak of the
+    comparison (the GPU boxes have terabytes; the test skips below 128 GB)."""
+    try:
+        mem_gb = os.sysconf("SC_PAGE_SIZE") * os.sysconf("SC_PHYS_PAGES") / 2.0 ** 30
+    except (ValueError, OSError):
+        mem_gb = 0.0
+    if mem_gb < 128:
+        pytest.skip("needs about 60 GB of host memory at its peak (this machine: %.0f GB)" % mem_gb)
+    M, steps = 4, 5
+    N = pkg.ekfslam.MAX_CAPACITY
+    assert N == 16000
+    x0, P0 = pkg.scenarios.injected_state(N, seed=20260016, extent=50.0 * (N / 4096.0) ** 0.5)
+    sc = pkg.scenarios.steady_script(x0, steps=steps, M=M, seed=20260017, min_separation=1.5)
+    ref = cached("n16000", lambda: oracle_checkpoints(oc, x0, P0, sc, M, (steps,)))[steps]
+    f = pkg.FilterBatch(1, N)
+    assert f.overlap == (pipeline_mode == "overlap") and 1 <= f.window <= 16
+    f.set_state(x0, P0)
+    del P0
+    load_script(f, [sc])
+    f.script_run(0, steps)
+    f.sync()
+    assert [(d[0], d[1]) for d in f.decisions(0, steps * M)] == ref["decs"]
+    assert all(d[0] == oc.OLD for d in ref["decs"])
+    assert f.num_landmarks()[0] == N
+    xg, Pg = f.get_state()
+    f.close()
+    assert_state_close(xg, Pg, ref["x"], ref["P"], "N=16000 after step %d" % steps)
+    assert_bitwise_symmetric(Pg)
+
+
 def test_config2_n1024_after_steps_1_10_200(pkg, oc):
     """N = 1024, default window, bench.py's inputs: oracle check after steps 1, 10 and 200."""
     M = 4
