@@ -166,7 +166,8 @@ def roofline_record(pkg, f, workload, B, N, K, M, window, launches, flush_ms, al
     if window > 16 and B == 1:
         r["window_note"] = ("window %d: a launch folds up to %d slot pairs into the same bytes that rounds 1-4 folded 8 pairs into (window 16: frac 0.61-0.64, still profiled: "
                             "profiles/r05_n4096_w16_overlap_summary.json) -- half the passes and half the HBM bytes per folded measurement, twice the fp64 MFMA work per byte "
-                            "(roofline.mfma); DESIGN.md 4.2 'The 16-pair pass' has the lab measurements of what that mix reaches" % (window, window // 2))
+                            "(roofline.mfma): %.1f flop per byte, at the ridge of the fp64 roofline (78.6 TFLOP/s / 8 TB/s = 9.8), so HBM and matrix-pipe fractions are both below their own ceilings; "
+                            "DESIGN.md 4.2 'The 16-pair pass' has the lab measurements of what that mix reaches" % (window, window // 2, flops_per_launch / float(bytes_per_launch)))
     if launches:
         avg_s = flush_ms / 1e3 / launches
         r["avg_launch_us"] = avg_s * 1e6
