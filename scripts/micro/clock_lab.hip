@@ -89,8 +89,8 @@ __global__ void k_fill(double *p, size_t n, unsigned seed) {
 // fetched as the library fetches them: per sweep of SW pairs, SW x 4 B elements and SW x 4 A elements of 8 bytes per lane from a 2 MB
 // array that lives in L2 (FA / FB of a window of 32 at N = 4096 are 2 x 2.1 MB), requested in front of the sweep's MFMAs (OPS = 1) or one
 // sweep ahead (OPS = 2).
-template <int PAIRS, int OPS, bool PERSIST, int SW, bool LO = false>
-__global__ __launch_bounds__(256, 2) void k_stream2(const double *in, double *out, const double *ops, int ntiles, unsigned long long *sums) {
+template <int PAIRS, int OPS, bool PERSIST, int SW, bool LO = false, int WPS = 2>
+__global__ __launch_bounds__(256, WPS) void k_stream2(const double *in, double *out, const double *ops, int ntiles, unsigned long long *sums) {
     const int lane = threadIdx.x & 63;
     int u = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int stride = PERSIST ? (int)gridDim.x * 4 : ntiles;
@@ -159,16 +159,16 @@ __global__ __launch_bounds__(256, 2) void k_stream2(const double *in, double *ou
     }
 }
 
-template <int PAIRS, int OPS, bool PERSIST, int SW, bool LO = false>
+template <int PAIRS, int OPS, bool PERSIST, int SW, bool LO = false, int WPS = 2>
 void run2(const double *in, double *out, const double *ops, int ntiles, unsigned long long *sums, const char *label) {
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
     const int blocks = PERSIST ? 512 : (ntiles + 3) / 4, launches = 12;
-    for (int w = 0; w < 3; w++) hipLaunchKernelGGL((k_stream2<PAIRS, OPS, PERSIST, SW, LO>), dim3(blocks), dim3(256), 0, 0, in, out, ops, ntiles, sums);
+    for (int w = 0; w < 3; w++) hipLaunchKernelGGL((k_stream2<PAIRS, OPS, PERSIST, SW, LO, WPS>), dim3(blocks), dim3(256), 0, 0, in, out, ops, ntiles, sums);
     CHECK(hipMemset(sums, 0, 16 * (size_t)ntiles));
     CHECK(hipEventRecord(e0));
-    for (int w = 0; w < launches; w++) hipLaunchKernelGGL((k_stream2<PAIRS, OPS, PERSIST, SW, LO>), dim3(blocks), dim3(256), 0, 0, in, out, ops, ntiles, sums);
+    for (int w = 0; w < launches; w++) hipLaunchKernelGGL((k_stream2<PAIRS, OPS, PERSIST, SW, LO, WPS>), dim3(blocks), dim3(256), 0, 0, in, out, ops, ntiles, sums);
     CHECK(hipEventRecord(e1));
     CHECK(hipEventSynchronize(e1));
     float ms;
@@ -243,6 +243,10 @@ int main(int argc, char **argv) {
         run2<16, 2, false, 2>(in, out, ops, ntiles, sums, "16 pairs, operands a sweep of 2 ahead, wave per tile");
         run2<16, 2, true, 2>(in, out, ops, ntiles, sums, "16 pairs, operands a sweep of 2 ahead, persistent");
         run2<16, 2, false, 2, true>(in, out, ops, ntiles, sums, "16 pairs, a sweep of 2 ahead, element = row*4+k");
+        run2<16, 2, false, 1, false, 3>(in, out, ops, ntiles, sums, "16 pairs, a sweep of 1 ahead, THREE waves per SIMD");
+        run2<16, 2, false, 1, false, 2>(in, out, ops, ntiles, sums, "16 pairs, a sweep of 1 ahead, two waves per SIMD");
+        run2<16, 0, false, 4, false, 3>(in, out, ops, ntiles, sums, "16 pairs, operands in registers, THREE waves per SIMD");
+        run2<8, 2, false, 1, false, 3>(in, out, ops, ntiles, sums, "8 pairs, a sweep of 1 ahead, THREE waves per SIMD");
         run2<16, 1, false, 4, true>(in, out, ops, ntiles, sums, "16 pairs, per sweep of 4, element = row*4+k");
         run2<8, 1, false, 8, true>(in, out, ops, ntiles, sums, "8 pairs, one sweep, element = row*4+k");
         run2<8, 1, false, 8>(in, out, ops, ntiles, sums, "8 pairs, operands in one sweep, wave per tile");
