@@ -148,11 +148,11 @@ def test_size_independent_properties_n4096(pkg):
     """Full-size checks that need no oracle: eager (a dense pass per measurement, as Update.cpp:188
     does) and deferred (one dense pass per step) agree; graph replay is bit-identical to plain
     launches; P stays symmetric with a shrinking trace."""
-    N, M, steps = 4096, 4, 8
+    N, M, steps = 4096, 4, 12
     x0, P0 = pkg.scenarios.injected_state(N, seed=20260003)
     sc = pkg.scenarios.steady_script(x0, steps=steps, M=M, seed=9)
     outs = []
-    for max_pending, graph in [(1, False), (4, False), (4, True)]:
+    for max_pending, graph in [(1, False), (4, False), (4, True), (32, False)]:  # (32: the window bench.py asks for -- 64 chain workgroups, 16-pair passes)
         f = pkg.FilterBatch(1, N, max_pending=max_pending)
         f.set_state(x0, P0)
         load_script(f, sc)
@@ -160,9 +160,11 @@ def test_size_independent_properties_n4096(pkg):
         f.sync()
         outs.append(f.get_state() + (f.decisions(0, steps * M),))
         f.close()
-    (xe, Pe, de), (xd, Pd, dd), (xq, Pq, dq) = outs
+    (xe, Pe, de), (xd, Pd, dd), (xq, Pq, dq), (xw, Pw, dw) = outs
     key = lambda ds: [(d[0], d[1]) for d in ds]
-    assert key(de) == key(dd) and dd == dq
+    assert key(de) == key(dd) and dd == dq and key(dw) == key(de)
+    assert np.abs(xe - xw).max() <= 1e-12 * np.abs(xe).max() and np.abs(Pe - Pw).max() <= 1e-12 * np.abs(Pe).max()
+    assert_bitwise_symmetric(Pw)
     assert np.allclose([d[2] for d in de], [d[2] for d in dd], rtol=1e-9, atol=1e-12)
     assert all(d[0] == pkg.ekfslam.OLD for d in de)
     assert [d[1] for d in de] == [3 + 2 * int(t) for t in sc["target"].ravel()]
