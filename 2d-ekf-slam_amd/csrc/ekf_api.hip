@@ -104,12 +104,15 @@ struct ekf_batch {
     int buf_in;     // Bm buffer the chain kernels read (complete up to the sets still open or in flight)
     bool flush_alternate; // EKF_FLUSH_ALTERNATE (default on): dense passes walk the tiles alternately first-to-last and last-to-first
     int flush_dir;        // direction of the next dense pass (0 = first to last)
+    // Product tunables (read from the environment at ekf_*_create, listed in include/ekfslam_c.h "Tunables"; every one of them
+    // changes scheduling only, never results): EKF_BALANCED_TAIL, EKF_OVERLAP, EKF_PERSIST, EKF_CHAIN_ONE, EKF_CHAIN_HELPERS,
+    // EKF_INLINE_REC, EKF_XCD_MAP, ... -- bench.py records every EKF_* variable it saw.
+    bool balanced_tail = true;          // EKF_BALANCED_TAIL=0: windows always close at max_pending (launch_ops)
+    long long windows_closed = 0;       // windows handed to a dense pass by close_set since create (ekf_debug_windows)
+    int last_window_slots = 0;          // ... and the slots of the last one
     // Test / experiment hooks.  They exist only in the debug variant of the library (make debug: -DEKF_DEBUG_HOOKS,
     // libekfslam_hip_debug.so); in the product build the fields keep these values and no environment variable can change them.
     bool dbg_skip_flush = false;        // EKF_DEBUG_SKIP_FLUSH=1: timing experiments only, results are wrong
-    bool balanced_tail = true;          // EKF_BALANCED_TAIL=0 (read at create): windows always close at max_pending (launch_ops)
-    long long windows_closed = 0;       // windows handed to a dense pass by close_set since create (ekf_debug_windows: tests)
-    int last_window_slots = 0;          // ... and the slots of the last one
     int dbg_drop_marks_from = 0;        // EKF_DEBUG_DROP_MARKS_FROM=k (and ..._TO=m, exclusive): dense passes k .. m-1 never report completion (tests of the bounded waits)
     int dbg_drop_marks_to = 0x7fffffff;
     // immediate-mode input ring (host-mapped pinned)
@@ -797,6 +800,27 @@ static const int *tile_map_for(ekf_batch *h, int nT) {
 //    start after pass k-1 (they read its output and overwrite the slot rows it read).
 typedef std::vector<std::function<hipError_t()>> EnqueueList;
 
+// The profiling events (a start / stop pair per dense pass, or per k_solo launch that folds its own windows) are created where
+// profiling is switched on and where a script is loaded -- enough pairs for every window the script can close between two reads --
+// never on the enqueue path: four hipEventCreate calls inside a timed region of 0.85 ms were part of what the round-5 driver
+// run paid.  The enqueue path still grows the pool when a caller outruns it (immediate-mode traffic without a read).
+static int prof_reserve(ekf_batch *h, size_t pairs) {
+    if (pairs > 4096) pairs = 4096;
+    while (h->prof_pool.size() < h->prof_used + 2 * pairs) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        h->prof_pool.push_back(e);
+    }
+    return EKF_OK;
+}
+static size_t prof_pairs_for_script(const ekf_batch *h) {
+    if (!h->script_d) return 8;
+    // a window closes after at least maxp / 2 measurements (the balanced tail) -- and once more per call (terminal passes)
+    const size_t slots = (size_t)h->script_steps * (size_t)(h->script_M > 0 ? h->script_M : 0);
+    const size_t half = (size_t)(h->dv.maxp > 1 ? h->dv.maxp / 2 : 1);
+    return (slots / half + 8) * (size_t)(h->ngroups > 1 ? h->ngroups : 1);
+}
+
 static int close_set(ekf_batch *h, bool terminal = false, EnqueueList *defer = nullptr) {
     if (h->pending == 0) return EKF_OK;
     int nT_hi = (2 * h->n_lm_hi + 63) / 64;
@@ -829,10 +853,9 @@ static int close_set(ekf_batch *h, bool terminal = false, EnqueueList *defer = n
     if (do_pass) {
         if (h->overlap && !terminal) e1 = h->ev_flush[h->ev_idx ^ 1];  // pass k's completion, signalled by its own dispatch packet
         if (h->prof_flush) {
-            while (h->prof_pool.size() < h->prof_used + 2) {
-                hipEvent_t e;
-                HIP_TRY(hipEventCreate(&e));
-                h->prof_pool.push_back(e);
+            if (h->prof_pool.size() < h->prof_used + 2) {  // (a caller that outran the pool of ekf_flush_profile / ekf_script_load)
+                int rc = prof_reserve(h, 8);
+                if (rc) return rc;
             }
             e0 = h->prof_pool[h->prof_used++], e1 = h->prof_pool[h->prof_used++];  // (recycled after a read, which leaves both streams idle; e1 doubles as the pass's completion event)
         }
@@ -988,10 +1011,9 @@ static int launch_ops(ekf_batch *h, const double *in, const int *cursor, int k0,
             static const int fuse_stagger = getenv("EKF_SOLO_FUSE_STAGGER_US") ? atoi(getenv("EKF_SOLO_FUSE_STAGGER_US")) * 100 : 0;
             plan.s[0].stagger = (sp >= 4 && h->dv.B >= 16) ? fuse_stagger : 0;
             if (h->prof_flush && sp > 0) {  // the passes live inside this launch: time the launch, count the passes
-                while (h->prof_pool.size() < h->prof_used + 2) {
-                    hipEvent_t ev;
-                    HIP_TRY(hipEventCreate(&ev));
-                    h->prof_pool.push_back(ev);
+                if (h->prof_pool.size() < h->prof_used + 2) {
+                    int rc = prof_reserve(h, 8);
+                    if (rc) return rc;
                 }
                 pe0 = h->prof_pool[h->prof_used++], pe1 = h->prof_pool[h->prof_used++];
                 h->prof_fused_passes += sp;
@@ -1040,7 +1062,10 @@ static int launch_ops(ekf_batch *h, const double *in, const int *cursor, int k0,
         int start = i, used = h->pending;
         if (used == 0) {
             limit = h->dv.maxp;
-            if (balanced_tail && persist && !solo && slots_left > h->dv.maxp && slots_left < 2 * h->dv.maxp) limit = ((slots_left + 1) / 2 + 1) & ~1;
+            if (balanced_tail && persist && !solo && slots_left > h->dv.maxp && slots_left < 2 * h->dv.maxp) {
+                limit = ((slots_left + 1) / 2 + 1) & ~1;
+                if (limit > h->dv.maxp) limit = h->dv.maxp;  // (an odd max_pending: rounding up to a slot pair must not pass the window -- slot_meta rows, the own-row cache and the pass are sized for maxp)
+            }
         }
         while (i < nops && i - start < EKF_CHAIN_MAX_OPS) {
             if (consumes[i]) {
@@ -1716,6 +1741,7 @@ extern "C" int ekf_reserve(ekf_handle h, int capacity_landmarks) {
     nh->prof_used = h->prof_used, h->prof_used = 0;
     nh->prof_ms = h->prof_ms, nh->prof_launches = h->prof_launches;
     nh->prof_fused_passes = h->prof_fused_passes, nh->prof_solo_pairs = h->prof_solo_pairs;
+    nh->windows_closed = h->windows_closed, nh->last_window_slots = h->last_window_slots;  // (ekf_debug_windows counts since create, across growths)
     {
         const hipStream_t s_new = nh->s_chain, s_old = h->s_chain;
         if (nh->s_flush == s_new) nh->s_flush = s_old;
@@ -1811,6 +1837,7 @@ extern "C" int ekf_script_load(ekf_handle h, int steps, int M, const double *ctr
     }
     HIP_TRY(hipMalloc((void **)&h->script_d, count * sizeof(double)));
     HIP_TRY(hipMemcpy(h->script_d, host.data(), count * sizeof(double), hipMemcpyHostToDevice));
+    if (h->prof_flush) return prof_reserve(h, prof_pairs_for_script(h));
     return EKF_OK;
 }
 
@@ -1952,6 +1979,10 @@ extern "C" int ekf_timer_stop(ekf_handle h, double *ms_out) {
 extern "C" int ekf_flush_profile(ekf_handle h, int enable) {
     if (!h) return set_error(EKF_ERR_BAD_ARG, "null handle");
     h->prof_flush = enable != 0;
+    if (h->prof_flush) {
+        HIP_TRY(hipSetDevice(h->device));
+        return prof_reserve(h, prof_pairs_for_script(h));  // the pool is sized here and in ekf_script_load, not while launches are enqueued
+    }
     return EKF_OK;
 }
 

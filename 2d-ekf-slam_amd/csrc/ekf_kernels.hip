@@ -1063,7 +1063,8 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                     bool ok = lane >= nrec;
                     // (nothing holds this wave back while the workers sweep: it stays off the memory system -- every poll lengthens
                     // everybody's -- until its own workgroup has published, which is when the others are about to)
-                    while (__hip_atomic_load(&L.pubflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != (int)(tag >> 32)) __builtin_amdgcn_s_sleep(1);
+                    // (bounded like every other device-side wait: the poll loop below shares the counter, finds it spent and reports EKF_ERR_TIMEOUT)
+                    while (__hip_atomic_load(&L.pubflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != (int)(tag >> 32) && ++spins <= (1L << 22)) __builtin_amdgcn_s_sleep(1);
                     for (;;) {
                         if (!ok) {  // (a lane whose head has arrived does not read it again: every poll lengthens everybody's)
                             h0 = __hip_atomic_load(hd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

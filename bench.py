@@ -24,6 +24,20 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+def compact(o, digits=7):
+    """Floats of the JSON line rounded to `digits` significant digits (a 17-digit double is 18 characters; the driver keeps an 8 KB
+    tail of the line).  `value` and `ms_per_step` at the top level are printed in full by main()."""
+    if isinstance(o, float):
+        if o != o or o in (float("inf"), float("-inf")):
+            return None
+        return float("%.*g" % (digits, o))
+    if isinstance(o, dict):
+        return {k: compact(v, digits) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [compact(v, digits) for v in o]
+    return o
+
+
 def ekf_environment():
     """Every EKF_* variable this process sees goes into the JSON line; a debug hook (EKF_DEBUG_*: skipped dense passes, dropped
     completion marks -- only the debug variant of the library knows them, but the line must not depend on which library was
@@ -35,6 +49,7 @@ def ekf_environment():
     return seen
 
 
+VERBOSE = False  # --verbose: the prose fields (byte model, window note, traffic source) ride on the line; the default line stays under 8 KB
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X datasheet fp64 matrix; v_mfma_f64_16x16x4_f64 measured 68 TFLOP/s (scripts/micro)
 
@@ -62,13 +77,27 @@ def window_for(workload, asked):
     return 16 if workload == "n1024" else 32
 
 
-def make_filters(pkg, mc, workload, lo, hi, steps, M, dev_id, max_pending, log_entries, tail_windows=0):
+def prime_steps_for(window, M, K):
+    """Untimed script steps in FRONT of the warm-up (round 6).  The driver's `--warmup 5` is 20 measurements: less than one window of 32, so the
+    warm-up never closed a window and the timed region was the first to run a pipeline pass -- second stream, stream gates, k_mark, a
+    multi-segment chain launch, both walking directions of the tile map -- with every first-use cost of the runtime (kernel lookup, queue
+    creation, signal pools) inside 0.85 ms.  The prime run is at least three windows (two pipeline passes and a terminal one) and at least as
+    long as the timed region up to 64 steps, so the timed region repeats a call pattern the process has already executed.  `steps` and
+    `warmup` of the JSON line stay the driver's; `prime_steps` is reported beside them."""
+    if M <= 0:
+        return 0
+    return max(min(K, 64), 3 * -(-window // M))
+
+
+def make_filters(pkg, mc, workload, lo, hi, steps, M, dev_id, max_pending, log_entries, tail_windows=0, prime_for=None):
     """A handle holding global filters [lo, hi) of `workload`, states injected and the step script loaded (all untimed):
-    `steps` steps plus `tail_windows` windows' worth for measurements outside the timed region."""
+    the prime steps (prime_steps_for(window, M, prime_for); f.prime_steps), `steps` steps, and `tail_windows` windows' worth for
+    measurements outside the timed region."""
     import numpy as np
     N, _, _, _, seed, extent, min_sep = WORKLOADS[workload]
     f = pkg.FilterBatch(hi - lo, N, device=dev_id, max_pending=max_pending, log_capacity=max(4096, log_entries))
-    total_steps = steps + tail_windows * -(-f.window // M)  # (the library may have shortened the window to fit its on-chip buffer)
+    f.prime_steps = prime_steps_for(f.window, M, prime_for) if prime_for else 0
+    total_steps = f.prime_steps + steps + tail_windows * -(-f.window // M)  # (the library may have shortened the window to fit its on-chip buffer)
     scripts = []
     for b, g in enumerate(range(lo, hi)):
         x0, P0 = pkg.scenarios.injected_state(N, seed=mc.filter_seed(seed, g), extent=extent)
@@ -81,13 +110,24 @@ def make_filters(pkg, mc, workload, lo, hi, steps, M, dev_id, max_pending, log_e
 
 
 def timed_steps(f, mc, torch, dist, coll_device, W, K, graph):
-    """W untimed warm-up steps, then exactly K steps bracketed by barrier + synchronize on both sides; the timed region
-    ends with P_LL fully folded (ekf_flush) and with the one collective, the all-gather of per-filter NIS / NEES."""
-    # the warm-up goes through every call of the timed region once (first calls pay for lazy imports, page faults of the
-    # host-mapped buffers and event creation: ~130 us, a tenth of a 20-step run) and ends like it, with P_LL fully folded:
-    # the timed region then holds exactly K steps of work
+    """Prime run (untimed, f.prime_steps), W untimed warm-up steps, then exactly K steps bracketed by barrier + synchronize on both
+    sides; the timed region ends with P_LL fully folded (ekf_flush) and with the one collective, the all-gather of per-filter NIS / NEES.
+    Returns (elapsed s, device ms, gathered rows, phases)."""
+    P = getattr(f, "prime_steps", 0)
+    if P:
+        # every code path of the timed region once, on script steps of its own: multi-segment launch, both pipeline streams, gates,
+        # k_mark, the terminal pass, the counters' read-back, the collective
+        f.timer_start()
+        f.script_run(0, P, use_graph=graph)
+        f.flush()
+        f.timer_stop()
+        mc.gather_device_stats(f, coll_device)
+        f.sync()
+        f.flush_profile_read()
+    # the warm-up goes through every call of the timed region once and ends like it, with P_LL fully folded: the timed region then
+    # holds exactly K steps of work
     f.timer_start()
-    f.script_run(0, W, use_graph=graph)
+    f.script_run(P, W, use_graph=graph)
     f.flush()
     f.timer_stop()
     mc.gather_device_stats(f, coll_device)
@@ -99,7 +139,7 @@ def timed_steps(f, mc, torch, dist, coll_device, W, K, graph):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     f.timer_start()
-    f.script_run(W, K, use_graph=graph)
+    f.script_run(P + W, K, use_graph=graph)
     f.flush()                # P_LL fully folded inside the timed region, whatever K*M modulo the window is
     t1 = time.perf_counter()
     dev_ms = f.timer_stop()  # hipEvents on the handle's own stream
@@ -110,33 +150,65 @@ def timed_steps(f, mc, torch, dist, coll_device, W, K, graph):
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    # where the host clock's time went: enqueue (launch calls, concurrent with the device), wait (device still busy after the last
+    # call returned), stats+gather (the collective), sync (synchronize + barrier); device = hipEvents around the K steps
+    phases = {"enqueue": (t1 - t0) * 1e6, "wait": (t2 - t1) * 1e6, "stats_gather": (t3 - t2) * 1e6, "sync_barrier": (t0 + elapsed - t3) * 1e6,
+              "device": dev_ms * 1e3, "host_minus_device": elapsed * 1e6 - dev_ms * 1e3}
     if os.environ.get("BENCH_PHASES"):
-        print("phases (us): enqueue %.1f  wait %.1f  stats+gather %.1f  sync+barrier %.1f  device %.1f" %
-              ((t1 - t0) * 1e6, (t2 - t1) * 1e6, (t3 - t2) * 1e6, (t0 + elapsed - t3) * 1e6, dev_ms * 1e3), file=sys.stderr)
+        print("phases (us): " + "  ".join("%s %.1f" % kv for kv in phases.items()), file=sys.stderr)
+    per_rank = [elapsed]
     if dist is not None:
-        te = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
-    return elapsed, dev_ms, gathered
+        tl = [torch.zeros(1, dtype=torch.float64, device=coll_device) for _ in range(dist.get_world_size())]
+        dist.all_gather(tl, torch.tensor([elapsed], dtype=torch.float64, device=coll_device))
+        per_rank = [float(t.item()) for t in tl]
+        elapsed = max(per_rank)  # MAX over ranks
+    phases["per_rank_ms"] = [t * 1e3 for t in per_rank]
+    return elapsed, dev_ms, gathered, phases
 
 
-def config5_legs(pkg, mc, torch, dist, coll_device, rank, world, dev_id, M, max_pending, steps=None):
+CONFIG5_LEG_KEYS = ("filters_total", "filters_per_gpu", "value", "unit", "ms_per_step", "gathered_rows", "ranks_seen", "per_rank_ms",
+                    "allgather_us", "roofline")
+CONFIG5_ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "bytes_per_launch", "launches", "avg_launch_us")
+
+
+def config5_leg_record(total, per_gpu, world, K, elapsed, gathered_rows, per_rank_ms, allgather_us, roof):
+    """One leg of BASELINE.json config 5 as it goes into the line (the dry run builds the same record with value = None): steps/s of the
+    whole job, every rank's own time, the all-gather's time on rank 0, how many ranks' rows arrived, and the dense pass's roofline on rank 0
+    -- north_star: "steps/sec and achieved HBM-bandwidth fraction reported at 1/2/4/8 GPUs"."""
+    r = dict((k, None) for k in CONFIG5_ROOFLINE_KEYS)
+    r.update({"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s"})
+    if roof:
+        r.update({k: roof.get(k) for k in CONFIG5_ROOFLINE_KEYS})
+        for extra in ("fused_pass", "mfma", "measurements_per_launch", "end_to_end_hbm_frac"):
+            if extra in roof:
+                r[extra] = roof[extra]
+    return {"filters_total": total, "filters_per_gpu": per_gpu, "value": (total * K / elapsed) if elapsed else None, "unit": "filter-steps/s",
+            "ms_per_step": (elapsed / K * 1e3) if elapsed else None, "gathered_rows": int(gathered_rows),
+            "ranks_seen": int(round(gathered_rows * world / float(total))), "per_rank_ms": per_rank_ms, "allgather_us": allgather_us, "roofline": r}
+
+
+def config5_legs(pkg, mc, torch, dist, coll_device, rank, world, dev_id, M, max_pending, steps=None, legs=("weak", "strong")):
     """BASELINE.json config 5: independent filters at N = 256 sharded over the ranks, RCCL all-gather of NIS / NEES inside
     the timed region.  Weak: 256 filters per GPU.  Strong: 2048 filters in all (more than 256 per GPU go out as several
-    chain launches per window)."""
-    _, per_gpu, K, W, _, _, _ = WORKLOADS["batch256"]
+    chain launches per window).  Every leg carries the dense pass's roofline (rank 0's passes, hipEvents inside the timed region)."""
+    N, per_gpu, K, W, _, _, _ = WORKLOADS["batch256"]
     if steps is not None:
         K = steps
-    out = {"world_size": world, "N": 256, "M": M, "steps": K, "warmup": W}
+    out = {"world_size": world, "N": N, "M": M, "steps": K, "warmup": W}
     for leg, total in (("weak", per_gpu * world), ("strong", 2048)):
+        if leg not in legs:
+            continue
         lo, hi = mc.shard_range(total, rank, world)
-        f, _ = make_filters(pkg, mc, "batch256", lo, hi, W + K, M, dev_id, window_for("batch256", max_pending), (K + W) * M)
-        elapsed, _, gathered = timed_steps(f, mc, torch, dist, coll_device, W, K, False)
+        f, _ = make_filters(pkg, mc, "batch256", lo, hi, W + K, M, dev_id, window_for("batch256", max_pending), (K + W) * M, prime_for=K)
+        f.flush_profile(True)
+        elapsed, dev_ms, gathered, phases = timed_steps(f, mc, torch, dist, coll_device, W, K, False)
+        f.sync()
+        launches, flush_ms = f.flush_profile_read()
         st = f.stats()
         assert all(s["n_old"] == K * M for s in st), "a filter left the Old branch"
+        roof = roofline_record(pkg, f, "batch256", hi - lo, N, K, M, f.window, launches, flush_ms, 0, 0.0, dev_ms, elapsed)
         f.close()
-        out[leg] = {"filters_total": total, "filters_per_gpu": hi - lo, "value": total * K / elapsed, "unit": "filter-steps/s",
-                    "ms_per_step": elapsed / K * 1e3, "gathered_rows": int(gathered.shape[0])}
+        out[leg] = config5_leg_record(total, hi - lo, world, K, elapsed, gathered.shape[0], phases["per_rank_ms"], phases["stats_gather"], roof)
     return out
 
 
@@ -160,10 +232,12 @@ def roofline_record(pkg, f, workload, B, N, K, M, window, launches, flush_ms, al
         slots_per_launch = min(float(window), K * M * groups / float(launches))
     flops_per_launch = filters_per_launch * chains * (slots_per_launch / 2.0) * 2048  # one v_mfma_f64_16x16x4_f64 per chain and PAIR of measurements
     r = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
-         "kernel": "k_flush_rb", "byte_model": "scheme C (one triangle authoritative): every live 16x16 chain of the upper-triangle tiles (2 KiB) read + written per pass -- %d tiles = %d chains, the %d dead chains below the diagonals of the diagonal tiles left out; %.4g measurements folded per pass (window %d)" % (tiles, chains, nT * 6, slots_per_launch, window),
+         "kernel": "k_flush_rb", "byte_model": "scheme C, DESIGN.md 4.2",
          "bytes_per_launch": bytes_per_launch, "launches": int(launches), "avg_launch_us": None, "measurements_per_launch": slots_per_launch,
          "mfma": {"achieved": None, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None, "flops_per_launch": flops_per_launch}}
-    if window > 16 and B == 1:
+    if VERBOSE:
+        r["byte_model"] = "scheme C (one triangle authoritative): every live 16x16 chain of the upper-triangle tiles (2 KiB) read + written per pass -- %d tiles = %d chains, the %d dead chains below the diagonals of the diagonal tiles left out; %.4g measurements folded per pass (window %d)" % (tiles, chains, nT * 6, slots_per_launch, window)
+    if VERBOSE and window > 16 and B == 1:
         r["window_note"] = ("window %d: a launch folds up to %d slot pairs into the same bytes that rounds 1-4 folded 8 pairs into (window 16: frac 0.61-0.64, still profiled: "
                             "profiles/r05_n4096_w16_overlap_summary.json) -- half the passes and half the HBM bytes per folded measurement, twice the fp64 MFMA work per byte "
                             "(roofline.mfma): %.1f flop per byte, at the ridge of the fp64 roofline (78.6 TFLOP/s / 8 TB/s = 9.8), so HBM and matrix-pipe fractions are both below their own ceilings; "
@@ -176,7 +250,7 @@ def roofline_record(pkg, f, workload, B, N, K, M, window, launches, flush_ms, al
         r["mfma"]["achieved"] = flops_per_launch / avg_s / 1e12
         r["mfma"]["frac"] = r["mfma"]["achieved"] / FP64_MFMA_PEAK_TFLOPS
         r["share_of_step_time"] = flush_ms / (dev_ms if dev_ms > 0 else 1.0)
-        r["concurrent_with"] = "k_chain of the next window (overlap)" if f.overlap else None
+        r["concurrent_with"] = "k_chain" if f.overlap else None  # (overlap mode: the next window's chain kernel runs beside the pass)
         # every pass of the timed region against the whole timed region: what the headline cannot hide (the sequential chain
         # kernels, launch gaps, fill and drain all count as time in which HBM should have been busy)
         r["end_to_end_hbm_frac"] = launches * bytes_per_launch / elapsed / 1e9 / HBM_PEAK_GBS
@@ -185,12 +259,12 @@ def roofline_record(pkg, f, workload, B, N, K, M, window, launches, flush_ms, al
             # no dense-pass launch to time.  `launches` counts the passes, the duration is that of the k_solo launches that contain them --
             # measurement loops included -- so this fraction is a LOWER bound of the pass's own (the stamps build separates the two:
             # DESIGN.md 4.1b); EKF_SOLO_FUSE=0 runs the passes as k_flush_rb launches again.
-            r["kernel"] = "k_solo<true>: measurement loop + its own dense pass (no separate pass launch; avg_launch_us is per window, loop included)"
+            r["kernel"] = "k_solo<true> (loop + own pass; avg_launch_us per window)"
             r["fused_pass"] = True
     if alone_launches:
         a_s = alone_ms / 1e3 / alone_launches
         r["alone"] = {"avg_launch_us": a_s * 1e6, "achieved": bytes_per_launch / a_s / 1e9, "frac": bytes_per_launch / a_s / 1e9 / HBM_PEAK_GBS,
-                      "launches": int(alone_launches), "note": "same pass, nothing else on the GPU, outside the timed region"}
+                      "launches": int(alone_launches)}  # (the same pass with nothing else on the GPU, outside the timed region)
     # PMC-derived HBM bytes per launch: NOT measured by this run -- replayed from the committed rocprofv3 --pmc passes of this very
     # command (scripts/profile_r0x.sh -> profiles/traffic_*.json); null when no committed pass matches the configuration
     have = kernel_source_digest()
@@ -205,23 +279,34 @@ def roofline_record(pkg, f, workload, B, N, K, M, window, launches, flush_ms, al
             if tj.get("max_pending") == window and tj.get("overlap", int(f.overlap)) == int(f.overlap) and tj.get("filters_per_gpu", B) == B:
                 if tj.get("kernel_source_sha16") != have:
                     # a counter pass of OTHER kernel sources says nothing about this binary: null, not a stale number
-                    r["traffic_source"] = "profiles/%s was collected on kernel sources %s, this run's are %s: stale, not replayed" % (tname, tj.get("kernel_source_sha16"), have)
+                    r["traffic_source"] = "profiles/%s: stale (collected on sources %s, this run's are %s), not replayed" % (tname, tj.get("kernel_source_sha16"), have)
                     continue
                 r["traffic"] = tj.get("hbm_bytes_per_launch")
-                r["traffic_source"] = "replayed from profiles/%s (separate rocprofv3 --pmc passes of these kernel sources, %s), not measured in this run" % (tname, have)
+                r["traffic_source"] = "replayed from profiles/%s (rocprofv3 --pmc passes of sources %s)" % (tname, have)
                 if tj.get("fused_pass"):
-                    r["traffic_source"] += ("; counted on whole windows of k_solo<true> (the measurement loop's own traffic included: the B side of the slots, %d bytes, "
-                                            "written once per window, and the matched landmarks' P_LL entries); without the slot emit the ratio to the tile bytes is %.3f"
-                                            % (tj.get("algorithmic_slot_emit_bytes", 0), tj.get("ratio_without_the_slot_emit", float("nan"))))
+                    # counted on whole windows of k_solo<true>: the measurement loop's own traffic (the B side of the slots, written once per
+                    # window, and the matched landmarks' P_LL entries) is included
+                    r["traffic_without_slot_emit_ratio"] = tj.get("ratio_without_the_slot_emit")
                 elif getattr(f, "fused_pass", False):
                     # the counters were taken on k_flush_rb (EKF_SOLO_FUSE=0), the binary measured here folds inside k_solo: same tiles, but the
                     # in-kernel pass stages a tile row's A operands ONCE per row (LDS-DMA) and walks the exact landmark count, so it re-reads
                     # fewer operand bytes than the pass kernel: the replayed figure is an UPPER bound for this run
                     r["traffic_is_upper_bound"] = True
-                    r["traffic_source"] += ("; counted on the pass as a kernel of its own (EKF_SOLO_FUSE=0): an UPPER BOUND for the in-kernel pass measured here, "
-                                            "which fetches a tile row's A operands once per row instead of once per tile")
                 break
     return r
+
+
+def slim_roofline(r):
+    """A secondary leg's roofline without the fields the headline's already explains (models, notes): the numbers only."""
+    keep = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "bytes_per_launch", "launches", "avg_launch_us", "measurements_per_launch",
+            "share_of_step_time", "end_to_end_hbm_frac", "fused_pass", "traffic_is_upper_bound", "traffic_without_slot_emit_ratio")
+    out = {k: r[k] for k in keep if k in r}
+    if r.get("mfma"):
+        out["mfma_frac"] = r["mfma"].get("frac")
+    if r.get("alone"):
+        out["alone_frac"] = r["alone"].get("frac")
+        out["alone_avg_launch_us"] = r["alone"].get("avg_launch_us")
+    return out
 
 
 def kernel_source_digest():
@@ -264,7 +349,7 @@ def host_cpu_record():
     except (AttributeError, OSError):
         aff = None
     rec["pinning"] = {"OMP_PROC_BIND": os.environ.get("OMP_PROC_BIND"), "OMP_PLACES": os.environ.get("OMP_PLACES"), "OMP_NUM_THREADS": os.environ.get("OMP_NUM_THREADS"),
-                      "taskset": "none (the process's affinity mask as inherited: %s CPUs)" % (len(aff) if aff else "?")}
+                      "taskset": "none"}
     return rec
 
 
@@ -276,17 +361,18 @@ def measure(pkg, mc, torch, dist, coll_device, rank, world, dev_id, workload, K,
     # (4 windows of untimed tail: dense passes measured one at a time, nothing beside them; latency: one step per call)
     extra = 264 if latency else 0
     max_pending = window_for(workload, max_pending)
-    f, scripts = make_filters(pkg, mc, workload, lo, hi, W + K + extra, M, dev_id, max_pending, (K + W + extra) * M, tail_windows=4 if alone else 0)
+    f, scripts = make_filters(pkg, mc, workload, lo, hi, W + K + extra, M, dev_id, max_pending, (K + W + extra + 64) * M, tail_windows=4 if alone else 0, prime_for=K)
     window = f.window  # the library may shorten the window to fit its on-chip buffer
     win_steps = -(-window // M)
+    P = f.prime_steps  # script steps run before the warm-up (untimed): every later step index is shifted by it
     f.flush_profile(flush_profile)
-    elapsed, dev_ms, gathered = timed_steps(f, mc, torch, dist, coll_device, W, K, graph)
+    elapsed, dev_ms, gathered, phases = timed_steps(f, mc, torch, dist, coll_device, W, K, graph)
     f.sync()
     launches, flush_ms = f.flush_profile_read()
     if check:
         for b in range(B if B <= 4 else 4):
             dec = f.decisions(b, K * M)
-            want = [3 + 2 * int(t) for t in scripts[b]["target"][W:W + K].ravel()]
+            want = [3 + 2 * int(t) for t in scripts[b]["target"][P + W:P + W + K].ravel()]
             assert len(dec) == K * M and all(d[0] == pkg.ekfslam.OLD for d in dec), "filter %d left the Old branch" % b
             assert [d[1] for d in dec] == want, "filter %d matched an unintended landmark" % b
         st = f.stats()
@@ -304,7 +390,7 @@ def measure(pkg, mc, torch, dist, coll_device, rank, world, dev_id, workload, K,
         gc_was_on = gc.isenabled()
         gc.disable()
         try:
-            for q_, s_ in enumerate(range(W + K, W + K + extra)):
+            for q_, s_ in enumerate(range(P + W + K, P + W + K + extra)):
                 t0 = time.perf_counter()
                 f.script_run(s_, 1)
                 f.poses()
@@ -313,17 +399,16 @@ def measure(pkg, mc, torch, dist, coll_device, rank, world, dev_id, workload, K,
             if gc_was_on:
                 gc.enable()
         ts = np.sort(raw[8:])
-        lat = {"unit": "us per step (1 Propagate + %d Updates, one call per step, pose read back)" % M, "samples": int(ts.size),
+        lat = {"unit": "us per step (one call per step, pose read back)", "samples": int(ts.size),
                "p10": float(np.percentile(ts, 10)), "p50": float(np.percentile(ts, 50)), "p90": float(np.percentile(ts, 90)),
                "p99": float(np.percentile(ts, 99)), "max": float(ts[-1]), "over_1ms": int((ts > 1000.0).sum()),
-               "first_8_calls_us": [float(t) for t in raw[:8]],
-               "note": "the first 8 calls (first per-step launches after the scripted run: host-side first-use costs) are listed, not ranked"}
+               "first_calls_us": [float(t) for t in raw[:4]]}  # (the first 8 calls -- host-side first-use costs -- are not ranked; four are listed)
         f.flush()
         f.sync()
         f.flush_profile_read()
     alone_launches, alone_ms = 0, 0.0
     if flush_profile and alone:
-        base = W + K + extra
+        base = P + W + K + extra
         for r in range(4):
             # a whole window, then its pipeline-style pass (buffer to buffer, on the pass's own stream) with the chain kernel
             # already finished and nothing following
@@ -337,7 +422,7 @@ def measure(pkg, mc, torch, dist, coll_device, rank, world, dev_id, workload, K,
     overlap = int(f.overlap)
     f.close()
     return {"workload": workload, "N": N, "B": B, "K": K, "W": W, "M": M, "window": window, "overlap": overlap, "elapsed": elapsed, "dev_ms": dev_ms,
-            "value": B * world * K / elapsed, "roofline": roof, "latency": lat, "report": rep, "seed": seed, "extent": extent, "min_sep": min_sep}
+            "prime_steps": P, "phases_us": phases, "value": B * world * K / elapsed, "roofline": roof, "latency": lat, "report": rep, "seed": seed, "extent": extent, "min_sep": min_sep}
 
 
 def immediate_leg(pkg, dev_id):
@@ -350,7 +435,7 @@ def immediate_leg(pkg, dev_id):
     replay = os.path.join(ROOT, "compat", "replay")
     if not os.path.exists(replay):
         return {"error": "compat/replay is not built"}
-    out = {"unit": "us per step of 1 doPropagation + 4 doUpdate calls (C++ shim, host clock)", "call_pattern": "slam.cpp:136-170"}
+    out = {"unit": "us per 5-call step (doPropagation + 4 doUpdate, C++ shim, host clock)", "call_pattern": "slam.cpp:136-170"}
     for name, N in (("n1024", 1024), ("n4096", 4096)):
         _, _, _, _, seed, extent, min_sep = WORKLOADS[name]
         x0, P0 = pkg.scenarios.injected_state(N, seed=seed, extent=extent)
@@ -387,7 +472,7 @@ def propagate_only_leg(pkg, dev_id, K=2048, W=64):
     import math
     import numpy as np
     out = {"unit": "us per step (1 Propagate, no measurement)", "reference": "odometry/Propagate.cpp:15-75", "bound": "latency",
-           "byte_model": "72 n - 72 bytes per step: rows 0..2 of P read, rows and columns 0..2 written (SURVEY.md 8d)"}
+           "byte_model": "72 n - 72 bytes per step (SURVEY.md 8d)"}
     for name in ("n4096", "n1024"):
         N, _, _, _, seed, extent, _ = WORKLOADS[name]
         x0, P0 = pkg.scenarios.injected_state(N, seed=seed, extent=extent)
@@ -470,15 +555,15 @@ def config1_leg(pkg, dev_id):
     cpu_t = time.perf_counter() - t0
     same = [(d[0], d[1]) for d in dec] == decs
     scale = float(np.abs(P).max())
-    return {"config": "BASELINE.json config 1: 1 robot, N=50 landmarks, synthetic odom + range/bearing, 1000 steps from x=0, P=0 (seed 20260001)",
+    return {"config": "BASELINE.json config 1: N=50, 1000 steps from x=0, P=0 (seed 20260001)",
             "steps": steps, "measurements": n_meas, "decisions": {"new": hist[oc.NEW], "old": hist[oc.OLD], "ignore": hist[oc.IGNORE]},
             "landmarks_final": int((x.size - 3) // 2), "gpu_steps_per_s": steps / min(gpu_s), "gpu_ms_per_step": min(gpu_s) / steps * 1e3,
             "cpu_baseline": {"value": steps / cpu_t, "unit": "steps/s", "cores": 1, "kind": "port",
-                             "sample": "all 1000 steps, faithful-dense oracle (the reference's dense passes, 1 thread), %.2f s" % cpu_t},
+                             "sample": "all 1000 steps, faithful-dense oracle, %.2f s" % cpu_t},
             "decisions_identical": bool(same), "max_rel_err_x": float(np.abs(xg - x).max() / max(1.0, np.abs(x).max())),
             "max_err_P_over_maxP": float(np.abs(Pg - P).max() / scale),
             "state_digest": {"oracle": pkg.scenarios.state_digest(x, P), "gpu": pkg.scenarios.state_digest(xg, Pg),
-                             "note": "sha256 over x and P rounded to 9 significant digits"}}
+                             "of": "sha256 over x and P rounded to 9 significant digits"}}
 
 
 def secondary_in_a_child(args, dev_id):
@@ -486,6 +571,8 @@ def secondary_in_a_child(args, dev_id):
     baselines are in hand: a GPU fault, a hang or a blown time budget in one of them then costs that record, never the line."""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--secondary-only", "--device", str(dev_id), "--M", str(args.M), "--max-pending", str(args.max_pending)]
+    if args.verbose:
+        cmd.append("--verbose")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
     try:
         p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=args.secondary_budget)
@@ -534,7 +621,13 @@ def dry_run(args, rank, world, ekf_env):
         ok = out.shape == (total, 2) and np.array_equal(out[:, 0], np.arange(total)) and np.array_equal(out[:, 1], 1e6 + np.arange(total))
         if not ok:
             raise SystemExit("rank %d: the gathered rows of the %s leg are not in global filter order" % (rank, leg))
-        c5[leg] = {"filters_total": total, "filters_per_gpu": hi - lo, "value": None, "gathered_rows": int(out.shape[0]), "gather_ms": el * 1e3}
+        per_rank = [el * 1e3]
+        if world > 1:
+            tl = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+            dist.all_gather(tl, torch.tensor([el * 1e3], dtype=torch.float64))
+            per_rank = [float(t.item()) for t in tl]
+        # the record a real run builds (config5_leg_record), with no GPU work behind it: value and the roofline's numbers are None
+        c5[leg] = config5_leg_record(total, hi - lo, world, 1, None, out.shape[0], per_rank, el * 1e6, None)
     # which ranks would time the CPU baselines in a real run of this shape (gathered so that the test sees every rank's answer)
     mine = 1.0 if runs_cpu_baseline(rank, world, args.no_cpu_baseline) else 0.0
     cpu_ranks = [mine]
@@ -602,10 +695,14 @@ def main():
     ap.add_argument("--secondary-budget", type=float, default=420.0, help="wall-clock limit in seconds of the child that measures the secondary records")
     ap.add_argument("--cpu-structured-child", action="store_true", help="(internal) one timed run of the structured CPU oracle in a process whose OpenMP runtime starts with the pinning variables set")
     ap.add_argument("--threads", type=int, default=1, help="(internal) OpenMP threads of --cpu-structured-child")
+    ap.add_argument("--verbose", action="store_true", help="put the prose fields (byte model, window note, environment notes) on the JSON line; the default line carries numbers and stays under 8 KB (the driver keeps an 8 KB tail)")
+    ap.add_argument("--config5", action="store_true", help="run both config-5 legs (weak 256 filters/GPU, strong 2048 in all) whatever the world size; by default they run for --gpus N > 1, and the weak leg alone rides on a one-GPU --workload batch256 line")
     ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous / shard / all-gather plumbing only, no GPU work: every rank gathers synthetic per-filter rows of its config-5 shards (CPU rehearsal, gloo)")
     args = ap.parse_args()
     if args.cpu_structured_child:
         return cpu_structured_child(args.workload, args.M, args.threads)
+    global VERBOSE
+    VERBOSE = bool(args.verbose)
     ekf_env = ekf_environment()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -648,8 +745,9 @@ def main():
     head = None if args.secondary_only else measure(pkg, mc, torch, dist, coll_device, rank, world, dev_id, args.workload, K, W, M, args.max_pending, bool(args.graph), not args.no_flush_profile)
 
     config5 = None
-    if world > 1 and not args.no_config5:
-        config5 = config5_legs(pkg, mc, torch, dist, coll_device, rank, world, dev_id, M, args.max_pending, args.config5_steps)
+    if not args.secondary_only and not args.no_config5 and (world > 1 or args.config5 or args.workload == "batch256"):
+        legs = ("weak", "strong") if (world > 1 or args.config5) else ("weak",)  # (one GPU, --workload batch256: the weak leg is config 4 itself, carrying config 5's keys)
+        config5 = config5_legs(pkg, mc, torch, dist, coll_device, rank, world, dev_id, M, args.max_pending, args.config5_steps, legs)
 
     # ---- secondary records on the same line (one GPU only): the other BASELINE.json configurations a single GPU holds, each with
     # its own roofline, so that the driver's one command puts a number behind every one of them
@@ -662,9 +760,10 @@ def main():
             except Exception as e:  # a secondary record must not cost the headline
                 secondary[name] = {"error": "%s: %s" % (type(e).__name__, e)}
         def summarise(r, unit="steps/s"):
-            out = {"workload": "%s: %d filter(s), N=%d, M=%d, window %d, overlap %d, %d timed steps after %d warm-up" % (r["workload"], r["B"], r["N"], r["M"], r["window"], r["overlap"], r["K"], r["W"]),
+            out = {"workload": "%s B=%d N=%d M=%d window=%d overlap=%d steps=%d warmup=%d prime=%d" % (r["workload"], r["B"], r["N"], r["M"], r["window"], r["overlap"], r["K"], r["W"], r["prime_steps"]),
                    "value": r["value"], "unit": unit, "ms_per_step": r["elapsed"] / r["K"] * 1e3, "device_ms_per_step": r["dev_ms"] / r["K"],
-                   "per_update_us": r["elapsed"] / (r["K"] * r["M"]) * 1e6, "roofline": r["roofline"]}
+                   "per_update_us": r["elapsed"] / (r["K"] * r["M"]) * 1e6, "host_minus_device_us": r["phases_us"]["host_minus_device"],
+                   "roofline": r["roofline"] if VERBOSE else slim_roofline(r["roofline"])}
             if r["latency"]:
                 out["per_step_latency"] = r["latency"]
             return out
@@ -672,6 +771,8 @@ def main():
         leg("config4_batch256", lambda: summarise(measure(pkg, mc, torch, None, coll_device, 0, 1, dev_id, "batch256", 200, 10, M, args.max_pending, False, True, alone=False), "filter-steps/s"))
         leg("config3_M1", lambda: summarise(measure(pkg, mc, torch, None, coll_device, 0, 1, dev_id, "n4096", 512, 32, 1, args.max_pending, False, True, alone=False)))
         leg("config3_512_steps", lambda: summarise(measure(pkg, mc, torch, None, coll_device, 0, 1, dev_id, "n4096", 512, 32, M, args.max_pending, False, True, alone=False)))
+        # the library's DEFAULT window (16; rounds 1-4 measured the headline there) beside the bench's window of 32: round-over-round comparability
+        leg("config3_512_steps_w16", lambda: summarise(measure(pkg, mc, torch, None, coll_device, 0, 1, dev_id, "n4096", 512, 32, M, 16, False, True, alone=False)))
         leg("config1_n50", lambda: config1_leg(pkg, dev_id))
         leg("immediate_calls", lambda: immediate_leg(pkg, dev_id))
         leg("propagate_only", lambda: propagate_only_leg(pkg, dev_id))
@@ -689,7 +790,7 @@ def main():
         cpu_strong = cpu_baseline_structured(args.workload, M)
         if cpu and cpu_strong and cpu_strong.get("value"):
             cpu_strong["gpu_over_cpu"] = {"faithful_dense_1_thread": head["value"] / cpu["value"], "structured_all_cores": head["value"] / cpu_strong["value"],
-                                          "note": "GPU steps/s of this line over the CPU legs' steps/s on the same host; a ratio says nothing about kernel quality (roofline does)"}
+                                          }  # (a ratio says nothing about kernel quality; the roofline does)
 
     if world == 1 and not args.no_secondary and args.workload == "n4096":
         secondary = secondary_in_a_child(args, dev_id)
@@ -716,6 +817,10 @@ def main():
                                % (args.workload, B, N, 3 + 2 * N, (3 + 2 * N) ** 2 * 8 / 1e6, M, window, head["overlap"], args.graph),
                    "N": N, "filters_per_gpu": B, "M": M, "max_pending": window, "overlap": head["overlap"]},
         "device_ms_per_step": dev_ms / K,
+        "prime_steps": head["prime_steps"],   # untimed script steps in front of the warm-up (prime_steps_for): not part of `warmup`, not timed
+        "phases_us": head["phases_us"],       # where the timed region's host-clock time went (timed_steps)
+        "max_pending": window,
+        "window_is_library_default": window == 16,  # (ekf_default_params: 16; secondary.config3_512_steps_w16 is the default-window figure)
         "roofline": head["roofline"],
         "cpu_baseline": cpu,
         "cpu_baseline_structured": cpu_strong,
@@ -723,10 +828,14 @@ def main():
         "mc_stats": mc_stats,
         "config5": config5,
         "secondary": secondary,
-        "multi_gpu_note": "no multi-GPU scaling curve has been measured by the builder (one-GPU boxes only); --gpus N shards filters with one RCCL all-gather",
+        "multi_gpu_note": "no scaling curve measured by the builder (one-GPU boxes); --gpus N shards filters, one RCCL all-gather",
         "ekf_environment": ekf_env,
     }
-    print(json.dumps(line))
+    full = {k: line[k] for k in ("value", "ms_per_step")}
+    if not VERBOSE:
+        line = compact(line)
+        line.update(full)  # the two figures the driver checks against its own clock stay exact
+    print(json.dumps(line, separators=(",", ":")))
     if dist is not None:
         dist.destroy_process_group()
 
@@ -754,9 +863,9 @@ def cpu_baseline(pkg, N, M, seed, extent, min_sep):
     t = sum(per_step)
     ps = np.array(per_step)
     return {"value": sample_steps / t, "unit": "steps/s", "cores": 1, "kind": "port",
-            "sample": "%d step(s) of the same workload (1 Propagate + %d Old Updates each) at N=%d, faithful-dense oracle, %.1f s" % (sample_steps, M, N, t),
+            "sample": "%d step(s) of the same workload (1 Propagate + %d Old Updates) at N=%d, faithful-dense oracle, %.1f s" % (sample_steps, M, N, t),
             "seconds_per_step": {"median": float(np.median(ps)), "p10": float(np.percentile(ps, 10)), "p90": float(np.percentile(ps, 90))},
-            "host_cpus": os.cpu_count(), "host": host_cpu_record(), "compiler_flags": "gcc -O3 -march=x86-64-v3 -ffp-contract=off (oracle/Makefile; the reference's Makefile:2 has no -O at all)"}
+            "host_cpus": os.cpu_count(), "host": host_cpu_record(), "compiler_flags": "gcc -O3 -march=x86-64-v3 -ffp-contract=off (oracle/Makefile)"}
 
 
 def cgroup_cpu_quota():
@@ -854,14 +963,17 @@ def cpu_baseline_structured(workload, M):
     # the strong baseline is the FASTER of the two (a host whose cores are shared or throttled without a visible quota can be slower
     # with every thread it shows than with sixteen); both runs are in the record
     best = max(ok.values(), key=lambda v: v["value"])
-    return {"value": best["value"], "unit": "steps/s", "cores": best["cores"], "kind": "port", "all_cores": runs.get("all_cores"),
-            "sample": "%d step(s) of the same workload at N=%d, structured oracle (in place, one rank-2 pass per update), %d OpenMP threads = every CPU the process may use (affinity mask, cgroup quota), %.1f s"
+    def brief(v):
+        return v if not v or "error" in v else {k: v[k] for k in ("value", "cores", "seconds", "sample_steps") if k in v}
+    same = runs.get("threads_16") is runs.get("all_cores")
+    return {"value": best["value"], "unit": "steps/s", "cores": best["cores"], "kind": "port", "all_cores": brief(runs.get("all_cores")),
+            "sample": "%d step(s) of the same workload at N=%d, structured oracle, %d OpenMP threads, %.1f s"
                       % (best["sample_steps"], best["N"], best["cores"], best["seconds"]),
             "seconds_per_step": best["seconds_per_step"],
-            "pinning": {"OMP_PROC_BIND": "spread", "OMP_PLACES": "threads", "first_touch": "P copied into the session inside the parallel region (static schedule, the rows a thread later updates)",
+            "pinning": {"OMP_PROC_BIND": "spread", "OMP_PLACES": "threads", "first_touch": "in the parallel region",
                         "affinity_cpus": affinity, "cgroup_cpu_quota": quota, "host_cpus": os.cpu_count(),
-                        "threads_rule": "min(affinity mask, cgroup CPU quota): every CPU the process can really run on"},
-            "threads_16": runs.get("threads_16")}
+                        "threads_rule": "min(affinity mask, cgroup CPU quota)"},
+            "threads_16": "= all_cores" if same else brief(runs.get("threads_16"))}
 
 
 if __name__ == "__main__":

@@ -210,6 +210,26 @@ int ekf_record_truth(ekf_handle h, const double *truth);
 void *ekf_stream(ekf_handle h);
 /* Bytes of HBM held by the handle. */
 size_t ekf_device_bytes(ekf_handle h);
+/* Diagnostic: dense-pass windows closed since create (kept across ekf_reserve) and the slot count of the last one -- how a
+ * scripted run was cut into windows (tests/test_gpu_parity.py: balanced tail, odd windows). */
+int ekf_debug_windows(ekf_handle h, long long *closed_out, int *last_slots_out);
+
+/* ---- Tunables -----------------------------------------------------------------------------------
+ * Environment variables read once per handle at ekf_create / ekf_batch_create by the PRODUCT library.  They change scheduling
+ * and kernel geometry only -- results are identical whatever they say (the parity suite runs the non-default side of each) --
+ * and exist for A/B measurements; bench.py prints every EKF_* variable it saw into its JSON line.
+ *   EKF_OVERLAP=0/1        force the in-place / the two-buffer overlapped dense-pass pipeline (default: ekf_params.overlap, -1 = by size)
+ *   EKF_PERSIST=0          scripted runs: one chain launch per window instead of multi-segment launches
+ *   EKF_BALANCED_TAIL=0    scripted runs close every window at max_pending (default: the last two windows share what is left)
+ *   EKF_CHAIN_ONE=0        several-workgroup filters use the general chain kernel, not the one-landmark-per-thread one
+ *   EKF_CHAIN_HELPERS=0/1  forbid / force the two helper waves of a one-owner-wave chain workgroup
+ *   EKF_CHAIN_WGS, EKF_CHAIN_CUS   chain workgroups per filter / CUs kept for them beside an overlapped pass
+ *   EKF_INLINE_REC=0       immediate-mode records travel through the host-mapped ring instead of the kernel arguments
+ *   EKF_XCD_MAP=0, EKF_BATCH_INTERLEAVE=0, EKF_FLUSH_ALTERNATE=0   dense-pass tile order experiments
+ *   EKF_SOLO=0, EKF_SOLO_FUSE=0, EKF_SOLO_LONG_WINDOW=0, EKF_SOLO_GROUPS=n   one-workgroup filters: general kernel / separate pass launches / short window / phase groups
+ *   EKF_INKERNEL_WAIT=0    chain launches wait for their pass by stream event instead of in-kernel
+ *   EKF_TRACE=1            progress marks of handle creation on stderr
+ * EKF_DEBUG_* hooks (skipped passes, dropped completion marks, short spin limits) exist ONLY in libekfslam_hip_debug.so. */
 
 #ifdef __cplusplus
 }

@@ -863,6 +863,38 @@ def test_balanced_tail_halves_what_is_left_and_changes_nothing_else(pkg, monkeyp
     assert_bitwise_symmetric(Pb)
 
 
+@pytest.mark.parametrize("max_pending,meas", [(15, 29), (15, 17), (7, 13), (31, 61)])
+def test_balanced_tail_with_an_odd_window_never_passes_max_pending(pkg, oc, monkeypatch, pipeline_mode, max_pending, meas):
+    """Round-5 advisor finding: the balanced tail rounds the half of what is left UP to a slot pair -- with an odd max_pending and
+    2 * max_pending - 1 measurements left that gave a limit of max_pending + 1 (a slot past the slot_meta row, the own-row cache and the
+    pass's slot count).  The limit is clamped now: no window closes with more than max_pending slots (ekf_debug_windows), and the run
+    equals the oracle.  One measurement per step so that every slot count can be reached exactly."""
+    import ctypes
+    if pipeline_mode != "overlap":
+        pytest.skip("overlap mode only")
+    N, M = 1024, 1
+    monkeypatch.setenv("EKF_OVERLAP", "1")
+    x0, P0 = pkg.scenarios.injected_state(N, seed=31, extent=25.0)
+    sc = pkg.scenarios.steady_script(x0, steps=meas, M=M, seed=32, min_separation=1.0)
+    f = pkg.FilterBatch(1, N, max_pending=max_pending, log_capacity=4096)
+    assert f.overlap and f.window == max_pending
+    f.L.ekf_debug_windows.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_int)]
+    closed, last = ctypes.c_longlong(), ctypes.c_int()
+    f.set_state(x0, P0)
+    load_script(f, sc)
+    f.script_run(0, meas)
+    f.flush()
+    f.sync()
+    assert f.L.ekf_debug_windows(f.h, ctypes.byref(closed), ctypes.byref(last)) == 0
+    assert last.value <= max_pending and closed.value >= 2, (closed.value, last.value)
+    xg, Pg = f.get_state()
+    xo, Po, decs = run_oracle_script(oc, x0, P0, sc, meas, M)
+    assert [(d[0], d[1]) for d in f.decisions(0, meas * M)] == decs
+    assert_state_close(xg, Pg, xo, Po, "odd window %d, %d measurements" % (max_pending, meas))
+    assert_bitwise_symmetric(Pg)
+    f.close()
+
+
 def test_multi_segment_launches_with_filters_that_run_ahead(pkg, monkeypatch, pipeline_mode):
     """Regression for the stream gates of multi-segment launches (round-2 advisor finding): workgroups of different filters do not
     wait for each other between segments, so a filter whose measurements are all masked (OP_SKIP_SLOT: no sweep, no exchange,
