@@ -115,6 +115,13 @@ struct ekf_batch {
     bool dbg_skip_flush = false;        // EKF_DEBUG_SKIP_FLUSH=1: timing experiments only, results are wrong
     int dbg_drop_marks_from = 0;        // EKF_DEBUG_DROP_MARKS_FROM=k (and ..._TO=m, exclusive): dense passes k .. m-1 never report completion (tests of the bounded waits)
     int dbg_drop_marks_to = 0x7fffffff;
+    // streaming immediate-mode calls (one-filter handles run by k_chain<true>; EKF_STREAM=0 switches them off): a resident launch consumes
+    // the calls' operations from a host-mapped command ring (ekf_device.h: StreamCtl)
+    StreamCtl *sctl_h = nullptr;  // host view of dv.sctl
+    bool stream_calls = false;    // the handle streams its immediate-mode calls
+    bool stream_alive = false;    // a streaming launch has been started and not been told (or seen) to leave
+    int stream_launch = 0;        // number of the newest streaming launch (ChainPlan::stream)
+    long long stream_starts = 0, stream_ops = 0;  // (diagnostics: ekf_debug_stream)
     // immediate-mode input ring (host-mapped pinned)
     double *ring_h;
     double *ring_d;
@@ -141,6 +148,7 @@ struct ekf_batch {
 };
 
 static int sticky_status(ekf_batch *h, bool include_capacity);
+static int stream_stop(ekf_batch *h);
 
 extern "C" const char *ekf_last_error(void) { return g_last_error.c_str(); }
 
@@ -435,6 +443,8 @@ static int create_impl(ekf_batch *h, int batch, int capacity_landmarks, int devi
     h->chain_lds = (size_t)lpw64 * cache_slots * 32;
     HIP_TRY(hipFuncSetAttribute((const void *)k_chain<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_budget));  // one setting for every handle
     HIP_TRY(hipFuncSetAttribute((const void *)k_chain<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_budget));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_chain<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_budget));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_chain<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_budget));
     HIP_TRY(hipFuncSetAttribute((const void *)k_solo<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_budget));
     HIP_TRY(hipFuncSetAttribute((const void *)k_solo<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_budget));
     int workers = (dv.lpw + 63) / 64 * 64;
@@ -514,6 +524,10 @@ static int create_impl(ekf_batch *h, int batch, int capacity_landmarks, int devi
     HIP_TRY(hipHostMalloc((void **)&h->mirror_h, B * sizeof(EkfMirror), hipHostMallocMapped));
     memset(h->mirror_h, 0, B * sizeof(EkfMirror));
     HIP_TRY(hipHostGetDevicePointer((void **)&dv.mirror, h->mirror_h, 0));
+    HIP_TRY(dev_alloc_zero(&dv.sfw, 40, &h->device_bytes, s));
+    HIP_TRY(hipHostMalloc((void **)&h->sctl_h, sizeof(StreamCtl), hipHostMallocMapped));
+    memset(h->sctl_h, 0, sizeof(StreamCtl));
+    HIP_TRY(hipHostGetDevicePointer((void **)&dv.sctl, h->sctl_h, 0));
     size_t rec_bytes = B * 8 * sizeof(double);
     long ring_ops = (long)((16u << 20) / rec_bytes);
     if (ring_ops > 1024) ring_ops = 1024;
@@ -608,6 +622,8 @@ static int create_impl(ekf_batch *h, int batch, int capacity_landmarks, int devi
     }
     h->flush_dir = 0;
     read_debug_hooks(h);
+    // streaming immediate-mode calls: one filter run by k_chain (every single-filter map above 256 landmarks, and smaller ones on forced geometries)
+    h->stream_calls = batch == 1 && !h->solo_kernel && !(getenv("EKF_STREAM") && atoi(getenv("EKF_STREAM")) == 0);
     h->xcd_map = getenv("EKF_XCD_MAP") ? atoi(getenv("EKF_XCD_MAP")) != 0 : true;
     h->batch_interleave = getenv("EKF_BATCH_INTERLEAVE") ? atoi(getenv("EKF_BATCH_INTERLEAVE")) != 0 : true;
     h->script_d = nullptr;
@@ -633,6 +649,7 @@ extern "C" int ekf_destroy(ekf_handle h) {
     if (!h) return EKF_OK;
     hipSetDevice(h->device);
     TRACE("destroy: sync");
+    if (h->sctl_h && h->s_chain) (void)stream_stop(h);  // (a resident streaming launch leaves first)
     if (h->s_chain) hipStreamSynchronize(h->s_chain);
 #ifdef EKF_CHAIN_CHECK
     if (h->dv.dbg) {
@@ -670,6 +687,8 @@ extern "C" int ekf_destroy(ekf_handle h) {
         if (m) hipFree(m);
     if (h->script_d) hipFree(h->script_d);
     if (h->ring_h) hipHostFree(h->ring_h);
+    if (h->sctl_h) hipHostFree(h->sctl_h);
+    if (h->dv.sfw) hipFree(h->dv.sfw);
     if (h->mirror_h) hipHostFree(h->mirror_h);
     for (int i = 0; i < 2; i++)
         if (h->ring_ev[i]) hipEventDestroy(h->ring_ev[i]);
@@ -694,7 +713,11 @@ extern "C" int ekf_window(ekf_handle h) { return h ? h->dv.maxp : EKF_ERR_BAD_AR
 extern "C" int ekf_overlap(ekf_handle h) { return h ? (h->overlap ? 1 : 0) : EKF_ERR_BAD_ARG; }
 
 extern "C" int ekf_capacity(ekf_handle h) { return h ? h->dv.Ncap : EKF_ERR_BAD_ARG; }
-extern "C" void *ekf_stream(ekf_handle h) { return h ? (void *)h->s_chain : nullptr; }
+extern "C" void *ekf_stream(ekf_handle h) {
+    if (!h) return nullptr;
+    (void)stream_stop(h);  // (the caller is about to order its own work on this stream: nothing resident may hold it)
+    return (void *)h->s_chain;
+}
 extern "C" size_t ekf_device_bytes(ekf_handle h) { return h ? h->device_bytes : 0; }
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
@@ -821,8 +844,147 @@ static size_t prof_pairs_for_script(const ekf_batch *h) {
     return (slots / half + 8) * (size_t)(h->ngroups > 1 ? h->ngroups : 1);
 }
 
+// ---- streaming immediate-mode calls (ekf_device.h: StreamCtl; k_chain<true, true>) -------------------------------------------------
+// The resident launch is told to leave and waited for (its epilogue writes the state back that later launches and copies read).  Every
+// entry point that enqueues on the chain stream, reads device memory or hands the stream out comes through here first; the
+// immediate-mode operations themselves and the mirror's readers (pose, landmark count, robot block, newest decisions, counters) do not.
+static int stream_stop(ekf_batch *h) {
+    if (!h->stream_alive) return EKF_OK;
+    h->stream_alive = false;
+    StreamCtl *c = h->sctl_h;
+    const unsigned long long launch = (unsigned long long)(unsigned)h->stream_launch;
+    // what has been posted is consumed first: the launch looks at the command slot before it looks at the stop word, but the two reads
+    // may be served in either order -- a stop seen without the command posted in front of it would leave that command behind
+    timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (long spin = 0;; spin++) {
+        if (__atomic_load_n(&h->mirror_h[0].seq, __ATOMIC_ACQUIRE) >= h->chain_seq) break;
+        if (__atomic_load_n(&c->state, __ATOMIC_ACQUIRE) == ((launch << 2) | EKF_STREAM_EXITED)) break;  // (left by itself, or gave up: the status says)
+        if ((spin & 255) == 255) {
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            if ((t1.tv_sec - t0.tv_sec) * 1000000000L + (t1.tv_nsec - t0.tv_nsec) > 2000000000L) break;  // (2 s: the stream wait below reports what is wrong)
+        }
+        __builtin_ia32_pause();
+    }
+    __atomic_store_n(&c->stop, launch, __ATOMIC_SEQ_CST);
+    HIP_TRY(stream_wait(h->s_chain));
+    // a command the launch left behind (it went by itself while the command was on its way, and nobody has relaunched since: only
+    // stream_op posts, and it resolves that before it returns) cannot exist here
+    return EKF_OK;
+}
+
+// Start a streaming launch on the open window: one segment without operations, consuming commands from h->chain_seq + 1 on.
+static int stream_start(ekf_batch *h) {
+    ChainPlan plan;
+    memset(&plan, 0, sizeof plan);
+    ChainSeg &sg = plan.s[0];
+    sg.k0 = 0, sg.nops = 0, sg.slot0 = h->pending, sg.set = h->cur_set, sg.buf_read = h->buf_in, sg.n_prev = h->prev_pending;
+    sg.need_pass = h->need_pass, sg.drop = 0;
+    sg.seq = h->chain_seq;  // the last command consumed before this launch
+    sg.gate = 0, sg.self_pass = 0, sg.stagger = 0;
+    plan.nseg = 1, plan.signal = 0, plan.inl_n = 0;
+    h->stream_launch = h->stream_launch >= 0xffff ? 1 : h->stream_launch + 1;  // (16 bits of it tag the forwards)
+    plan.stream = h->stream_launch;
+    __atomic_store_n(&h->sctl_h->state, ((unsigned long long)(unsigned)plan.stream << 2) | EKF_STREAM_RUNNING, __ATOMIC_SEQ_CST);
+    if (h->chain_one)
+        hipExtLaunchKernelGGL((k_chain<true, true>), dim3(h->chain_wgs, 1), dim3(h->chain_threads), h->chain_lds, h->s_chain, nullptr, nullptr, 0, h->dv,
+                              (const double *)h->ring_d, (const int *)nullptr, plan, 0);
+    else
+        hipExtLaunchKernelGGL((k_chain<false, true>), dim3(h->chain_wgs, 1), dim3(h->chain_threads), h->chain_lds, h->s_chain, nullptr, nullptr, 0, h->dv,
+                              (const double *)h->ring_d, (const int *)nullptr, plan, 0);
+    h->stream_alive = true;
+    h->chain_signalled = false;
+    h->stream_starts++;
+    return check_launch();
+}
+
+static int close_set(ekf_batch *h, bool terminal, EnqueueList *defer);
+
+// One immediate-mode operation through the streaming launch: post the command, make sure somebody consumes it, keep the host's
+// window bookkeeping (launch_ops' for a one-operation launch).  rec: the operation's record; consumes: it takes a slot.
+static int stream_op(ekf_batch *h, const double *rec, bool consumes) {
+    StreamCtl *c = h->sctl_h;
+    const bool closes = consumes && h->pending + 1 >= h->dv.maxp;
+    const long long seq = ++h->chain_seq;
+    StreamCmd *cmd = &c->cmd[(unsigned long long)seq % EKF_STREAM_RING];
+    if (seq > EKF_STREAM_RING) {  // the slot's previous command (seq - ring) must have been consumed: a caller that posts without ever reading
+        timespec t0, t1;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        for (long spin = 0; __atomic_load_n(&h->mirror_h[0].seq, __ATOMIC_ACQUIRE) < seq - EKF_STREAM_RING; spin++) {
+            if ((spin & 255) == 255) {
+                clock_gettime(CLOCK_MONOTONIC, &t1);
+                if ((t1.tv_sec - t0.tv_sec) * 1000000000L + (t1.tv_nsec - t0.tv_nsec) > 1000000000L) {
+                    h->chain_seq--;
+                    return set_error(EKF_ERR_TIMEOUT, "the streaming launch does not consume its commands");
+                }
+            }
+            __builtin_ia32_pause();
+        }
+    }
+    {
+        // seventeen granules {32 payload bits, the sequence number's low half}; the flags last (the launch looks for them first, and re-reads
+        // every other granule until it carries the tag)
+        const unsigned long long tg = ((unsigned long long)seq & 0xffffffffull) << 32;
+        for (int i = 0; i < 8; i++) {
+            unsigned long long bits;
+            memcpy(&bits, rec + i, sizeof bits);
+            __atomic_store_n(&cmd->g[2 * i], (bits & 0xffffffffull) | tg, __ATOMIC_RELAXED);
+            __atomic_store_n(&cmd->g[2 * i + 1], (bits >> 32) | tg, __ATOMIC_RELAXED);
+        }
+        __atomic_store_n(&cmd->g[16], (unsigned long long)(closes ? EKF_STREAM_END_AFTER : 0) | tg, __ATOMIC_RELEASE);
+    }
+    h->stream_ops++;
+    for (int attempt = 0;; attempt++) {
+        if (!h->stream_alive) {
+            // (nothing of an earlier launch is pending in the ring: commands are consumed in order and this one is the newest)
+            h->chain_seq = seq - 1;  // stream_start reads "the last command consumed before the launch" here
+            int rc = stream_start(h);
+            h->chain_seq = seq;
+            if (rc) return rc;
+            break;
+        }
+        // "write mine, fence, read yours": the launch does the same with its state word and this command slot before it leaves by itself
+        __atomic_thread_fence(__ATOMIC_SEQ_CST);
+        const unsigned long long launch = (unsigned long long)(unsigned)h->stream_launch;
+        unsigned long long st = __atomic_load_n(&c->state, __ATOMIC_ACQUIRE);
+        if (st == ((launch << 2) | EKF_STREAM_RUNNING)) break;
+        // leaving, or gone: the outcome is either the operation done (the launch found the command and stayed) or the launch gone without it
+        bool gone = false;
+        timespec t0, t1;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        for (long spin = 0;; spin++) {
+            if (__atomic_load_n(&h->mirror_h[0].seq, __ATOMIC_ACQUIRE) >= seq) break;
+            st = __atomic_load_n(&c->state, __ATOMIC_ACQUIRE);
+            if (st == ((launch << 2) | EKF_STREAM_RUNNING)) break;  // the exit was cancelled: the command is being worked on
+            if (st == ((launch << 2) | EKF_STREAM_EXITED)) {
+                gone = (long long)__atomic_load_n(&c->consumed, __ATOMIC_ACQUIRE) < seq;
+                break;
+            }
+            if ((spin & 255) == 255) {
+                clock_gettime(CLOCK_MONOTONIC, &t1);
+                if ((t1.tv_sec - t0.tv_sec) * 1000000000L + (t1.tv_nsec - t0.tv_nsec) > 1000000000L) return set_error(EKF_ERR_TIMEOUT, "a streaming launch neither stayed nor left");
+            }
+            __builtin_ia32_pause();
+        }
+        if (!gone || attempt > 2) break;
+        h->stream_alive = false;  // relaunch for this command
+    }
+    h->mirror_by_chain = true;
+    h->stats_in_mirror = true;
+    if (consumes) h->pending++;
+    if (closes) {
+        h->stream_alive = false;  // (the launch leaves behind this operation by itself: EKF_STREAM_END_AFTER)
+        return close_set(h, false, nullptr);
+    }
+    return EKF_OK;
+}
+
 static int close_set(ekf_batch *h, bool terminal = false, EnqueueList *defer = nullptr) {
-    if (h->pending == 0) return EKF_OK;
+    if (h->pending == 0) return stream_stop(h);
+    {
+        int rc_s = stream_stop(h);
+        if (rc_s) return rc_s;
+    }
     int nT_hi = (2 * h->n_lm_hi + 63) / 64;
     const int fin = (h->overlap && h->prev_pending > 0) ? h->buf_in ^ 1 : h->buf_in;
     // terminal: the caller asked for everything to be folded (ekf_flush, settle), so no chain kernel will run beside this
@@ -959,6 +1121,22 @@ static int settle(ekf_batch *h) {
 static int launch_ops_grouped(ekf_batch *h, const double *in, int k0, const unsigned char *consumes, int nops);
 
 static int launch_ops(ekf_batch *h, const double *in, const int *cursor, int k0, const unsigned char *consumes, int nops, bool defer_last_close = false) {
+    if (h->stream_calls && cursor == nullptr && in == h->ring_d && nops > 0) {
+        // an immediate-mode call of a one-filter handle: its operations go to the resident streaming launch, one command each
+        if (h->pending == h->dv.maxp) {  // a set whose close a scripted run deferred: more work follows, regular pass
+            int rc = close_set(h);
+            if (rc) return rc;
+        }
+        for (int q = 0; q < nops; q++) {
+            int rc = stream_op(h, h->ring_h + (size_t)(k0 + q) * 8, consumes[q] != 0);
+            if (rc) return rc;
+        }
+        return EKF_OK;
+    }
+    {
+        int rc = stream_stop(h);
+        if (rc) return rc;
+    }
     int i = 0;
     if (h->pending == h->dv.maxp && nops > 0) {  // a set whose close the previous call deferred: more work follows, regular pass
         int rc = close_set(h);
@@ -1096,7 +1274,7 @@ static int launch_ops(ekf_batch *h, const double *in, const int *cursor, int k0,
         next_drop = 0;
         plan.s[plan.nseg++] = sg;
         plan.signal = persist ? 1 : 0;
-        plan.reserved_ = 0;
+        plan.stream = 0;
         h->mirror_by_chain = true;
         h->stats_in_mirror = true;
         h->pending = used;
@@ -1227,7 +1405,11 @@ static int ring_reserve(ekf_batch *h, int count, double **rec, int *k_out) {
     if (count > half) return set_error(EKF_ERR_BAD_ARG, "too many operations in one call");
     int pos = h->ring_pos;
     int which = pos < half ? 0 : 1;
-    if (pos + count > (which + 1) * half) {  // does not fit the rest of this half: move to the next half
+    if (h->stream_calls && pos + count > (which + 1) * half) {
+        // (a streaming handle's records are copied into the command ring when they are posted: no launch ever reads this ring)
+        which ^= 1;
+        pos = which * half;
+    } else if (pos + count > (which + 1) * half) {  // does not fit the rest of this half: move to the next half
         HIP_TRY(hipEventRecord(h->ring_ev[which], h->s_chain));
         h->ring_ev_valid[which] = true;
         which ^= 1;
@@ -1268,7 +1450,11 @@ static int refresh_bounds(ekf_batch *h, bool full = true) {
             __builtin_ia32_pause();
         }
     }
-    if (!done) HIP_TRY(stream_wait(h->s_chain));
+    if (!done) {
+        int rc_ = stream_stop(h);  // (a resident streaming launch leaves first: the stream would not drain before its idle time is over)
+        if (rc_) return rc_;
+        HIP_TRY(stream_wait(h->s_chain));
+    }
     int mx = 0;
     for (int b = 0; b < h->dv.B; b++) {
         h->h_int[b] = h->mirror_h[b].n_lm;
@@ -1428,6 +1614,7 @@ static int sticky_status(ekf_batch *h, bool include_capacity) {
 extern "C" int ekf_sync(ekf_handle h) {
     if (!h) return set_error(EKF_ERR_BAD_ARG, "null handle");
     HIP_TRY(hipSetDevice(h->device));
+    { int rc_ = stream_stop(h); if (rc_) return rc_; }  // (a resident streaming launch leaves first)
     HIP_TRY(stream_wait(h->s_chain));
     if (h->overlap) HIP_TRY(stream_wait(h->s_flush));
     // Every bounded wait that runs out stores EKF_ERR_TIMEOUT into the host-mapped mirror itself, at once (and nothing but
@@ -1502,6 +1689,7 @@ extern "C" int ekf_get_robot_cov(ekf_handle h, double P_RR_out[9]) {
 extern "C" int ekf_get_x(ekf_handle h, int index, double *x_out, int n_max) {
     if (!h || index < 0 || index >= h->dv.B || !x_out || n_max < 0) return set_error(EKF_ERR_BAD_ARG, "bad argument");
     HIP_TRY(hipSetDevice(h->device));
+    { int rc_ = stream_stop(h); if (rc_) return rc_; }  // (a resident streaming launch leaves first)
     int rc = refresh_bounds(h);
     if (rc) return rc;
     int n = 3 + 2 * h->h_int[index];
@@ -1536,6 +1724,7 @@ static int fetch_decisions(ekf_batch *h, int n_z, ekf_decision *out) {
 extern "C" int ekf_get_decisions(ekf_handle h, int index, ekf_decision *out, int count) {
     if (!h || !out || index < 0 || index >= h->dv.B || count < 0) return set_error(EKF_ERR_BAD_ARG, "bad argument");
     HIP_TRY(hipSetDevice(h->device));
+    { int rc_ = stream_stop(h); if (rc_) return rc_; }  // (a resident streaming launch leaves first)
     long long cnt;
     HIP_TRY(hipMemcpyAsync(&cnt, h->dv.log_count + index, sizeof cnt, hipMemcpyDeviceToHost, h->s_chain));
     HIP_TRY(stream_wait(h->s_chain));
@@ -1566,6 +1755,7 @@ extern "C" int ekf_get_stats(ekf_handle h, ekf_stats *out) {
 extern "C" int ekf_stats_means_device(ekf_handle h, double *out_device) {
     if (!h || !out_device) return set_error(EKF_ERR_BAD_ARG, "null argument");
     HIP_TRY(hipSetDevice(h->device));
+    { int rc_ = stream_stop(h); if (rc_) return rc_; }  // (a resident streaming launch leaves first)
     hipPointerAttribute_t attr;
     if (hipPointerGetAttributes(&attr, out_device) != hipSuccess || (attr.type != hipMemoryTypeDevice && attr.type != hipMemoryTypeManaged)) {
         (void)hipGetLastError();
@@ -1579,6 +1769,7 @@ extern "C" int ekf_stats_means_device(ekf_handle h, double *out_device) {
 extern "C" int ekf_reset_stats(ekf_handle h) {
     if (!h) return set_error(EKF_ERR_BAD_ARG, "null handle");
     HIP_TRY(hipSetDevice(h->device));
+    { int rc_ = stream_stop(h); if (rc_) return rc_; }  // (a resident streaming launch leaves first)
     HIP_TRY(hipMemsetAsync(h->dv.stats, 0, sizeof(ekf_stats) * h->dv.B, h->s_chain));
     h->stats_in_mirror = false;  // until the next chain launch writes the mirror
     return EKF_OK;
@@ -1588,6 +1779,7 @@ extern "C" int ekf_reset_stats(ekf_handle h) {
 extern "C" int ekf_get_state(ekf_handle h, int index, double *x_out, double *P_out, int ld) {
     if (!h || index < 0 || index >= h->dv.B) return set_error(EKF_ERR_BAD_ARG, "bad argument");
     HIP_TRY(hipSetDevice(h->device));
+    { int rc_ = stream_stop(h); if (rc_) return rc_; }  // (a resident streaming launch leaves first)
     int rc = refresh_bounds(h);
     if (rc) return rc;
     int n = 3 + 2 * h->h_int[index];
@@ -1614,6 +1806,7 @@ extern "C" int ekf_set_state(ekf_handle h, int index, const double *x, const dou
     int N = (n - 3) / 2;
     if (N > h->dv.Ncap) return set_error(EKF_ERR_CAPACITY, "state larger than capacity_landmarks");
     HIP_TRY(hipSetDevice(h->device));
+    { int rc_ = stream_stop(h); if (rc_) return rc_; }  // (a resident streaming launch leaves first)
     int rc = settle(h);
     if (rc) return rc;
     EkfDev &dv = h->dv;
@@ -1662,6 +1855,7 @@ extern "C" int ekf_reserve(ekf_handle h, int capacity_landmarks) {
     if (!h || capacity_landmarks < 1 || capacity_landmarks > EKF_MAX_CAPACITY) return set_error(EKF_ERR_BAD_ARG, "bad handle / capacity (EKF_MAX_CAPACITY)");
     if (capacity_landmarks <= h->dv.Ncap) return EKF_OK;
     HIP_TRY(hipSetDevice(h->device));
+    { int rc_ = stream_stop(h); if (rc_) return rc_; }  // (a resident streaming launch leaves first)
     int rc = settle(h);  // every deferred slot folded, both streams idle
     if (rc) return rc;
     rc = refresh_bounds(h);  // h_int[b] = landmarks of filter b; a sticky EKF_ERR_TIMEOUT (invalid state) ends it here
@@ -1762,6 +1956,7 @@ extern "C" int ekf_reserve(ekf_handle h, int capacity_landmarks) {
 extern "C" int ekf_broadcast_state(ekf_handle h) {
     if (!h) return set_error(EKF_ERR_BAD_ARG, "null handle");
     HIP_TRY(hipSetDevice(h->device));
+    { int rc_ = stream_stop(h); if (rc_) return rc_; }  // (a resident streaming launch leaves first)
     int rc = settle(h);
     if (rc) return rc;
     EkfDev &dv = h->dv;
@@ -1794,6 +1989,7 @@ extern "C" int ekf_script_load(ekf_handle h, int steps, int M, const double *ctr
                                const unsigned char *valid, const double *truth) {
     if (!h || steps < 1 || M < 0 || !ctrl || (M > 0 && (!z || !R))) return set_error(EKF_ERR_BAD_ARG, "bad argument");
     HIP_TRY(hipSetDevice(h->device));
+    { int rc_ = stream_stop(h); if (rc_) return rc_; }  // (a resident streaming launch leaves first)
     HIP_TRY(stream_wait(h->s_chain));
     for (auto &g : h->graphs) hipGraphExecDestroy(g.exec);
     h->graphs.clear();
@@ -1864,6 +2060,7 @@ extern "C" int ekf_script_run(ekf_handle h, int first_step, int n_steps, int use
     if (!h || !h->script_d) return set_error(EKF_ERR_STATE, "no script loaded");
     if (first_step < 0 || n_steps < 0 || first_step + n_steps > h->script_steps) return set_error(EKF_ERR_BAD_ARG, "step range outside the script");
     HIP_TRY(hipSetDevice(h->device));
+    { int rc_ = stream_stop(h); if (rc_) return rc_; }  // (a resident streaming launch leaves first)
     int ops = ops_per_step(h);
     int s = first_step, end = first_step + n_steps;
     if (use_graph && !h->overlap) {  // (the two-stream pipeline is not captured: plain launches)
@@ -1935,9 +2132,18 @@ extern "C" int ekf_debug_windows(ekf_handle h, long long *closed, int *last_slot
     return EKF_OK;
 }
 
+// (tests, bench) streaming launches started and operations posted to them since create
+extern "C" int ekf_debug_stream(ekf_handle h, long long *starts, long long *ops) {
+    if (!h || !starts || !ops) return set_error(EKF_ERR_BAD_ARG, "null argument");
+    *starts = h->stream_starts;
+    *ops = h->stream_ops;
+    return h->stream_calls ? 1 : 0;
+}
+
 extern "C" int ekf_debug_stamps(ekf_handle h, long long *out16, int reset) {
     if (!h || !out16) return EKF_ERR_BAD_ARG;
     HIP_TRY(hipSetDevice(h->device));
+    { int rc_ = stream_stop(h); if (rc_) return rc_; }  // (a resident streaming launch leaves first)
     HIP_TRY(stream_wait(h->s_chain));
     HIP_TRY(hipMemcpy(out16, h->dv.dbg, 32 * sizeof(long long), hipMemcpyDeviceToHost));
     if (reset) HIP_TRY(hipMemset(h->dv.dbg, 0, 32 * sizeof(long long)));
@@ -1950,6 +2156,7 @@ extern "C" int ekf_debug_stamps(ekf_handle h, long long *out16, int reset) {
 extern "C" int ekf_debug_exchange_trace(ekf_handle h, long long *out) {
     if (!h || !out) return EKF_ERR_BAD_ARG;
     HIP_TRY(hipSetDevice(h->device));
+    { int rc_ = stream_stop(h); if (rc_) return rc_; }  // (a resident streaming launch leaves first)
     HIP_TRY(stream_wait(h->s_chain));
     HIP_TRY(hipMemcpy(out, h->dv.dbg + 32, (size_t)65 * 2048 * sizeof(long long), hipMemcpyDeviceToHost));
     return EKF_OK;
@@ -1960,6 +2167,7 @@ extern "C" int ekf_debug_exchange_trace(ekf_handle h, long long *out) {
 extern "C" int ekf_timer_start(ekf_handle h) {
     if (!h) return set_error(EKF_ERR_BAD_ARG, "null handle");
     HIP_TRY(hipSetDevice(h->device));
+    { int rc_ = stream_stop(h); if (rc_) return rc_; }  // (a resident streaming launch leaves first)
     HIP_TRY(hipEventRecord(h->t0, h->s_chain));
     return EKF_OK;
 }
@@ -1967,6 +2175,7 @@ extern "C" int ekf_timer_start(ekf_handle h) {
 extern "C" int ekf_timer_stop(ekf_handle h, double *ms_out) {
     if (!h || !ms_out) return set_error(EKF_ERR_BAD_ARG, "null argument");
     HIP_TRY(hipSetDevice(h->device));
+    { int rc_ = stream_stop(h); if (rc_) return rc_; }  // (a resident streaming launch leaves first)
     if (h->overlap && h->prev_pending > 0) HIP_TRY(hipStreamWaitEvent(h->s_chain, h->pass_done[h->ev_idx], 0));  // the pass in flight counts
     HIP_TRY(hipEventRecord(h->t1, h->s_chain));
     HIP_TRY(event_wait(h->t1));
@@ -1991,6 +2200,7 @@ extern "C" int ekf_fused_pass(ekf_handle h) { return h && h->solo_fuse ? 1 : 0; 
 extern "C" int ekf_flush_profile_read(ekf_handle h, long long *launches_out, double *total_ms_out) {
     if (!h) return set_error(EKF_ERR_BAD_ARG, "null handle");
     HIP_TRY(hipSetDevice(h->device));
+    { int rc_ = stream_stop(h); if (rc_) return rc_; }  // (a resident streaming launch leaves first)
     HIP_TRY(stream_wait(h->s_chain));
     if (h->overlap) HIP_TRY(stream_wait(h->s_flush));
     for (size_t i = 0; i + 1 < h->prof_used; i += 2) {

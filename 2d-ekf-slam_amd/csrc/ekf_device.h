@@ -89,9 +89,45 @@ struct ChainPlan {
     int inl_n;                      // != 0: the launch's one operation record (one filter, one operation: an immediate-mode call) travels in inl[]
                                     // with the kernel arguments instead of the host-mapped input ring: the kernel's first trip to host memory
                                     // (its arguments) brings the record along, where the ring costs a second, dependent one
-    int reserved_;
+    int stream;                     // != 0: a STREAMING launch (k_chain<true, true>, round 6), the value is its launch number: one segment with no
+                                    // operations of its own; the operations arrive one by one through the host-mapped command ring (StreamCtl),
+                                    // s[0].seq is the number of the last command consumed BEFORE this launch
     ChainSeg s[EKF_PLAN_MAX];
     double inl[8];
+};
+
+// ---- streaming immediate-mode calls (round 6) -----------------------------------------------------------------------------------
+// The reference drives the filter one synchronising call per operation (slam.cpp:136-170).  As one kernel launch per call that is
+// ~20 us per call around 1-7 us of device work: launch, dispatch, the workgroups' state reload (landmark registers, the own-row cache
+// of the open window), completion.  A streaming launch stays resident instead: workgroup 0's control lane polls a command ring in
+// host-mapped memory, forwards each command to the filter's other workgroups through device memory, the operation runs exactly as
+// it does inside a scripted segment, and workgroup 0 publishes the host mirror (pose, robot block, counts, decisions, sequence
+// number) after EVERY operation.  The kernel leaves when the host says so (the window is full: the dense pass must run; any API call
+// that needs the stream), or by itself after EKF_STREAM_IDLE_TICKS without a command.
+//   host -> device: StreamCmd, seventeen self-validating granules (record and flags), each tagged with the command's sequence number
+//   device -> host: StreamCtl::state = (launch number << 2) | phase, and the mirror
+// Leaving by itself races with a command being posted; both sides do "write mine, fence, read yours" (the host: command, mfence,
+// state; workgroup 0: state = EXITING, system fence, command slot -- a PCIe read does not pass the posted write in front of it), so at
+// least one sees the other: workgroup 0 cancels its exit when it finds a command, the host waits for the outcome when it finds
+// EXITING, and relaunches when the kernel has left without consuming the command.
+#define EKF_STREAM_RING 16
+#define EKF_STREAM_IDLE_TICKS 10000 /* of the 100 MHz clock: 100 us */
+enum { EKF_STREAM_RUNNING = 1, EKF_STREAM_EXITING = 2, EKF_STREAM_EXITED = 3 };
+enum { EKF_STREAM_END_AFTER = 1, EKF_STREAM_EXIT = 2 };  // command flags: leave after this operation (host); leave now (workgroup 0's forward only)
+struct alignas(128) StreamCmd {
+    // Seventeen self-validating 8-byte granules {32 payload bits, 32-bit tag = the low half of the command's sequence number} -- the form the
+    // cross-workgroup exchange uses (MI355X_MICROARCH.md, granules): g[2i], g[2i + 1] = low / high half of rec[i], g[16] = the flags.  The
+    // host writes g[16] last and the launch looks for it first, but nothing DEPENDS on that order: every granule is re-read until it carries
+    // the tag, so no assumption is made about the order in which reads of two cache lines of host memory are served.
+    unsigned long long g[18];
+};
+struct alignas(128) StreamCtl {
+    unsigned long long state;  // written by workgroup 0: (launch << 2) | EKF_STREAM_*
+    unsigned long long consumed;  // ... with EXITED: the last command the launch consumed
+    unsigned long long pad0[14];
+    unsigned long long stop;   // written by the host: launch number that shall leave now
+    unsigned long long pad1[15];
+    StreamCmd cmd[EKF_STREAM_RING];
 };
 
 struct EkfDev {
@@ -126,6 +162,9 @@ struct EkfDev {
     int *bar;          // [B][2]: [0] = cross-workgroup exchanges done so far (tags of the records continue from it)
     long long *dbg;    // [32] diagnostics: tick counters of the control lane [0..7] and of the first worker [16..23] (EKF_CHAIN_STAMPS), first bad index [8..11] (EKF_CHAIN_CHECK)
     double *part;      // [B][2][nrec][EKF_REC_DOUBLES]: arg-min records (per workgroup; k_chain<true>: per owner wave), double-buffered by exchange parity
+    StreamCtl *sctl;   // streaming launches (one-filter handles): the host-mapped command ring and state word, device view
+    unsigned long long *sfw;  // [32 granules + 1]: workgroup 0's forward of the current command to the filter's other workgroups (10 values as tagged
+                              // 16-byte granule pairs), [32] = how many workgroups have read a forward so far (all launches)
     ekf_decision *log;
     long long *log_count;
     ekf_stats *stats;

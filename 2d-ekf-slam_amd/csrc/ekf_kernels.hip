@@ -153,6 +153,7 @@ struct ChainLds {
     double hp[4 * 128];
     int hflag, hflag2;  // (hflag2: the second helper wave of a workgroup of at most 64 landmarks)
     int pubflag;        // k_chain<true>: tag of the exchange whose head this workgroup's first owner wave has published (the polling wave starts then)
+    int scmd;           // streaming launches: flags of the command just fetched (EKF_STREAM_END_AFTER, EKF_STREAM_EXIT)
 };
 
 // Header of the Old branch (Update.cpp:181-189): a pure function of the heading the sweep ran with and of the
@@ -463,8 +464,12 @@ struct ChainKArgs {  // k_chain's arguments as they lie in the kernel-argument s
 // instantiations, so results agree with k_chain<false> up to rounding (tests: decisions identical, states within 1e-11 / 1e-12).
 // Measured (round 5, same-box A/B): N = 1024 (16 workgroups of one owner wave) 39.2 k -> 42.3 k steps/s; N = 4096 (32 workgroups of two owner
 // waves) unchanged -- its measurements are paced by the two memory trips beside the streaming pass, not by what happens between them.
-template <bool ONE>
+// STREAM (round 6): the launch may be a streaming one (plan.stream != 0) -- one segment without operations of its own, the
+// operations arrive through the host-mapped command ring, the host mirror is published after every one of them (ekf_device.h,
+// "streaming immediate-mode calls").  A separate instantiation, so that the scripted path's code and registers are untouched.
+template <bool ONE, bool STREAM = false>
 __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, const double *in, const int *cursor, ChainPlan plan, int b_off) {
+
     __shared__ ChainLds L;
     __shared__ double recs[EKF_CHAIN_MAX_OPS * 8];
     // own-row cache, per chunk of 64 local landmarks: [virtual slot][plane: components 00 01 | 10 11][lane][2 doubles] -- K rows (Old,
@@ -516,7 +521,13 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
     typedef __attribute__((address_space(4))) const ChainSeg *SegPtr;
     const SegPtr segs = (SegPtr)((__attribute__((address_space(4))) const char *)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(ChainKArgs, plan) + offsetof(ChainPlan, s));
     const long long last_seq = segs[nseg - 1].seq;
-    if (tid == 0) L.abort = 0, L.hflag = -1, L.hflag2 = -1, L.pubflag = 0;
+    // streaming: the number of the last command consumed (the mirror's seq after it), how many commands this launch has forwarded, and
+    // the other workgroups' read count when the launch began (workgroup 0's control lane)
+    unsigned long long consumed = STREAM ? (unsigned long long)segs[0].seq : 0ull, n_fw = 0, ack_base = 0;
+    const unsigned long long consumed0 = consumed;
+    bool end_after = false;
+    (void)consumed0, (void)n_fw, (void)ack_base, (void)end_after;
+    if (tid == 0) L.abort = 0, L.hflag = -1, L.hflag2 = -1, L.pubflag = 0, L.scmd = 0;
     int fold_no = 0;  // Old measurements whose fold the helper wave shared (wave-uniform, kept by every thread)
     // Launches without a measurement (Propagate, compass, truth samples) have no exchange, hence nothing that keeps the filter's
     // workgroups in step: workgroup 0 could finish the whole launch and write the new robot state, landmark count and counters
@@ -796,7 +807,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
     // doUpdateCompass of the reference's call pattern (slam.cpp:136,146) -- therefore skips the refill (nothing later in the launch
     // could miss it: one segment only).  The scan is a handful of LDS reads, so it is only made for launches that short.
     bool need_cache = true;
-    if (nseg == 1 && nops <= 4) {
+    if (nseg == 1 && nops <= 4 && !(STREAM && plan.stream)) {  // (a streaming launch does not know what will arrive: it fills the cache)
         need_cache = false;
         for (int q = 0; q < nops; q++) need_cache = need_cache || uni((int)recs[q * 8 + 7]) == OP_MEAS;
     }
@@ -911,7 +922,152 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
 
     STAMP(7);  // segment prologue: waits, records, slot kinds, LDS refill / shift, robot state
     int slot = slot0;
-    for (int op = 0; op < nops; op++) {
+    // The host mirror (what an API call reads without a copy): the newest decisions, pose, robot block, counts, counters, then -- behind
+    // a release fence -- the sequence number a host thread may be spinning on.  Workgroup 0's thread 0; a streaming launch calls it after
+    // every operation, every launch at its end.
+    auto publish_mirror = [&](long long seq_) {
+        const RobotState &R = L.rs[cur];
+        EkfMirror *mr = dv.mirror + b;
+        for (int i = 0; i < L.n_dec; i++) mr->last[(L.log_count - L.n_dec + i) % EKF_MIRROR_DECISIONS] = L.dec_buf[i];
+        L.n_dec = 0;
+        for (int i = 0; i < 3; i++) mr->pose[i] = R.pose[i];
+        for (int i = 0; i < 9; i++) mr->Prr[i] = R.Prr[i];
+        mr->n_lm = R.n_lm;
+        mr->stats = L.st;
+        if (dv.status[b] != 0) mr->status = dv.status[b];  // (never a zero: a workgroup whose bounded wait ran out has written the mirror itself, and its
+                                                            //  store to dv.status need not be visible here; k_set_meta clears both)
+        mr->log_count = L.log_count;
+        // everything above is in host memory before the sequence number is: a host thread spinning on seq reads a complete mirror
+        __atomic_thread_fence(__ATOMIC_RELEASE);
+        __hip_atomic_store(&mr->seq, seq_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    };
+    int nops_run = nops;  // (streaming: 1 for every fetched command, whose record lies in recs[0..7])
+    for (int op = 0;; op++) {
+        if (op >= nops_run) {
+            if constexpr (!STREAM) {
+                break;
+            } else {
+                if (!plan.stream || end_after) break;
+                // ---- streaming: the operation just done goes to the host mirror, the next command comes in ------------------------------
+                // (an operation without a barrier of its own -- a truth sample -- must not have its record and flags overwritten under a wave
+                // that has not read them yet)
+                __syncthreads();
+                if (tid == 0 && lead && consumed != consumed0) publish_mirror((long long)consumed);
+                if (!worker) {
+                    const int lane = tid & 63;
+                    const unsigned tag32 = ((unsigned)plan.stream << 16) | (unsigned)((consumed + 1) & 0xffffull);
+                    double val = 0;
+                    if (lead) {
+                        StreamCtl *ctl = dv.sctl;
+                        const StreamCmd *cmd = &ctl->cmd[(consumed + 1) % EKF_STREAM_RING];
+                        const unsigned long long launch = (unsigned long long)(unsigned)plan.stream;
+                        const unsigned ctag = (unsigned)((consumed + 1) & 0xffffffffull);  // the tag every granule of command consumed + 1 carries
+                        int verdict = 0;  // 1: a command, 2: leave
+                        if (lane == 0) {
+                            unsigned long long t0, t1;
+                            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+                            for (;;) {
+                                // (the command first: what the host posted before it asked the launch to stop is consumed before the launch leaves)
+                                const unsigned long long fg = __hip_atomic_load(&cmd->g[16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                const unsigned long long stp = __hip_atomic_load(&ctl->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                if ((unsigned)(fg >> 32) == ctag) {
+                                    verdict = 1;
+                                    break;
+                                }
+                                if (stp == launch) {
+                                    verdict = 2;
+                                    break;
+                                }
+                                asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+                                if (t1 - t0 > EKF_STREAM_IDLE_TICKS) {
+                                    // leaving by itself: say so, then look once more (a PCIe read does not pass the posted write in front of it; the host
+                                    // does the mirror image: command, fence, state) -- a command that is there now is consumed, the exit cancelled
+                                    __hip_atomic_store(&ctl->state, (launch << 2) | EKF_STREAM_EXITING, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                    __atomic_thread_fence(__ATOMIC_SEQ_CST);
+                                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                                    if ((unsigned)(__hip_atomic_load(&cmd->g[16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >> 32) == ctag) {
+                                        __hip_atomic_store(&ctl->state, (launch << 2) | EKF_STREAM_RUNNING, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                        verdict = 1;
+                                    } else {
+                                        verdict = 2;
+                                    }
+                                    break;
+                                }
+                            }
+                            // every other workgroup has read the previous forward (normally long ago): the slot may be overwritten
+                            if (n_fw == 0) ack_base = __hip_atomic_load(dv.sfw + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            long spins = 0;
+                            while (__hip_atomic_load(dv.sfw + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ack_base < n_fw * (unsigned long long)(G - 1)) {
+                                __builtin_amdgcn_s_sleep(1);
+                                if (++spins > (1L << 22)) {  // bounded
+                                    dv.status[b] = EKF_ERR_TIMEOUT, dv.mirror[b].status = EKF_ERR_TIMEOUT, L.abort = 1;
+                                    verdict = 2;
+                                    break;
+                                }
+                            }
+                            n_fw++;
+                        }
+                        verdict = uni(verdict);  // (lane 0 is the first active lane)
+                        unsigned long long fl = 0;
+                        if (verdict == 1) {
+                            // the record and the flags: one granule per lane, each re-read until it carries the command's tag (normally at once)
+                            unsigned long long gq = 0;
+                            long spins = 0;
+                            bool ok = lane > 16;
+                            for (;;) {
+                                if (!ok) {
+                                    gq = __hip_atomic_load(&cmd->g[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                    ok = (unsigned)(gq >> 32) == ctag;
+                                }
+                                if (__all(ok)) break;
+                                if (++spins > (1L << 18)) {  // bounded: a command whose flags arrived is complete within a bus transaction or two
+                                    if (lane == 0) dv.status[b] = EKF_ERR_TIMEOUT, dv.mirror[b].status = EKF_ERR_TIMEOUT, L.abort = 1;
+                                    verdict = 2;
+                                    break;
+                                }
+                            }
+                            if (lane < 16) ((unsigned *)recs)[lane] = (unsigned)gq;  // (little-endian: words 2i, 2i + 1 are record value i)
+                            fl = __shfl(gq, 16) & 0xffffffffull;
+                        }
+                        verdict = uni(verdict);
+                        if (verdict == 1) {
+                            if (lane < 8) val = recs[lane];
+                            else if (lane == 8) val = (double)(long long)fl;
+                        } else if (lane == 8) {
+                            val = (double)EKF_STREAM_EXIT;
+                        }
+                        // the forward: nine values as tagged 16-byte granule pairs (the tag names launch and command: a stale slot never validates)
+                        if (lane < 9) st_sc1_b128(dv.sfw + 2 * lane, (uint4_t){(unsigned)__double2loint(val), tag32, (unsigned)__double2hiint(val), tag32});
+                    } else {
+                        unsigned long long g0 = 0, g1 = 0;
+                        long spins = 0;
+                        bool ok = lane >= 9;
+                        for (;;) {
+                            if (!ok) {
+                                g0 = __hip_atomic_load(dv.sfw + 2 * lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                g1 = __hip_atomic_load(dv.sfw + 2 * lane + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                ok = (unsigned)(g0 >> 32) == tag32 && (unsigned)(g1 >> 32) == tag32;
+                            }
+                            if (__all(ok)) break;
+                            if (++spins > (1L << 21)) {  // bounded (workgroup 0 may sit out its whole idle time first: about a second of polls)
+                                if (lane == 0) dv.status[b] = EKF_ERR_TIMEOUT, dv.mirror[b].status = EKF_ERR_TIMEOUT, L.abort = 1;
+                                break;
+                            }
+                            __builtin_amdgcn_s_sleep(4);
+                        }
+                        val = __longlong_as_double((long long)((g1 << 32) | (g0 & 0xffffffffull)));
+                        if (lane == 0) __hip_atomic_fetch_add(dv.sfw + 32, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    if (lane < 8) recs[lane] = val;
+                    if (lane == 8) L.scmd = (int)val, L.ap_tab[0] = -1;
+                }
+                __syncthreads();
+                if (L.abort || (uni(L.scmd) & EKF_STREAM_EXIT)) break;
+                consumed++;
+                end_after = (uni(L.scmd) & EKF_STREAM_END_AFTER) != 0;
+                op = 0, nops_run = 1;
+            }
+        }
         const double *rec = recs + op * 8;
         const int type = uni((int)rec[7]);  // uniform over the filter's workgroups
         const RobotState &RS = L.rs[cur];
@@ -1593,10 +1749,7 @@ finish:  // (also the way out when a bounded wait ran out: the sticky status say
                 }
             }
             dv.n_lm_flush[(size_t)b * 2 + set] = R.n_lm;  // (read by the set's dense pass)
-            EkfMirror *mr = dv.mirror + b;
-            // (between segments the decisions go to the host-mapped mirror behind the count below: nobody waits for writes over PCIe)
-            if (last_seg)
-                for (int i = 0; i < L.n_dec; i++) mr->last[(L.log_count - L.n_dec + i) % EKF_MIRROR_DECISIONS] = L.dec_buf[i];
+            // (between segments the decisions go to the host-mapped mirror behind the segment's count below: nobody waits for writes over PCIe)
             if (last_seg) {
                 for (int i = 0; i < 3; i++) {
                     x[i] = R.pose[i];
@@ -1604,22 +1757,21 @@ finish:  // (also the way out when a bounded wait ran out: the sticky status say
                 }
                 dv.n_lm[b] = R.n_lm;
                 dv.n_lm_sweep[b] = R.n_sweep;
-                for (int i = 0; i < 3; i++) mr->pose[i] = R.pose[i];
-                for (int i = 0; i < 9; i++) mr->Prr[i] = R.Prr[i];
-                mr->n_lm = R.n_lm;
                 dv.stats[b] = L.st;
-                mr->stats = L.st;
                 dv.log_count[b] = L.log_count;
-                if (dv.status[b] != 0) mr->status = dv.status[b];  // (never a zero: a workgroup whose bounded wait ran out has written the mirror itself, and its
-                                                                    //  store to dv.status need not be visible here; k_set_meta clears both)
-                mr->log_count = L.log_count;
-                // everything above is in host memory before the sequence number is: a host thread spinning on seq reads a complete mirror
-                __atomic_thread_fence(__ATOMIC_RELEASE);
-                __hip_atomic_store(&mr->seq, last_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                publish_mirror((STREAM && plan.stream) ? (long long)consumed : last_seq);
             }
         }
         // (a workgroup can only get here after every workgroup of the filter has read ebase: it took part in each exchange)
         if (lead && epoch > 0) bar[0] = ebase + epoch;
+        if constexpr (STREAM) {
+            if (lead && plan.stream) {  // the launch has left: what it consumed, then the state word (the host relaunches for a command that is still in the ring)
+                StreamCtl *ctl = dv.sctl;
+                __hip_atomic_store(&ctl->consumed, consumed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __atomic_thread_fence(__ATOMIC_RELEASE);
+                __hip_atomic_store(&ctl->state, ((unsigned long long)(unsigned)plan.stream << 2) | EKF_STREAM_EXITED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
     }
     // The register-resident landmark (x, its columns of the robot rows, its 2x2 block) has lived in registers since the launch began:
     // nobody else reads it meanwhile (other workgroups sweep their own landmarks; the dense pass reads slots and tiles; the host reads

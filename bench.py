@@ -279,7 +279,7 @@ def roofline_record(pkg, f, workload, B, N, K, M, window, launches, flush_ms, al
             if tj.get("max_pending") == window and tj.get("overlap", int(f.overlap)) == int(f.overlap) and tj.get("filters_per_gpu", B) == B:
                 if tj.get("kernel_source_sha16") != have:
                     # a counter pass of OTHER kernel sources says nothing about this binary: null, not a stale number
-                    r["traffic_source"] = "profiles/%s: stale (collected on sources %s, this run's are %s), not replayed" % (tname, tj.get("kernel_source_sha16"), have)
+                    r["traffic_source"] = "profiles/%s: stale (sources %s, now %s)" % (tname, tj.get("kernel_source_sha16"), have)
                     continue
                 r["traffic"] = tj.get("hbm_bytes_per_launch")
                 r["traffic_source"] = "replayed from profiles/%s (rocprofv3 --pmc passes of sources %s)" % (tname, have)
@@ -296,10 +296,39 @@ def roofline_record(pkg, f, workload, B, N, K, M, window, launches, flush_ms, al
     return r
 
 
+def chain_record(workload, window, overlap, alone_us, pipeline_us):
+    """The line's `chain` record: what paces the step rate is the measurement chain of Update.cpp:80-194 (sweep -> filter-wide arg-min ->
+    winner's record and P_LL column -> fold + gain), a latency chain the HBM roofline of the dense pass says nothing about.
+    `us_per_measurement`: measured in this run -- `alone` = hipEvents around chain launches of one window with nothing beside them,
+    `in_pipeline` = device time per measurement of the 512-step run (dense passes hidden beside the chain).  The stamp split and the floor
+    (scripts/chain_floor.py: instruction-bound parts + 2 x one measured cross-XCC hand-off) are replayed from profiles/chain_<workload>.json,
+    collected on the stamps build of the same kernel sources; null when stale."""
+    rec = {"reference": "odometry/Update.cpp:80-194", "us_per_measurement": {"alone": alone_us, "in_pipeline": pipeline_us}, "split_us": None,
+           "hop_us": None, "floor_us": None, "floor_us_idle": None, "floor_over_measured": None}
+    path = os.path.join(ROOT, "profiles", "chain_%s.json" % workload)
+    if os.path.exists(path):
+        cj = json.load(open(path))
+        st = cj.get("stamps", {})
+        if cj.get("kernel_source_sha16") != kernel_source_digest():
+            rec["source"] = "profiles/chain_%s.json: stale" % workload
+        elif st.get("max_pending") == window and st.get("overlap") == overlap:
+            w = st["first_worker_us"]
+            rec["split_us"] = {"sweep_argmin_publish": w["sweep_argmin_publish"], "exchange_wait": w["wait_pick"], "gate": w["gate_bookkeeping"],
+                               "record_trip_wait": w["wait_staged_record"], "pll_wait": w["wait_pll_entries"], "fold": w["fold"],
+                               "gain_stores": w["gain_stores_or_robot_block"], "between_and_barriers": w["between_measurements"] + w["end_barrier"] + w["segment_prologue_share"],
+                               "stamped_total": st["first_worker_sum_us"]}
+            rec.update({"hop_us": cj["hop_us"], "floor_us": cj["floor_us"], "floor_us_idle": cj["floor_us_idle"],
+                        "source": "profiles/chain_%s.json" % workload})
+            measured = pipeline_us or alone_us
+            if measured:
+                rec["floor_over_measured"] = cj["floor_us"] / measured
+    return rec
+
+
 def slim_roofline(r):
     """A secondary leg's roofline without the fields the headline's already explains (models, notes): the numbers only."""
-    keep = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "bytes_per_launch", "launches", "avg_launch_us", "measurements_per_launch",
-            "share_of_step_time", "end_to_end_hbm_frac", "fused_pass", "traffic_is_upper_bound", "traffic_without_slot_emit_ratio")
+    keep = ("achieved", "frac", "traffic", "bytes_per_launch", "launches", "avg_launch_us", "measurements_per_launch",
+            "end_to_end_hbm_frac", "fused_pass", "traffic_is_upper_bound", "traffic_without_slot_emit_ratio")  # (bound "hbm", peak and unit as in the headline's record)
     out = {k: r[k] for k in keep if k in r}
     if r.get("mfma"):
         out["mfma_frac"] = r["mfma"].get("frac")
@@ -348,8 +377,7 @@ def host_cpu_record():
         rec["affinity_cpus"] = len(aff)
     except (AttributeError, OSError):
         aff = None
-    rec["pinning"] = {"OMP_PROC_BIND": os.environ.get("OMP_PROC_BIND"), "OMP_PLACES": os.environ.get("OMP_PLACES"), "OMP_NUM_THREADS": os.environ.get("OMP_NUM_THREADS"),
-                      "taskset": "none"}
+    rec["pinning"] = "1 thread, no taskset; OMP_NUM_THREADS=%s" % os.environ.get("OMP_NUM_THREADS")
     return rec
 
 
@@ -406,23 +434,27 @@ def measure(pkg, mc, torch, dist, coll_device, rank, world, dev_id, workload, K,
         f.flush()
         f.sync()
         f.flush_profile_read()
-    alone_launches, alone_ms = 0, 0.0
+    alone_launches, alone_ms, chain_alone_us = 0, 0.0, None
     if flush_profile and alone:
         base = P + W + K + extra
+        chain_alone_ms = 0.0
         for r in range(4):
-            # a whole window, then its pipeline-style pass (buffer to buffer, on the pass's own stream) with the chain kernel
-            # already finished and nothing following
+            # a whole window -- the chain kernel with nothing beside it, hipEvents around its launch -- then its pipeline-style pass
+            # (buffer to buffer, on the pass's own stream) with the chain kernel already finished and nothing following
+            f.timer_start()
             f.script_run(base + r * win_steps, win_steps)
+            chain_alone_ms += f.timer_stop()
             f.sync()
             f.close_window()
             f.sync()
         alone_launches, alone_ms = f.flush_profile_read()
+        chain_alone_us = chain_alone_ms * 1e3 / (4 * win_steps * M) if M else None
     roof = roofline_record(pkg, f, workload, B, N, K, M, window, launches, flush_ms, alone_launches, alone_ms, dev_ms, elapsed)
     rep = mc.consistency_report(gathered, K * M, K)
     overlap = int(f.overlap)
     f.close()
     return {"workload": workload, "N": N, "B": B, "K": K, "W": W, "M": M, "window": window, "overlap": overlap, "elapsed": elapsed, "dev_ms": dev_ms,
-            "prime_steps": P, "phases_us": phases, "value": B * world * K / elapsed, "roofline": roof, "latency": lat, "report": rep, "seed": seed, "extent": extent, "min_sep": min_sep}
+            "prime_steps": P, "phases_us": phases, "chain_alone_us": chain_alone_us, "value": B * world * K / elapsed, "roofline": roof, "latency": lat, "report": rep, "seed": seed, "extent": extent, "min_sep": min_sep}
 
 
 def immediate_leg(pkg, dev_id):
@@ -471,8 +503,7 @@ def propagate_only_leg(pkg, dev_id, K=2048, W=64):
     from a bandwidth question this is.  The pose after K steps is checked against the motion model of Propagate.cpp:33-38."""
     import math
     import numpy as np
-    out = {"unit": "us per step (1 Propagate, no measurement)", "reference": "odometry/Propagate.cpp:15-75", "bound": "latency",
-           "byte_model": "72 n - 72 bytes per step (SURVEY.md 8d)"}
+    out = {"unit": "us per step (1 Propagate, no measurement)", "reference": "Propagate.cpp:15-75", "bound": "latency"}  # (72 n - 72 bytes per step, SURVEY.md 8d)
     for name in ("n4096", "n1024"):
         N, _, _, _, seed, extent, _ = WORKLOADS[name]
         x0, P0 = pkg.scenarios.injected_state(N, seed=seed, extent=extent)
@@ -498,11 +529,9 @@ def propagate_only_leg(pkg, dev_id, K=2048, W=64):
         n = 3 + 2 * N
         nbytes = 72 * n - 72
         us = el / K * 1e6
-        out[name] = {"N": N, "steps": K, "warmup": W, "us_per_step": us, "device_us_per_step": dev_ms / K * 1e3, "steps_per_s": K / el,
-                     "overlap": int(f.overlap), "algorithmic_bytes_per_step": nbytes, "achieved_GBs": nbytes / (us * 1e-6) / 1e9,
-                     "frac_of_hbm_peak": nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                     "pose_max_abs_err_vs_motion_model": float(np.abs(pose - want).max())}
-        assert out[name]["pose_max_abs_err_vs_motion_model"] < 1e-9, out[name]
+        out[name] = {"steps": K, "us_per_step": us, "device_us_per_step": dev_ms / K * 1e3, "algorithmic_bytes_per_step": nbytes,
+                     "frac_of_hbm_peak": nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "pose_err_vs_motion_model": float(np.abs(pose - want).max())}
+        assert out[name]["pose_err_vs_motion_model"] < 1e-9, out[name]
         f.close()
     return out
 
@@ -562,8 +591,8 @@ def config1_leg(pkg, dev_id):
                              "sample": "all 1000 steps, faithful-dense oracle, %.2f s" % cpu_t},
             "decisions_identical": bool(same), "max_rel_err_x": float(np.abs(xg - x).max() / max(1.0, np.abs(x).max())),
             "max_err_P_over_maxP": float(np.abs(Pg - P).max() / scale),
-            "state_digest": {"oracle": pkg.scenarios.state_digest(x, P), "gpu": pkg.scenarios.state_digest(xg, Pg),
-                             "of": "sha256 over x and P rounded to 9 significant digits"}}
+            "state_digest": {"oracle": pkg.scenarios.state_digest(x, P)[:16], "gpu": pkg.scenarios.state_digest(xg, Pg)[:16],
+                             "of": "sha256[:16] over x, P at 9 significant digits"}}
 
 
 def secondary_in_a_child(args, dev_id):
@@ -762,7 +791,8 @@ def main():
         def summarise(r, unit="steps/s"):
             out = {"workload": "%s B=%d N=%d M=%d window=%d overlap=%d steps=%d warmup=%d prime=%d" % (r["workload"], r["B"], r["N"], r["M"], r["window"], r["overlap"], r["K"], r["W"], r["prime_steps"]),
                    "value": r["value"], "unit": unit, "ms_per_step": r["elapsed"] / r["K"] * 1e3, "device_ms_per_step": r["dev_ms"] / r["K"],
-                   "per_update_us": r["elapsed"] / (r["K"] * r["M"]) * 1e6, "host_minus_device_us": r["phases_us"]["host_minus_device"],
+                   "per_update_us": r["elapsed"] / (r["K"] * r["M"]) * 1e6, "device_us_per_measurement": r["dev_ms"] * 1e3 / (r["K"] * r["M"]),
+                   "host_minus_device_us": r["phases_us"]["host_minus_device"],
                    "roofline": r["roofline"] if VERBOSE else slim_roofline(r["roofline"])}
             if r["latency"]:
                 out["per_step_latency"] = r["latency"]
@@ -795,6 +825,12 @@ def main():
     if world == 1 and not args.no_secondary and args.workload == "n4096":
         secondary = secondary_in_a_child(args, dev_id)
 
+    chain = None
+    if B == 1:
+        pipe = None
+        if secondary and isinstance(secondary.get("config3_512_steps"), dict) and args.workload == "n4096":
+            pipe = secondary["config3_512_steps"].get("device_us_per_measurement")
+        chain = chain_record(args.workload, head["window"], head["overlap"], head["chain_alone_us"], pipe)
     rep = head["report"]
     # the steady workload feeds 0.5-sigma measurement noise and a noise-free truth (margins
     # for the gate), so NIS/NEES below their dof are expected here; the chi-square verdict is for config 1 style runs
@@ -822,6 +858,7 @@ def main():
         "max_pending": window,
         "window_is_library_default": window == 16,  # (ekf_default_params: 16; secondary.config3_512_steps_w16 is the default-window figure)
         "roofline": head["roofline"],
+        "chain": chain,
         "cpu_baseline": cpu,
         "cpu_baseline_structured": cpu_strong,
         "per_update_us": elapsed / (K * M) * 1e6,

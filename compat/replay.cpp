@@ -188,6 +188,9 @@ int main(int argc, char **argv) {
             std::vector<double> s(step_us.begin() + std::min<size_t>(step_us.size() / 5, 10), step_us.end());  // skip the warm-up iterations
             std::sort(s.begin(), s.end());
             std::printf("timing iterations %zu median_us %.1f p90_us %.1f max_us %.1f\n", s.size(), s[s.size() / 2], s[(s.size() * 9) / 10], s.back());
+            long long starts = 0, ops = 0;  // (how the calls travelled: streaming launches started, operations posted to them; 0 0 = one launch per call)
+            const int streams = ekf_debug_stream(ekf->handle(), &starts, &ops);
+            std::printf("streaming %d launches %lld operations %lld\n", streams, starts, ops);
         }
         if (state_out) {
             int n = ekf_get_state(ekf->handle(), 0, nullptr, nullptr, 0);

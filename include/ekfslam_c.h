@@ -213,6 +213,9 @@ size_t ekf_device_bytes(ekf_handle h);
 /* Diagnostic: dense-pass windows closed since create (kept across ekf_reserve) and the slot count of the last one -- how a
  * scripted run was cut into windows (tests/test_gpu_parity.py: balanced tail, odd windows). */
 int ekf_debug_windows(ekf_handle h, long long *closed_out, int *last_slots_out);
+/* Diagnostic: streaming launches started and operations posted to them since create; returns 1 when the handle streams its
+ * immediate-mode calls (one filter of more than 256 landmarks; EKF_STREAM=0 switches it off), 0 when every call is a launch. */
+int ekf_debug_stream(ekf_handle h, long long *starts_out, long long *ops_out);
 
 /* ---- Tunables -----------------------------------------------------------------------------------
  * Environment variables read once per handle at ekf_create / ekf_batch_create by the PRODUCT library.  They change scheduling
@@ -225,6 +228,9 @@ int ekf_debug_windows(ekf_handle h, long long *closed_out, int *last_slots_out);
  *   EKF_CHAIN_HELPERS=0/1  forbid / force the two helper waves of a one-owner-wave chain workgroup
  *   EKF_CHAIN_WGS, EKF_CHAIN_CUS   chain workgroups per filter / CUs kept for them beside an overlapped pass
  *   EKF_INLINE_REC=0       immediate-mode records travel through the host-mapped ring instead of the kernel arguments
+ *   EKF_STREAM=0           immediate-mode calls of a one-filter handle are one launch each (default: a resident launch consumes them
+ *                          from a host-mapped command ring and publishes the host mirror after every operation; it leaves when the
+ *                          window is full, when another entry point needs the stream, or after 100 us without a call)
  *   EKF_XCD_MAP=0, EKF_BATCH_INTERLEAVE=0, EKF_FLUSH_ALTERNATE=0   dense-pass tile order experiments
  *   EKF_SOLO=0, EKF_SOLO_FUSE=0, EKF_SOLO_LONG_WINDOW=0, EKF_SOLO_GROUPS=n   one-workgroup filters: general kernel / separate pass launches / short window / phase groups
  *   EKF_INKERNEL_WAIT=0    chain launches wait for their pass by stream event instead of in-kernel

@@ -1125,7 +1125,7 @@ def test_random_operation_sequences_vs_oracle(pkg, oc, monkeypatch, seed):
         elif r < 0.28:
             f.close_window()
         elif r < 0.4:
-            assert np.allclose(f.poses()[0], x[:3], rtol=1e-9, atol=1e-12) and int(f.num_landmarks()[0]) == (x.size - 3) // 2
+            assert np.allclose(f.poses()[0], x[:3], rtol=1e-9, atol=1e-12) and int(f.num_landmarks()[0]) == (x.size - 3) // 2, (seed, step, n_z)
     xg, Pg = f.get_state()
     assert_state_close(xg, Pg, x, P, "seed %d final" % seed)
     assert_bitwise_symmetric(Pg)

@@ -1,0 +1,180 @@
+"""Streaming immediate-mode calls (round 6; csrc/ekf_device.h "streaming immediate-mode calls", k_chain<true, true>): a one-filter handle of
+more than 256 landmarks runs its per-call operations -- the reference's own call pattern, slam.cpp:136-170 -- through ONE resident launch
+that consumes commands from a host-mapped ring, instead of one launch per call.  Same operations in the same order: decisions must be
+identical and states equal up to the rounding of another template instantiation (as between k_chain<true> and k_chain<false>), against
+EKF_STREAM=0 and against the oracle; the launch must leave and come back cleanly (idle time-out, full windows, every entry point that
+needs the stream), and a command posted while the launch is leaving by itself must not be lost."""
+import ctypes
+import time
+
+import numpy as np
+import pytest
+
+from helpers import assert_bitwise_symmetric, assert_state_close
+
+pytestmark = pytest.mark.gpu
+
+
+def stream_counts(f):
+    f.L.ekf_debug_stream.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_longlong)]
+    a, b = ctypes.c_longlong(), ctypes.c_longlong()
+    on = f.L.ekf_debug_stream(f.h, ctypes.byref(a), ctypes.byref(b))
+    return on, a.value, b.value
+
+
+def drive(pkg, N, steps, M, max_pending, seed, gaps=None, compass=True, reads=False, x0P0=None):
+    """`steps` steps of propagate + M single-measurement updates (+ compass, + truth) as immediate calls; gaps: seconds slept before some calls."""
+    rng = np.random.default_rng(seed)
+    x0, P0 = x0P0 if x0P0 is not None else pkg.scenarios.injected_state(N, seed=seed, extent=50.0 * (N / 4096.0) ** 0.5)
+    sc = pkg.scenarios.steady_script(x0, steps=steps, M=M, seed=seed + 1, min_separation=1.0)
+    f = pkg.FilterBatch(1, N, max_pending=max_pending, log_capacity=4096)
+    f.set_state(x0, P0)
+    decs, poses = [], []
+    for s in range(steps):
+        v, w, dt = sc["ctrl"][s]
+        if gaps is not None and rng.random() < 0.5:
+            time.sleep(float(rng.choice(gaps)))
+        f.propagate(v, w, dt)
+        poses.append(f.poses()[0].copy())
+        for m in range(M):
+            if gaps is not None and rng.random() < 0.3:
+                time.sleep(float(rng.choice(gaps)))
+            d = f.update(sc["z"][s, m].reshape(1, 1, 2), sc["R"][s, m].reshape(2, 2, order="F").reshape(1, 1, 2, 2))
+            decs.append((d[0][0][0], d[0][0][1]))
+        if compass and s % 3 == 1:
+            f.update_compass(float(sc["truth"][s, 2]) % 6.283185307, 0.0005)
+        f.record_truth(sc["truth"][s])
+        if reads and s % 5 == 4:
+            f.get_state()  # (a synchronising read in the middle of a window: the launch leaves, the next call starts another)
+    on, starts, ops = stream_counts(f)
+    x, P = f.get_state()
+    st = f.stats()[0]
+    f.close()
+    return dict(decs=decs, poses=np.array(poses), x=x, P=P, stats=st, on=on, starts=starts, ops=ops, x0=x0, P0=P0, sc=sc)
+
+
+@pytest.mark.parametrize("N,max_pending,steps", [(1024, 16, 14), (4096, 16, 10), (4096, 32, 18), (600, 7, 9)])
+def test_streamed_calls_equal_one_launch_per_call(pkg, monkeypatch, pipeline_mode, N, max_pending, steps):
+    outs = {}
+    init = None
+    for stream in ("0", "1"):
+        monkeypatch.setenv("EKF_STREAM", stream)
+        outs[stream] = drive(pkg, N, steps, 4, max_pending, seed=500 + N, x0P0=init)
+        init = (outs[stream]["x0"], outs[stream]["P0"])
+    a, b = outs["0"], outs["1"]
+    assert a["on"] == 0 and a["ops"] == 0 and b["on"] == 1 and b["ops"] > 5 * steps and 1 <= b["starts"] <= b["ops"]
+    assert a["decs"] == b["decs"] and all(d[0] == pkg.ekfslam.OLD for d in b["decs"])
+    assert np.abs(a["poses"] - b["poses"]).max() <= 1e-11
+    assert np.abs(a["x"] - b["x"]).max() <= 1e-11 * max(1.0, np.abs(a["x"]).max()) and np.abs(a["P"] - b["P"]).max() <= 1e-12 * np.abs(a["P"]).max()
+    assert_bitwise_symmetric(b["P"])
+    for k in ("nis_count", "nees_count", "n_new", "n_old", "n_ignore"):
+        assert a["stats"][k] == b["stats"][k]
+    assert abs(a["stats"]["nis_sum"] - b["stats"]["nis_sum"]) <= 1e-9 * max(1.0, abs(a["stats"]["nis_sum"]))
+
+
+def test_streamed_calls_against_the_oracle(pkg, oc, pipeline_mode):
+    """N = 1024, window 16, 12 steps of 4 measurements + compass as immediate calls through the streaming launch, against the oracle."""
+    r = drive(pkg, 1024, 12, 4, 16, seed=77, compass=True)
+    assert r["on"] == 1 and r["starts"] >= 1
+    x, P = r["x0"], r["P0"]
+    sc = r["sc"]
+    decs = []
+    for s in range(12):
+        v, w, dt = sc["ctrl"][s]
+        x, P = oc.propagate(x, P, v, w, oc.make_Q(v), dt)
+        for m in range(4):
+            x, P, dec, mat, _ = oc.update(x, P, sc["z"][s, m].reshape(2, 1), sc["R"][s, m].reshape(2, 2, order="F"))
+            decs.append((dec[0], mat[0]))
+        if s % 3 == 1:
+            x, P = oc.compass(x, P, float(sc["truth"][s, 2]) % 6.283185307, 0.0005)
+    assert r["decs"] == decs
+    assert_state_close(r["x"], r["P"], x, P, "streamed calls, N = 1024")
+    assert_bitwise_symmetric(r["P"])
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_the_launch_leaves_by_itself_and_comes_back_without_losing_a_command(pkg, monkeypatch, pipeline_mode, seed):
+    """Pauses of 0 ... 400 us between calls, around the launch's idle time (100 us): it leaves by itself again and again, sometimes while
+    the next command is being posted (the state word / command slot handshake), and synchronising reads in the middle of windows make
+    it leave on request.  Results as with one launch per call."""
+    gaps = [0.0, 20e-6, 60e-6, 90e-6, 100e-6, 110e-6, 130e-6, 200e-6, 400e-6]
+    outs = {}
+    init = None
+    for stream in ("0", "1"):
+        monkeypatch.setenv("EKF_STREAM", stream)
+        outs[stream] = drive(pkg, 1024, 30, 3, 8, seed=900 + seed, gaps=gaps if stream == "1" else None, reads=True, x0P0=init)
+        init = (outs[stream]["x0"], outs[stream]["P0"])
+    a, b = outs["0"], outs["1"]
+    assert b["on"] == 1 and b["starts"] > 6, b["starts"]  # (idle exits and the reads' stops)
+    assert a["decs"] == b["decs"]
+    assert np.abs(a["poses"] - b["poses"]).max() <= 1e-11
+    assert np.abs(a["x"] - b["x"]).max() <= 1e-11 * max(1.0, np.abs(a["x"]).max()) and np.abs(a["P"] - b["P"]).max() <= 1e-12 * np.abs(a["P"]).max()
+
+
+def test_streaming_and_scripted_runs_share_a_handle(pkg, oc, pipeline_mode):
+    """Immediate calls (streamed), a scripted run, immediate calls again, flush, reserve, more calls: every hand-over stops the resident
+    launch first; the whole sequence against the oracle."""
+    N, M = 640, 4
+    x0, P0 = pkg.scenarios.injected_state(N, seed=41, extent=20.0)
+    sc = pkg.scenarios.steady_script(x0, steps=16, M=M, seed=42, min_separation=1.0)
+    f = pkg.FilterBatch(1, N, max_pending=8, log_capacity=4096)
+    f.set_state(x0, P0)
+    f.script_load(sc["ctrl"][:, None, :], sc["z"][:, :, None, :], sc["R"][:, :, None, :])
+
+    def immediate(s):
+        v, w, dt = sc["ctrl"][s]
+        f.propagate(v, w, dt)
+        for m in range(M):
+            f.update(sc["z"][s, m].reshape(1, 1, 2), sc["R"][s, m].reshape(2, 2, order="F").reshape(1, 1, 2, 2))
+
+    for s in range(0, 3):
+        immediate(s)
+    f.script_run(3, 5)
+    for s in range(8, 10):
+        immediate(s)
+    f.flush()
+    immediate(10)
+    f.reserve(N + 300)
+    for s in range(11, 14):
+        immediate(s)
+    f.script_run(14, 2)
+    f.sync()
+    on, starts, ops = stream_counts(f)
+    assert on == 1 and starts >= 1  # (the reserve gave the handle new buffers and counters: what is counted is the part after it)
+    xg, Pg = f.get_state()
+    dg = f.decisions(0, 16 * M)
+    f.close()
+    x, P, decs = x0, P0, []
+    for s in range(16):
+        v, w, dt = sc["ctrl"][s]
+        x, P = oc.propagate(x, P, v, w, oc.make_Q(v), dt)
+        for m in range(M):
+            x, P, dec, mat, _ = oc.update(x, P, sc["z"][s, m].reshape(2, 1), sc["R"][s, m].reshape(2, 2, order="F"))
+            decs.append((dec[0], mat[0]))
+    assert [(d[0], d[1]) for d in dg] == decs
+    assert_state_close(xg, Pg, x, P, "streamed + scripted")
+    assert_bitwise_symmetric(Pg)
+
+
+def test_a_chunk_of_several_measurements_streams_in_order(pkg, oc, pipeline_mode):
+    """ekf_update with n_z = 5 posts five commands without waiting in between (the stale landmark count of Update.cpp:26 travels in the
+    record); a chunk that crosses the end of a window makes the launch leave after the closing measurement and a new one take over."""
+    N = 900
+    x0, P0 = pkg.scenarios.injected_state(N, seed=61, extent=24.0)
+    sc = pkg.scenarios.steady_script(x0, steps=6, M=5, seed=62, min_separation=1.0)
+    f = pkg.FilterBatch(1, N, max_pending=8, log_capacity=4096)
+    f.set_state(x0, P0)
+    x, P = x0, P0
+    for s in range(6):
+        v, w, dt = sc["ctrl"][s]
+        f.propagate(v, w, dt)
+        x, P = oc.propagate(x, P, v, w, oc.make_Q(v), dt)
+        z = sc["z"][s].reshape(1, 5, 2)
+        R = np.stack([sc["R"][s, m].reshape(2, 2, order="F") for m in range(5)]).reshape(1, 5, 2, 2)
+        got = f.update(z, R)[0]
+        Rc = np.concatenate([R[0, m] for m in range(5)], axis=1)
+        x, P, dec, mat, _ = oc.update(x, P, z[0].T.copy(), Rc)
+        assert [(g[0], g[1]) for g in got] == list(zip(dec, mat))
+    xg, Pg = f.get_state()
+    f.close()
+    assert_state_close(xg, Pg, x, P, "streamed chunks")
