@@ -115,6 +115,8 @@ struct ekf_batch {
     bool dbg_skip_flush = false;        // EKF_DEBUG_SKIP_FLUSH=1: timing experiments only, results are wrong
     int dbg_drop_marks_from = 0;        // EKF_DEBUG_DROP_MARKS_FROM=k (and ..._TO=m, exclusive): dense passes k .. m-1 never report completion (tests of the bounded waits)
     int dbg_drop_marks_to = 0x7fffffff;
+    long dbg_stream_idle_ticks = 0;     // EKF_DEBUG_STREAM_IDLE_TICKS=t: a streaming launch leaves by itself after t ticks of the 100 MHz clock without a command (default 10 000)
+    bool dbg_stream_no_recheck = false; // EKF_DEBUG_STREAM_NO_RECHECK=1: ... and WITHOUT looking at the command slot once more: commands get lost on purpose (tests of the host's safety net)
     // streaming immediate-mode calls (one-filter handles run by k_chain<true>; EKF_STREAM=0 switches them off): a resident launch consumes
     // the calls' operations from a host-mapped command ring (ekf_device.h: StreamCtl)
     StreamCtl *sctl_h = nullptr;  // host view of dv.sctl
@@ -122,6 +124,8 @@ struct ekf_batch {
     bool stream_alive = false;    // a streaming launch has been started and not been told (or seen) to leave
     int stream_launch = 0;        // number of the newest streaming launch (ChainPlan::stream)
     long long stream_starts = 0, stream_ops = 0;  // (diagnostics: ekf_debug_stream)
+    long long stream_last_seq = 0;  // sequence number of the newest streamed command
+    int stream_slot_before[EKF_STREAM_RING] = {};  // slots of the open window filled BEFORE streamed command seq (index seq % ring): where a replacement launch resumes
     // immediate-mode input ring (host-mapped pinned)
     double *ring_h;
     double *ring_d;
@@ -277,6 +281,8 @@ static void read_debug_hooks(ekf_batch *h) {
     h->dbg_skip_flush = getenv("EKF_DEBUG_SKIP_FLUSH") && atoi(getenv("EKF_DEBUG_SKIP_FLUSH")) != 0;
     h->dbg_drop_marks_from = getenv("EKF_DEBUG_DROP_MARKS_FROM") ? atoi(getenv("EKF_DEBUG_DROP_MARKS_FROM")) : 0;
     h->dbg_drop_marks_to = getenv("EKF_DEBUG_DROP_MARKS_TO") ? atoi(getenv("EKF_DEBUG_DROP_MARKS_TO")) : 0x7fffffff;
+    h->dbg_stream_idle_ticks = getenv("EKF_DEBUG_STREAM_IDLE_TICKS") ? atol(getenv("EKF_DEBUG_STREAM_IDLE_TICKS")) : 0;
+    h->dbg_stream_no_recheck = getenv("EKF_DEBUG_STREAM_NO_RECHECK") && atoi(getenv("EKF_DEBUG_STREAM_NO_RECHECK")) != 0;
 #else
     (void)h;
 #endif
@@ -844,45 +850,21 @@ static size_t prof_pairs_for_script(const ekf_batch *h) {
     return (slots / half + 8) * (size_t)(h->ngroups > 1 ? h->ngroups : 1);
 }
 
-// ---- streaming immediate-mode calls (ekf_device.h: StreamCtl; k_chain<true, true>) -------------------------------------------------
-// The resident launch is told to leave and waited for (its epilogue writes the state back that later launches and copies read).  Every
-// entry point that enqueues on the chain stream, reads device memory or hands the stream out comes through here first; the
-// immediate-mode operations themselves and the mirror's readers (pose, landmark count, robot block, newest decisions, counters) do not.
-static int stream_stop(ekf_batch *h) {
-    if (!h->stream_alive) return EKF_OK;
-    h->stream_alive = false;
-    StreamCtl *c = h->sctl_h;
-    const unsigned long long launch = (unsigned long long)(unsigned)h->stream_launch;
-    // what has been posted is consumed first: the launch looks at the command slot before it looks at the stop word, but the two reads
-    // may be served in either order -- a stop seen without the command posted in front of it would leave that command behind
-    timespec t0, t1;
-    clock_gettime(CLOCK_MONOTONIC, &t0);
-    for (long spin = 0;; spin++) {
-        if (__atomic_load_n(&h->mirror_h[0].seq, __ATOMIC_ACQUIRE) >= h->chain_seq) break;
-        if (__atomic_load_n(&c->state, __ATOMIC_ACQUIRE) == ((launch << 2) | EKF_STREAM_EXITED)) break;  // (left by itself, or gave up: the status says)
-        if ((spin & 255) == 255) {
-            clock_gettime(CLOCK_MONOTONIC, &t1);
-            if ((t1.tv_sec - t0.tv_sec) * 1000000000L + (t1.tv_nsec - t0.tv_nsec) > 2000000000L) break;  // (2 s: the stream wait below reports what is wrong)
-        }
-        __builtin_ia32_pause();
-    }
-    __atomic_store_n(&c->stop, launch, __ATOMIC_SEQ_CST);
-    HIP_TRY(stream_wait(h->s_chain));
-    // a command the launch left behind (it went by itself while the command was on its way, and nobody has relaunched since: only
-    // stream_op posts, and it resolves that before it returns) cannot exist here
-    return EKF_OK;
-}
-
-// Start a streaming launch on the open window: one segment without operations, consuming commands from h->chain_seq + 1 on.
-static int stream_start(ekf_batch *h) {
+// ---- streaming immediate-mode calls (ekf_device.h: StreamCtl; k_chain<ONE, true>) -------------------------------------------------
+// Start a streaming launch on the open window: one segment without operations, consuming commands from consumed0 + 1 on.
+static int stream_start(ekf_batch *h, long long consumed0, int slot0) {
     ChainPlan plan;
     memset(&plan, 0, sizeof plan);
     ChainSeg &sg = plan.s[0];
-    sg.k0 = 0, sg.nops = 0, sg.slot0 = h->pending, sg.set = h->cur_set, sg.buf_read = h->buf_in, sg.n_prev = h->prev_pending;
+    sg.k0 = 0, sg.nops = 0, sg.slot0 = slot0, sg.set = h->cur_set, sg.buf_read = h->buf_in, sg.n_prev = h->prev_pending;
     sg.need_pass = h->need_pass, sg.drop = 0;
-    sg.seq = h->chain_seq;  // the last command consumed before this launch
+    sg.seq = consumed0;  // the last command consumed before this launch
     sg.gate = 0, sg.self_pass = 0, sg.stagger = 0;
     plan.nseg = 1, plan.signal = 0, plan.inl_n = 0;
+    if (h->dbg_stream_idle_ticks > 0 || h->dbg_stream_no_recheck) {  // (debug library only: a streaming launch has no inline record, the fields carry the test hooks)
+        plan.inl_n = 1 | (h->dbg_stream_no_recheck ? 2 : 0);
+        plan.inl[0] = h->dbg_stream_idle_ticks > 0 ? (double)h->dbg_stream_idle_ticks : (double)EKF_STREAM_IDLE_TICKS;
+    }
     h->stream_launch = h->stream_launch >= 0xffff ? 1 : h->stream_launch + 1;  // (16 bits of it tag the forwards)
     plan.stream = h->stream_launch;
     __atomic_store_n(&h->sctl_h->state, ((unsigned long long)(unsigned)plan.stream << 2) | EKF_STREAM_RUNNING, __ATOMIC_SEQ_CST);
@@ -898,6 +880,50 @@ static int stream_start(ekf_batch *h) {
     return check_launch();
 }
 
+// Wait until the streamed command `seq` has been executed (the mirror's sequence number reaches it).  This is also the safety net under
+// the leave-by-itself handshake: a launch that has LEFT without consuming what was posted (state EXITED, consumed < seq) is replaced by a
+// new one that starts behind what the old one did consume -- the commands are still in the ring -- so that no posted command can be lost
+// whatever the order in which the two sides' accesses to host memory were served.  Bounded.
+static int stream_wait_consumed(ekf_batch *h, long long seq) {
+    StreamCtl *c = h->sctl_h;
+    timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    int relaunches = 0;
+    for (long spin = 0;; spin++) {
+        if (__atomic_load_n(&h->mirror_h[0].seq, __ATOMIC_ACQUIRE) >= seq) return EKF_OK;
+        const unsigned long long launch = (unsigned long long)(unsigned)h->stream_launch;
+        if (__atomic_load_n(&c->state, __ATOMIC_ACQUIRE) == ((launch << 2) | EKF_STREAM_EXITED)) {
+            const long long consumed = (long long)__atomic_load_n(&c->consumed, __ATOMIC_ACQUIRE);
+            if (__atomic_load_n(&h->mirror_h[0].seq, __ATOMIC_ACQUIRE) >= seq) return EKF_OK;
+            if (h->mirror_h[0].status == EKF_ERR_TIMEOUT) return sticky_status(h, false);  // the launch gave up: the state is invalid, say so
+            if (consumed >= seq || ++relaunches > 4) return set_error(EKF_ERR_STATE, "a streaming launch left without publishing what it consumed");
+            // (queued behind the old launch; it resumes at the slot the first unconsumed command was posted at -- the window has not changed:
+            // a window only closes behind a command that is known to have been executed)
+            int rc = stream_start(h, consumed, h->stream_slot_before[(unsigned long long)(consumed + 1) % EKF_STREAM_RING]);
+            if (rc) return rc;
+        }
+        if ((spin & 255) == 255) {
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            if ((t1.tv_sec - t0.tv_sec) * 1000000000L + (t1.tv_nsec - t0.tv_nsec) > 4000000000L) return set_error(EKF_ERR_TIMEOUT, "a streamed command was not executed within 4 s");
+        }
+        __builtin_ia32_pause();
+    }
+}
+
+// The resident launch is told to leave and waited for (its epilogue writes the state back that later launches and copies read).  Every
+// entry point that enqueues on the chain stream, reads device memory or hands the stream out comes through here first; the
+// immediate-mode operations themselves and the mirror's readers (pose, landmark count, robot block, newest decisions, counters) do not.
+static int stream_stop(ekf_batch *h) {
+    if (!h->stream_alive) return EKF_OK;
+    // what has been posted is executed first (the launch looks at the command slot before it looks at the stop word, but two reads of
+    // host memory may be served in either order: a stop seen without the command posted in front of it would leave that command behind)
+    int rc = stream_wait_consumed(h, h->stream_last_seq);
+    h->stream_alive = false;
+    __atomic_store_n(&h->sctl_h->stop, (unsigned long long)(unsigned)h->stream_launch, __ATOMIC_SEQ_CST);
+    HIP_TRY(stream_wait(h->s_chain));
+    return rc;
+}
+
 static int close_set(ekf_batch *h, bool terminal, EnqueueList *defer);
 
 // One immediate-mode operation through the streaming launch: post the command, make sure somebody consumes it, keep the host's
@@ -907,18 +933,11 @@ static int stream_op(ekf_batch *h, const double *rec, bool consumes) {
     const bool closes = consumes && h->pending + 1 >= h->dv.maxp;
     const long long seq = ++h->chain_seq;
     StreamCmd *cmd = &c->cmd[(unsigned long long)seq % EKF_STREAM_RING];
-    if (seq > EKF_STREAM_RING) {  // the slot's previous command (seq - ring) must have been consumed: a caller that posts without ever reading
-        timespec t0, t1;
-        clock_gettime(CLOCK_MONOTONIC, &t0);
-        for (long spin = 0; __atomic_load_n(&h->mirror_h[0].seq, __ATOMIC_ACQUIRE) < seq - EKF_STREAM_RING; spin++) {
-            if ((spin & 255) == 255) {
-                clock_gettime(CLOCK_MONOTONIC, &t1);
-                if ((t1.tv_sec - t0.tv_sec) * 1000000000L + (t1.tv_nsec - t0.tv_nsec) > 1000000000L) {
-                    h->chain_seq--;
-                    return set_error(EKF_ERR_TIMEOUT, "the streaming launch does not consume its commands");
-                }
-            }
-            __builtin_ia32_pause();
+    if (h->stream_alive && seq - EKF_STREAM_RING > 0) {  // the slot's previous command (seq - ring) must have been executed: a caller that posts without ever reading
+        int rc = stream_wait_consumed(h, seq - EKF_STREAM_RING);
+        if (rc) {
+            h->chain_seq--;
+            return rc;
         }
     }
     {
@@ -934,46 +953,32 @@ static int stream_op(ekf_batch *h, const double *rec, bool consumes) {
         __atomic_store_n(&cmd->g[16], (unsigned long long)(closes ? EKF_STREAM_END_AFTER : 0) | tg, __ATOMIC_RELEASE);
     }
     h->stream_ops++;
-    for (int attempt = 0;; attempt++) {
-        if (!h->stream_alive) {
-            // (nothing of an earlier launch is pending in the ring: commands are consumed in order and this one is the newest)
-            h->chain_seq = seq - 1;  // stream_start reads "the last command consumed before the launch" here
-            int rc = stream_start(h);
-            h->chain_seq = seq;
-            if (rc) return rc;
-            break;
-        }
-        // "write mine, fence, read yours": the launch does the same with its state word and this command slot before it leaves by itself
+    h->stream_last_seq = seq;
+    h->stream_slot_before[(unsigned long long)seq % EKF_STREAM_RING] = h->pending;
+    if (!h->stream_alive) {
+        // (every earlier streamed command has been executed: a launch is only written off behind stream_wait_consumed -- stream_stop, a closing command)
+        int rc = stream_start(h, seq - 1, h->pending);
+        if (rc) return rc;
+    } else {
+        // "write mine, fence, read yours": the launch does the same with its state word and this command slot before it leaves by itself, so
+        // normally one of the two sees the other.  RUNNING: the launch will find the command.  Anything else: wait for the outcome (the
+        // operation done, or the launch gone without it and replaced).
         __atomic_thread_fence(__ATOMIC_SEQ_CST);
         const unsigned long long launch = (unsigned long long)(unsigned)h->stream_launch;
-        unsigned long long st = __atomic_load_n(&c->state, __ATOMIC_ACQUIRE);
-        if (st == ((launch << 2) | EKF_STREAM_RUNNING)) break;
-        // leaving, or gone: the outcome is either the operation done (the launch found the command and stayed) or the launch gone without it
-        bool gone = false;
-        timespec t0, t1;
-        clock_gettime(CLOCK_MONOTONIC, &t0);
-        for (long spin = 0;; spin++) {
-            if (__atomic_load_n(&h->mirror_h[0].seq, __ATOMIC_ACQUIRE) >= seq) break;
-            st = __atomic_load_n(&c->state, __ATOMIC_ACQUIRE);
-            if (st == ((launch << 2) | EKF_STREAM_RUNNING)) break;  // the exit was cancelled: the command is being worked on
-            if (st == ((launch << 2) | EKF_STREAM_EXITED)) {
-                gone = (long long)__atomic_load_n(&c->consumed, __ATOMIC_ACQUIRE) < seq;
-                break;
-            }
-            if ((spin & 255) == 255) {
-                clock_gettime(CLOCK_MONOTONIC, &t1);
-                if ((t1.tv_sec - t0.tv_sec) * 1000000000L + (t1.tv_nsec - t0.tv_nsec) > 1000000000L) return set_error(EKF_ERR_TIMEOUT, "a streaming launch neither stayed nor left");
-            }
-            __builtin_ia32_pause();
+        if (__atomic_load_n(&c->state, __ATOMIC_ACQUIRE) != ((launch << 2) | EKF_STREAM_RUNNING)) {
+            int rc = stream_wait_consumed(h, seq);
+            if (rc) return rc;
         }
-        if (!gone || attempt > 2) break;
-        h->stream_alive = false;  // relaunch for this command
     }
     h->mirror_by_chain = true;
     h->stats_in_mirror = true;
     if (consumes) h->pending++;
     if (closes) {
-        h->stream_alive = false;  // (the launch leaves behind this operation by itself: EKF_STREAM_END_AFTER)
+        // the launch leaves behind this operation by itself (EKF_STREAM_END_AFTER); the window's dense pass is enqueued behind it once the
+        // closing command is known to have been executed (a synchronising caller would wait for it next anyway)
+        int rc = stream_wait_consumed(h, seq);
+        h->stream_alive = false;
+        if (rc) return rc;
         return close_set(h, false, nullptr);
     }
     return EKF_OK;

@@ -979,7 +979,11 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                                     break;
                                 }
                                 asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
-                                if (t1 - t0 > EKF_STREAM_IDLE_TICKS) {
+                                if (t1 - t0 > (plan.inl_n ? (unsigned long long)plan.inl[0] : (unsigned long long)EKF_STREAM_IDLE_TICKS)) {  // (inl_n: the debug library's test hooks)
+                                    if (plan.inl_n & 2) {  // (test hook: leave without the second look -- the host's safety net must pick the command up)
+                                        verdict = 2;
+                                        break;
+                                    }
                                     // leaving by itself: say so, then look once more (a PCIe read does not pass the posted write in front of it; the host
                                     // does the mirror image: command, fence, state) -- a command that is there now is consumed, the exit cancelled
                                     __hip_atomic_store(&ctl->state, (launch << 2) | EKF_STREAM_EXITING, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -348,10 +348,10 @@ class KalmanFilter:
     velocity reads of doPropagation (kalmanfilter.cpp:17-20) become the v_mm_s / rotvel_deg_s arguments."""
 
     def __init__(self, capacity_landmarks=1024, device=0, print_decisions=False, **params):
-        # one synchronising call per operation (the mirrors must be current after each): no dense pass ever runs beside a chain
-        # kernel, so the in-place pipeline is the faster one for this class (compat/kalmanfilter.h does the same); overlap=-1 / 1
-        # can still be asked for
-        params.setdefault("overlap", 0)
+        # one synchronising call per operation (the mirrors must be current after each); the calls travel to a resident streaming
+        # launch, and the window's dense pass runs in place for small maps, beside the next window's calls from 2048 landmarks on
+        # (compat/kalmanfilter.h has the measurements); overlap=-1 / 0 / 1 can still be asked for
+        params.setdefault("overlap", 1 if capacity_landmarks >= 2048 else 0)
         self._f = FilterBatch(1, capacity_landmarks, device, **params)
         self.X = self.Y = self.Phi = 0.0
         self.Num_Landmarks = 0

@@ -232,7 +232,7 @@ def roofline_record(pkg, f, workload, B, N, K, M, window, launches, flush_ms, al
         slots_per_launch = min(float(window), K * M * groups / float(launches))
     flops_per_launch = filters_per_launch * chains * (slots_per_launch / 2.0) * 2048  # one v_mfma_f64_16x16x4_f64 per chain and PAIR of measurements
     r = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
-         "kernel": "k_flush_rb", "byte_model": "scheme C, DESIGN.md 4.2",
+         "kernel": "k_flush_rb", "byte_model": "scheme C, DESIGN.md 4.3",
          "bytes_per_launch": bytes_per_launch, "launches": int(launches), "avg_launch_us": None, "measurements_per_launch": slots_per_launch,
          "mfma": {"achieved": None, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None, "flops_per_launch": flops_per_launch}}
     if VERBOSE:
@@ -241,7 +241,7 @@ def roofline_record(pkg, f, workload, B, N, K, M, window, launches, flush_ms, al
         r["window_note"] = ("window %d: a launch folds up to %d slot pairs into the same bytes that rounds 1-4 folded 8 pairs into (window 16: frac 0.61-0.64, still profiled: "
                             "profiles/r05_n4096_w16_overlap_summary.json) -- half the passes and half the HBM bytes per folded measurement, twice the fp64 MFMA work per byte "
                             "(roofline.mfma): %.1f flop per byte, at the ridge of the fp64 roofline (78.6 TFLOP/s / 8 TB/s = 9.8), so HBM and matrix-pipe fractions are both below their own ceilings; "
-                            "DESIGN.md 4.2 'The 16-pair pass' has the lab measurements of what that mix reaches" % (window, window // 2, flops_per_launch / float(bytes_per_launch)))
+                            "DESIGN.md 4.3 has the lab measurements of what that mix reaches" % (window, window // 2, flops_per_launch / float(bytes_per_launch)))
     if launches:
         avg_s = flush_ms / 1e3 / launches
         r["avg_launch_us"] = avg_s * 1e6
@@ -258,7 +258,7 @@ def roofline_record(pkg, f, workload, B, N, K, M, window, launches, flush_ms, al
             # one-workgroup filters with a long window fold their windows inside the chain kernel (k_solo<true>, ChainSeg::self_pass): there is
             # no dense-pass launch to time.  `launches` counts the passes, the duration is that of the k_solo launches that contain them --
             # measurement loops included -- so this fraction is a LOWER bound of the pass's own (the stamps build separates the two:
-            # DESIGN.md 4.1b); EKF_SOLO_FUSE=0 runs the passes as k_flush_rb launches again.
+            # DESIGN.md 4.2); EKF_SOLO_FUSE=0 runs the passes as k_flush_rb launches again.
             r["kernel"] = "k_solo<true> (loop + own pass; avg_launch_us per window)"
             r["fused_pass"] = True
     if alone_launches:
@@ -410,7 +410,7 @@ def measure(pkg, mc, torch, dist, coll_device, rank, world, dev_id, workload, K,
         # per-step latency: one scripted step per call, host clock from the call to the moment the pose of
         # that step is readable (kernel launch + completion, no state copy); the window's dense pass falls on every fourth step
         # (the interpreter's cyclic garbage collector is off inside the loop and the samples go into a preallocated array: a one-off
-        # pause of 0.65-1.1 ms at a fixed iteration count of this very loop -- whatever the GPU was doing, DESIGN.md section 5 -- was the
+        # pause of 0.65-1.1 ms at a fixed iteration count of this very loop -- whatever the GPU was doing, docs/history section 5 -- was the
         # harness, not the library)
         import gc
         raw = np.empty(extra)

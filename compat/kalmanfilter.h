@@ -46,13 +46,16 @@ public:
 
     // capacity_landmarks / device_id are additions with defaults: `new KalmanFilter(&robot)` still works
     explicit KalmanFilter(ArRobot *robot, int capacity_landmarks = 4096, int device_id = 0) : robot(robot) {
-        // This class synchronises after every call (the public mirrors must be current, kalmanfilter.cpp:46-48,85-89), so a dense pass
-        // never runs beside a chain kernel: the in-place pipeline is the faster one for this call pattern (one slot set to stage per
-        // launch, no second P_LL buffer) -- 106 / 117 us per 5-call step at N = 1024 / 4096 against 127 / 144 overlapped.  The library's
-        // automatic choice (overlap = -1) is made for scripted runs, which do not synchronise.
+        // This class synchronises after every call (the public mirrors must be current, kalmanfilter.cpp:46-48,85-89).  Its calls travel as
+        // commands to a resident "streaming" launch (round 6, ekfslam_c.h "Tunables": EKF_STREAM), so what a call costs is one trip to the
+        // device and back plus the operation itself; what is left to choose is where the window's dense pass runs.  In place (overlap = 0)
+        // the call that follows a full window waits for the pass: nothing at N = 1024 (15 us), 100 us at N = 4096.  From 2048 landmarks on
+        // the pass therefore runs beside the next window's calls (overlap = 1, a second P_LL buffer): per 5-call step at N = 4096 median
+        // 70 us / p90 115 us against 65 / 163 in place; at N = 1024 in place is the faster one (62 / 77 against 66 / 104).  (Before round 6,
+        // one launch per call: 100 / 110 us median, p90 185 us at N = 4096.)
         ekf_params params;
         ekf_default_params(&params);
-        params.overlap = 0;
+        params.overlap = capacity_landmarks >= 2048 ? 1 : 0;
         check(ekf_create(&h, capacity_landmarks, device_id, &params));  // x = 0_3, P = 0_3x3: kalmanfilter.cpp:10-11
     }
     ~KalmanFilter() { ekf_destroy(h); }

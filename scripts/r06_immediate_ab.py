@@ -23,9 +23,9 @@ for name, N in (("n1024", 1024), ("n4096", 4096)):
             np.ascontiguousarray(P0).tofile(f)
         del P0
         for rep in range(int(os.environ.get("REPS", "2"))):
-            for stream in ("0", "1"):
-                env = dict(os.environ, EKF_STREAM=stream)
+            for stream, overlap in (("0", "0"), ("1", "0"), ("1", "1"), ("0", "1")):
+                env = dict(os.environ, EKF_STREAM=stream, EKF_OVERLAP=overlap)
                 p = subprocess.run([replay, os.path.join(td, "rec.txt"), td, str(N), "--state", os.path.join(td, "state.bin"), "--timing"], env=env,
                                    stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
                 lines = [l for l in p.stdout.splitlines() if l.startswith(("timing", "streaming", "final"))]
-                print(name, "EKF_STREAM=" + stream, " | ".join(lines), p.stderr[-200:], flush=True)
+                print(name, "EKF_STREAM=" + stream, "EKF_OVERLAP=" + overlap, " | ".join(lines), p.stderr[-200:], flush=True)

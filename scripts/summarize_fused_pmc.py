@@ -5,6 +5,7 @@ import collections, csv, glob, json, os, sys
 sys.path.insert(0, os.getcwd())
 import bench
 
+ROUND = os.environ.get("ROUND", "r05")  # (the round whose collection is summarised: names the output file)
 src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof_r05_batch256_fusedpmc"
 WINDOWS, WIN, B, N = 24, 32, 256, 256
 
@@ -66,7 +67,7 @@ if "FETCH_SIZE" in per_disp and "WRITE_SIZE" in per_disp:
          "note": "whole k_solo<true> windows: the measurement loop's traffic (P_LL entries of the matched landmarks, the B side of the slots written once: "
                  "algorithmic_slot_emit_bytes) is IN these counters; ratio_without_the_slot_emit is the figure comparable with traffic_batch256.json, "
                  "which counted the pass kernel alone (its operand reads, not the writes that produced them).  A per-launch = per-window figure.",
-         "source": "profiles/r05_batch256_fusedpmc_summary.json"}
+         "source": "profiles/%s_batch256_fusedpmc_summary.json" % ROUND}
     # the measurement loop alone (scripts/r05_collect_looponly_and_bench.sh: the debug library with the dense passes skipped): what is left
     # after subtracting its reads is the in-kernel pass's own read traffic (tiles + operands); the pass writes the tiles and nothing else
     lo_dir = sys.argv[2] if len(sys.argv) > 2 else "gpurun_out/prof_r05_batch256_looponly"
@@ -86,5 +87,5 @@ if "FETCH_SIZE" in per_disp and "WRITE_SIZE" in per_disp:
                                     "traffic_batch256.json's hbm_bytes_per_launch / algorithmic (the pass as a kernel of its own, round 4: 1.127)"})
     out["traffic"] = t
     json.dump(t, open("profiles/traffic_batch256_fused.json", "w"), indent=1)
-json.dump(out, open("profiles/r05_batch256_fusedpmc_summary.json", "w"), indent=1)
+json.dump(out, open("profiles/%s_batch256_fusedpmc_summary.json" % ROUND, "w"), indent=1)
 print(json.dumps({k2: v for k2, v in out.items() if k2 in ("us_per_window", "windows_per_dispatch")}), json.dumps(out.get("traffic", {}))[:900])

@@ -175,16 +175,16 @@ def test_replay_against_the_oracle_trajectory_and_reference_file_layout(replay_b
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("N", [50, 1024, 4096])
-def test_immediate_mode_latency_is_bounded(replay_bin, pkg, tmp_path, N):
+def test_immediate_mode_latency_is_bounded(replay_bin, pkg, tmp_path, pipeline_mode, N):
     """The path slam.cpp really uses: one synchronising call at a time with the public mirrors refreshed after each
-    (kalmanfilter.cpp:46-48,85-89).  A step of 1 doPropagation + 4 doUpdate costs five kernel launches and five waits
-    on the host-mapped mirror -- about 0.1 ms from C++ and 0.15 ms through ctypes whatever N is since round 5 (the shims run the pass in place,
-    a one-operation launch carries its record in the kernel arguments, launches without a measurement skip the cache refill: 85 / 105 /
-    111 us at N = 50 / 1024 / 4096); the bound is 200 us (600 in rounds 2-4).  Both hosts: the C++ replay driver and the Python mirror."""
+    (kalmanfilter.cpp:46-48,85-89).  Round 6: for maps above 256 landmarks the calls are commands to a resident streaming launch
+    (N = 1024 / 4096: 62-70 us per 5-call step from C++, p90 77 / 115 us; one launch per call cost 100 / 110 us, p90 185 us); maps of up to
+    256 landmarks keep one k_solo launch per call (85 us at N = 50).  The C++ bounds: median 150 us (200 in round 5, 600 before), p90
+    150 us where the calls stream.  Both hosts: the C++ replay driver and the Python mirror (ctypes and NumPy conversions: 200 us)."""
     M, steps = 4, 80
     x0, P0 = pkg.scenarios.injected_state(N, seed=1, extent=50.0 * (N / 4096.0) ** 0.5)  # constant landmark density
     sc = pkg.scenarios.steady_script(x0, steps=steps, M=M, seed=2, min_separation=1.0)
-    bound_us = 200.0
+    bound_us = 150.0
     # C++: compat/replay --timing, starting from the injected state; measurements handed over as robot-frame mm features
     rec = tmp_path / "rec.txt"
     with open(rec, "w") as f:
@@ -215,7 +215,13 @@ def test_immediate_mode_latency_is_bounded(replay_bin, pkg, tmp_path, N):
         per_step.append((time.perf_counter() - t0) * 1e6)
     median_py = float(np.median(per_step[16:]))
     print("immediate mode N=%d: %.0f us/step C++ (p90 %.0f), %.0f us/step Python" % (N, median_cpp, p90_cpp, median_py))
-    assert median_cpp < bound_us and median_py < bound_us, (N, median_cpp, median_py)
+    assert median_cpp < bound_us and median_py < 200.0, (N, median_cpp, median_py)
+    if N > 256:
+        assert "streaming 1" in out.stdout, out.stdout[-300:]
+        # (the p90 is the step behind a full window: with the pass forced in place -- this suite's "inplace" mode overrides the shim's choice
+        # of the overlapped pipeline from 2048 landmarks on -- that step waits 100 us for the pass at N = 4096)
+        if not (N >= 2048 and pipeline_mode == "inplace"):
+            assert p90_cpp < bound_us, (N, p90_cpp, out.stdout[-300:])
 
 
 def test_compat_featuredetector_header_keeps_the_reference_interface():

@@ -178,3 +178,50 @@ def test_a_chunk_of_several_measurements_streams_in_order(pkg, oc, pipeline_mode
     xg, Pg = f.get_state()
     f.close()
     assert_state_close(xg, Pg, x, P, "streamed chunks")
+
+
+_LOSSY_CHILD = r"""
+import json, os, sys
+sys.path.insert(0, %(root)r)
+sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import numpy as np
+import __graft_entry__ as ge
+import test_streaming as T
+pkg = ge.load_package()
+outs = {}
+init = None
+for stream in ("0", "1"):
+    os.environ["EKF_STREAM"] = stream
+    outs[stream] = T.drive(pkg, 1024, 24, 4, 8, seed=4242, compass=True, reads=True, x0P0=init)
+    init = (outs[stream]["x0"], outs[stream]["P0"])
+a, b = outs["0"], outs["1"]
+print("RESULT " + json.dumps({"same_decisions": a["decs"] == b["decs"], "n_dec": len(b["decs"]), "starts": b["starts"], "ops": b["ops"],
+                              "dpose": float(np.abs(a["poses"] - b["poses"]).max()), "dx": float(np.abs(a["x"] - b["x"]).max()),
+                              "dP": float(np.abs(a["P"] - b["P"]).max() / np.abs(a["P"]).max()),
+                              "old": int(a["stats"]["n_old"]), "old_s": int(b["stats"]["n_old"])}))
+"""
+
+
+@pytest.mark.parametrize("idle_ticks,no_recheck", [(200, 1), (50, 1), (400, 0)])
+def test_commands_a_leaving_launch_did_not_see_are_picked_up(pipeline_mode, idle_ticks, no_recheck):
+    """The host's safety net under the leave-by-itself handshake (stream_wait_consumed).  The DEBUG library makes the launch leave after
+    0.5-4 us without a command (EKF_DEBUG_STREAM_IDLE_TICKS) and, worse, WITHOUT its second look at the command slot
+    (EKF_DEBUG_STREAM_NO_RECHECK): the host then regularly reads "running" from a launch that is about to leave without the command it has
+    just posted.  Nothing may be lost or executed twice: decisions identical to one launch per call, states equal to rounding -- and far
+    more launches than windows."""
+    import json
+    import os
+    import subprocess
+    import sys
+    if pipeline_mode != "inplace":
+        pytest.skip("once is enough: the handshake does not depend on the pipeline mode")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "2d-ekf-slam_amd", "lib", "libekfslam_hip_debug.so")
+    env = {k: v for k, v in os.environ.items() if not k.startswith("EKF")}
+    env.update(EKFSLAM_LIB=lib, EKF_DEBUG_STREAM_IDLE_TICKS=str(idle_ticks), EKF_DEBUG_STREAM_NO_RECHECK=str(no_recheck), EKF_OVERLAP="0")
+    p = subprocess.run([sys.executable, "-c", _LOSSY_CHILD % {"root": root}], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    r = json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][0][7:])
+    assert r["same_decisions"] and r["n_dec"] == 96 and r["old"] == r["old_s"], r
+    assert r["dpose"] <= 1e-11 and r["dx"] <= 1e-11 and r["dP"] <= 1e-12, r
+    assert r["starts"] > 40, r  # (24 steps of 6-7 calls with Python between them: the launch leaves after almost every call)
