@@ -941,16 +941,16 @@ static int stream_op(ekf_batch *h, const double *rec, bool consumes) {
         }
     }
     {
-        // seventeen granules {32 payload bits, the sequence number's low half}; the flags last (the launch looks for them first, and re-reads
-        // every other granule until it carries the tag)
+        // seventeen granules {32 payload bits, the sequence number's low half}; the flags (g[0]) last: the launch polls them, and re-reads
+        // every other granule until it carries the tag
         const unsigned long long tg = ((unsigned long long)seq & 0xffffffffull) << 32;
         for (int i = 0; i < 8; i++) {
             unsigned long long bits;
             memcpy(&bits, rec + i, sizeof bits);
-            __atomic_store_n(&cmd->g[2 * i], (bits & 0xffffffffull) | tg, __ATOMIC_RELAXED);
-            __atomic_store_n(&cmd->g[2 * i + 1], (bits >> 32) | tg, __ATOMIC_RELAXED);
+            __atomic_store_n(&cmd->g[1 + 2 * i], (bits & 0xffffffffull) | tg, __ATOMIC_RELAXED);
+            __atomic_store_n(&cmd->g[2 + 2 * i], (bits >> 32) | tg, __ATOMIC_RELAXED);
         }
-        __atomic_store_n(&cmd->g[16], (unsigned long long)(closes ? EKF_STREAM_END_AFTER : 0) | tg, __ATOMIC_RELEASE);
+        __atomic_store_n(&cmd->g[0], (unsigned long long)(closes ? EKF_STREAM_END_AFTER : 0) | tg, __ATOMIC_RELEASE);
     }
     h->stream_ops++;
     h->stream_last_seq = seq;
@@ -979,7 +979,26 @@ static int stream_op(ekf_batch *h, const double *rec, bool consumes) {
         int rc = stream_wait_consumed(h, seq);
         h->stream_alive = false;
         if (rc) return rc;
-        return close_set(h, false, nullptr);
+        // The next window's streaming launch goes out at once, IN FRONT of the pass's launch: a pass that is already streaming holds every CU
+        // its mask allows with a queue of workgroups behind them, and a chain launch that arrives later gets its 64 CUs one by one as tiles
+        // finish -- the first exchange then waits for the last workgroup, 100 us (seen as a bimodal p90).  Launched first, it is resident when
+        // the next call comes (within the idle time) and the pass takes what is left.  The event the pass waits for sits between the two.
+        if (h->overlap) {
+            HIP_TRY(hipEventRecord(h->ev_chain, h->s_chain));  // (behind the launch that filled the window)
+            h->chain_signalled = true;
+            EnqueueList pass;
+            rc = close_set(h, false, &pass);  // the host's state now describes the next window; the pass's calls wait in `pass`
+            if (rc) return rc;
+            rc = stream_start(h, seq, h->pending);
+            for (auto &enq : pass) {
+                hipError_t e = enq();
+                if (e != hipSuccess && rc == EKF_OK) rc = set_error(EKF_ERR_HIP, hipGetErrorString(e));
+            }
+            return rc;
+        }
+        rc = close_set(h, false, nullptr);  // (in place: the pass runs on the chain's stream, the next launch behind it)
+        if (rc) return rc;
+        return stream_start(h, seq, h->pending);
     }
     return EKF_OK;
 }

@@ -116,9 +116,10 @@ enum { EKF_STREAM_RUNNING = 1, EKF_STREAM_EXITING = 2, EKF_STREAM_EXITED = 3 };
 enum { EKF_STREAM_END_AFTER = 1, EKF_STREAM_EXIT = 2 };  // command flags: leave after this operation (host); leave now (workgroup 0's forward only)
 struct alignas(128) StreamCmd {
     // Seventeen self-validating 8-byte granules {32 payload bits, 32-bit tag = the low half of the command's sequence number} -- the form the
-    // cross-workgroup exchange uses (MI355X_MICROARCH.md, granules): g[2i], g[2i + 1] = low / high half of rec[i], g[16] = the flags.  The
-    // host writes g[16] last and the launch looks for it first, but nothing DEPENDS on that order: every granule is re-read until it carries
-    // the tag, so no assumption is made about the order in which reads of two cache lines of host memory are served.
+    // cross-workgroup exchange uses (MI355X_MICROARCH.md, granules): g[0] = the flags, g[1 + 2i], g[2 + 2i] = low / high half of rec[i].  The
+    // host writes g[0] last and the launch polls it (with the rest of the command's first cache line) -- but nothing DEPENDS on that order:
+    // every granule is re-read until it carries the tag, so no assumption is made about the order in which reads of two cache lines of host
+    // memory are served.
     unsigned long long g[18];
 };
 struct alignas(128) StreamCtl {

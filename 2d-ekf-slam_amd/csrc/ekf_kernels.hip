@@ -963,61 +963,59 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                         const unsigned long long launch = (unsigned long long)(unsigned)plan.stream;
                         const unsigned ctag = (unsigned)((consumed + 1) & 0xffffffffull);  // the tag every granule of command consumed + 1 carries
                         int verdict = 0;  // 1: a command, 2: leave
-                        if (lane == 0) {
-                            unsigned long long t0, t1;
-                            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
-                            for (;;) {
-                                // (the command first: what the host posted before it asked the launch to stop is consumed before the launch leaves)
-                                const unsigned long long fg = __hip_atomic_load(&cmd->g[16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                                const unsigned long long stp = __hip_atomic_load(&ctl->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                                if ((unsigned)(fg >> 32) == ctag) {
+                        // Reads of host memory cost about a microsecond PER CACHE LINE and one wave's reads of different lines do not overlap (measured:
+                        // polling all three lines of a command plus the stop word every round was no faster than two dependent trips), so the
+                        // waiting loop touches ONE line: the command's first, which holds the flags granule g[0] (written last by the host) and the
+                        // first seven record granules; the stop word is looked at every fourth round.  When the flags carry the tag, lanes 8..16 fetch
+                        // the other two lines once.  Every granule is re-read until it carries the command's tag: no ordering assumption anywhere.
+                        unsigned long long gq = 0, t0, t1;
+                        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+                        const unsigned long long idle_ticks = plan.inl_n ? (unsigned long long)plan.inl[0] : (unsigned long long)EKF_STREAM_IDLE_TICKS;  // (inl_n: the debug library's test hooks)
+                        bool ok = lane > 16;
+                        for (unsigned round = 0;; round++) {
+                            unsigned long long stp = 0;
+                            if (!ok && lane < 8) {
+                                gq = __hip_atomic_load(&cmd->g[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                ok = (unsigned)(gq >> 32) == ctag;
+                            } else if (lane == 17 && (round & 3) == 3) {
+                                stp = __hip_atomic_load(&ctl->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            }
+                            // (the command first: what the host posted before it asked the launch to stop is consumed before the launch leaves)
+                            if (__any(lane == 0 && ok)) {
+                                verdict = 1;
+                                break;
+                            }
+                            if (__any(lane == 17 && stp == launch)) {
+                                verdict = 2;
+                                break;
+                            }
+                            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+                            if (t1 - t0 > idle_ticks) {
+                                if (plan.inl_n & 2) {  // (test hook: leave without the second look -- the host's safety net must pick the command up)
+                                    verdict = 2;
+                                    break;
+                                }
+                                // leaving by itself: say so, then look once more (the host does the mirror image: command, fence, state) -- a command
+                                // that is there now is consumed, the exit cancelled; the host's safety net covers whatever order the accesses are served in
+                                if (lane == 0) __hip_atomic_store(&ctl->state, (launch << 2) | EKF_STREAM_EXITING, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                __atomic_thread_fence(__ATOMIC_SEQ_CST);
+                                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                                if (lane == 0) {
+                                    gq = __hip_atomic_load(&cmd->g[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                    ok = (unsigned)(gq >> 32) == ctag;
+                                }
+                                if (__any(lane == 0 && ok)) {
+                                    if (lane == 0) __hip_atomic_store(&ctl->state, (launch << 2) | EKF_STREAM_RUNNING, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                                     verdict = 1;
-                                    break;
-                                }
-                                if (stp == launch) {
+                                } else {
                                     verdict = 2;
-                                    break;
                                 }
-                                asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
-                                if (t1 - t0 > (plan.inl_n ? (unsigned long long)plan.inl[0] : (unsigned long long)EKF_STREAM_IDLE_TICKS)) {  // (inl_n: the debug library's test hooks)
-                                    if (plan.inl_n & 2) {  // (test hook: leave without the second look -- the host's safety net must pick the command up)
-                                        verdict = 2;
-                                        break;
-                                    }
-                                    // leaving by itself: say so, then look once more (a PCIe read does not pass the posted write in front of it; the host
-                                    // does the mirror image: command, fence, state) -- a command that is there now is consumed, the exit cancelled
-                                    __hip_atomic_store(&ctl->state, (launch << 2) | EKF_STREAM_EXITING, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                                    __atomic_thread_fence(__ATOMIC_SEQ_CST);
-                                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                                    if ((unsigned)(__hip_atomic_load(&cmd->g[16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >> 32) == ctag) {
-                                        __hip_atomic_store(&ctl->state, (launch << 2) | EKF_STREAM_RUNNING, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                                        verdict = 1;
-                                    } else {
-                                        verdict = 2;
-                                    }
-                                    break;
-                                }
+                                break;
                             }
-                            // every other workgroup has read the previous forward (normally long ago): the slot may be overwritten
-                            if (n_fw == 0) ack_base = __hip_atomic_load(dv.sfw + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            long spins = 0;
-                            while (__hip_atomic_load(dv.sfw + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ack_base < n_fw * (unsigned long long)(G - 1)) {
-                                __builtin_amdgcn_s_sleep(1);
-                                if (++spins > (1L << 22)) {  // bounded
-                                    dv.status[b] = EKF_ERR_TIMEOUT, dv.mirror[b].status = EKF_ERR_TIMEOUT, L.abort = 1;
-                                    verdict = 2;
-                                    break;
-                                }
-                            }
-                            n_fw++;
                         }
-                        verdict = uni(verdict);  // (lane 0 is the first active lane)
-                        unsigned long long fl = 0;
                         if (verdict == 1) {
-                            // the record and the flags: one granule per lane, each re-read until it carries the command's tag (normally at once)
-                            unsigned long long gq = 0;
+                            // the rest of the command: lanes 1..16 (lines 0, 1, 2), each re-read until it carries the tag (normally at once)
                             long spins = 0;
-                            bool ok = lane > 16;
                             for (;;) {
                                 if (!ok) {
                                     gq = __hip_atomic_load(&cmd->g[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1030,10 +1028,24 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                                     break;
                                 }
                             }
-                            if (lane < 16) ((unsigned *)recs)[lane] = (unsigned)gq;  // (little-endian: words 2i, 2i + 1 are record value i)
-                            fl = __shfl(gq, 16) & 0xffffffffull;
+                        }
+                        if (verdict == 1 && lane >= 1 && lane <= 16) ((unsigned *)recs)[lane - 1] = (unsigned)gq;  // (little-endian: words 2i, 2i + 1 are record value i)
+                        const unsigned long long fl = __shfl(gq, 0) & 0xffffffffull;
+                        if (lane == 0) {
+                            // every other workgroup has read the previous forward (normally long ago): the slot may be overwritten
+                            if (n_fw == 0) ack_base = __hip_atomic_load(dv.sfw + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            long spins = 0;
+                            while (__hip_atomic_load(dv.sfw + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ack_base < n_fw * (unsigned long long)(G - 1)) {
+                                __builtin_amdgcn_s_sleep(1);
+                                if (++spins > (1L << 22)) {  // bounded
+                                    dv.status[b] = EKF_ERR_TIMEOUT, dv.mirror[b].status = EKF_ERR_TIMEOUT, L.abort = 1;
+                                    break;
+                                }
+                            }
+                            n_fw++;
                         }
                         verdict = uni(verdict);
+                        if (uni(L.abort)) verdict = 2;
                         if (verdict == 1) {
                             if (lane < 8) val = recs[lane];
                             else if (lane == 8) val = (double)(long long)fl;
