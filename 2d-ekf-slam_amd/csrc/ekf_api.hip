@@ -453,6 +453,8 @@ static int create_impl(ekf_batch *h, int batch, int capacity_landmarks, int devi
     HIP_TRY(hipFuncSetAttribute((const void *)k_chain<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_budget));
     HIP_TRY(hipFuncSetAttribute((const void *)k_solo<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_budget));
     HIP_TRY(hipFuncSetAttribute((const void *)k_solo<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_budget));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_solo<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_budget));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_solo<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_budget));
     int workers = (dv.lpw + 63) / 64 * 64;
     if (workers > max_workers) workers = max_workers;
     if (dv.lpw > 64 && dv.lpw <= 128) workers = 192;  // two owner waves and a third that shares their fold (k_chain: helper_on)
@@ -628,8 +630,8 @@ static int create_impl(ekf_batch *h, int batch, int capacity_landmarks, int devi
     }
     h->flush_dir = 0;
     read_debug_hooks(h);
-    // streaming immediate-mode calls: one filter run by k_chain (every single-filter map above 256 landmarks, and smaller ones on forced geometries)
-    h->stream_calls = batch == 1 && !h->solo_kernel && !(getenv("EKF_STREAM") && atoi(getenv("EKF_STREAM")) == 0);
+    // streaming immediate-mode calls: every handle of ONE filter (k_chain above 256 landmarks, k_solo up to 256)
+    h->stream_calls = batch == 1 && !(getenv("EKF_STREAM") && atoi(getenv("EKF_STREAM")) == 0);
     h->xcd_map = getenv("EKF_XCD_MAP") ? atoi(getenv("EKF_XCD_MAP")) != 0 : true;
     h->batch_interleave = getenv("EKF_BATCH_INTERLEAVE") ? atoi(getenv("EKF_BATCH_INTERLEAVE")) != 0 : true;
     h->script_d = nullptr;
@@ -859,7 +861,8 @@ static int stream_start(ekf_batch *h, long long consumed0, int slot0) {
     sg.k0 = 0, sg.nops = 0, sg.slot0 = slot0, sg.set = h->cur_set, sg.buf_read = h->buf_in, sg.n_prev = h->prev_pending;
     sg.need_pass = h->need_pass, sg.drop = 0;
     sg.seq = consumed0;  // the last command consumed before this launch
-    sg.gate = 0, sg.self_pass = 0, sg.stagger = 0;
+    // (a one-workgroup filter whose launches fold the windows they fill does so in a streaming launch too, behind the command that closes the window)
+    sg.gate = 0, sg.self_pass = (h->solo_kernel && h->solo_fuse && !h->dbg_skip_flush) ? 1 : 0, sg.stagger = 0;
     plan.nseg = 1, plan.signal = 0, plan.inl_n = 0;
     if (h->dbg_stream_idle_ticks > 0 || h->dbg_stream_no_recheck) {  // (debug library only: a streaming launch has no inline record, the fields carry the test hooks)
         plan.inl_n = 1 | (h->dbg_stream_no_recheck ? 2 : 0);
@@ -868,7 +871,13 @@ static int stream_start(ekf_batch *h, long long consumed0, int slot0) {
     h->stream_launch = h->stream_launch >= 0xffff ? 1 : h->stream_launch + 1;  // (16 bits of it tag the forwards)
     plan.stream = h->stream_launch;
     __atomic_store_n(&h->sctl_h->state, ((unsigned long long)(unsigned)plan.stream << 2) | EKF_STREAM_RUNNING, __ATOMIC_SEQ_CST);
-    if (h->chain_one)
+    if (h->solo_kernel && h->solo_long)
+        hipExtLaunchKernelGGL((k_solo<true, true>), dim3(1, 1), dim3(h->chain_threads), h->chain_lds, h->s_chain, nullptr, nullptr, 0, h->dv,
+                              (const double *)h->ring_d, (const int *)nullptr, plan, 0);
+    else if (h->solo_kernel)
+        hipExtLaunchKernelGGL((k_solo<false, true>), dim3(1, 1), dim3(h->chain_threads), h->chain_lds, h->s_chain, nullptr, nullptr, 0, h->dv,
+                              (const double *)h->ring_d, (const int *)nullptr, plan, 0);
+    else if (h->chain_one)
         hipExtLaunchKernelGGL((k_chain<true, true>), dim3(h->chain_wgs, 1), dim3(h->chain_threads), h->chain_lds, h->s_chain, nullptr, nullptr, 0, h->dv,
                               (const double *)h->ring_d, (const int *)nullptr, plan, 0);
     else
@@ -995,6 +1004,14 @@ static int stream_op(ekf_batch *h, const double *rec, bool consumes) {
                 if (e != hipSuccess && rc == EKF_OK) rc = set_error(EKF_ERR_HIP, hipGetErrorString(e));
             }
             return rc;
+        }
+        if (h->solo_kernel && h->solo_fuse && !h->dbg_skip_flush) {
+            // (folded by the launch itself, behind the closing command: the next launch starts an empty window, as launch_ops has it)
+            h->windows_closed++;
+            h->last_window_slots = h->pending;
+            h->cur_set ^= 1;
+            h->pending = 0;
+            return stream_start(h, seq, 0);
         }
         rc = close_set(h, false, nullptr);  // (in place: the pass runs on the chain's stream, the next launch behind it)
         if (rc) return rc;

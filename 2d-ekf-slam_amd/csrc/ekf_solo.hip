@@ -37,6 +37,7 @@ struct SoloLds {
     long long log_count;
     ekf_decision dec_buf[EKF_CHAIN_MAX_OPS];
     int n_dec;
+    int scmd;  // streaming launches: flags of the command just fetched (EKF_STREAM_END_AFTER, EKF_STREAM_EXIT)
     // per measurement parity, per wave: arg-min candidate and the winner record res(2) S00,S01,S11 hcol(2) P_R,Lo(6) D(3)
     double wd[2][4];
     int wi[2][4];
@@ -117,7 +118,11 @@ __device__ __forceinline__ void solo_nees_sample(const SoloRobot &R, const doubl
 // else the host launches k_flush_rb in place between the launches).
 // LONG: the window may be longer than the own-row cache (its first half then lives in accumulation registers, solo_agpr.h); the
 // host launches k_solo<true> only for such handles -- windows the cache holds run the kernel without any of that code.
-template <bool LONG>
+// STREAM (round 6): the launch may be a streaming one (plan.stream != 0; ekf_device.h "streaming immediate-mode calls") -- one segment without
+// operations of its own, wave 0 fetches them one by one from the host-mapped command ring and publishes the host mirror after each.  One
+// workgroup: no forward to anybody.  A streaming launch whose window fills (EKF_STREAM_END_AFTER) folds it itself where the handle's
+// launches do (ChainSeg::self_pass) and leaves.  A separate instantiation: the batch's code and registers are untouched.
+template <bool LONG, bool STREAM = false>
 __global__ __launch_bounds__(256) void k_solo(EkfDev dv, const double *in, const int *cursor, ChainPlan plan, int b_off) {
     __shared__ SoloLds L;
     __shared__ double recs[EKF_CHAIN_MAX_OPS * 8];
@@ -139,6 +144,13 @@ __global__ __launch_bounds__(256) void k_solo(EkfDev dv, const double *in, const
     const SegPtr segs = (SegPtr)((__attribute__((address_space(4))) const char *)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(ChainKArgs, plan) + offsetof(ChainPlan, s));
     const int nseg = plan.nseg;
     const long long last_seq = segs[nseg - 1].seq;
+    // streaming: the number of the last command consumed (the mirror's seq after it), whether the command just done closes the window, the
+    // decisions already in the host mirror
+    unsigned long long consumed = STREAM ? (unsigned long long)segs[0].seq : 0ull;
+    const unsigned long long consumed0 = consumed;
+    bool end_after = false;
+    int pub_dec = 0;
+    (void)consumed0, (void)end_after, (void)pub_dec;
 
     // state that lives across the segments of the launch
     unsigned long long new_mask = 0;  // slots of the open window that appended a landmark
@@ -164,7 +176,9 @@ __global__ __launch_bounds__(256) void k_solo(EkfDev dv, const double *in, const
 
     for (int seg = 0; seg < nseg; seg++) {
         const int k0 = segs[seg].k0, nops = segs[seg].nops, slot0 = segs[seg].slot0, set = segs[seg].set, buf_read = segs[seg].buf_read;
-        const int self_pass = segs[seg].self_pass;
+        // (a streaming launch does not know whether it will fill the window: its slots go out with both sides -- a pass KERNEL may have to fold
+        // them -- and it folds the window itself only behind the command that closes it)
+        const int self_pass = (STREAM && plan.stream) ? 0 : segs[seg].self_pass;
         if (seg == 0 && segs[0].stagger > 0 && (b & 3) != 0) {  // phase shift between the filters of a batch (see "the workgroup's own dense pass" below)
             unsigned long long t0, now;
             asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
@@ -294,7 +308,7 @@ __global__ __launch_bounds__(256) void k_solo(EkfDev dv, const double *in, const
             // only a measurement reads the cached rows (k_chain: need_cache): a short launch without one -- a doPropagation or
             // doUpdateCompass call -- does not fetch them (one segment only, so nothing later in the launch could miss them)
             bool need_cache = true;
-            if (nseg == 1 && nops <= 4) {
+            if (nseg == 1 && nops <= 4 && !(STREAM && plan.stream)) {  // (a streaming launch does not know what will arrive: it fills the cache)
                 need_cache = false;
                 for (int q = 0; q < nops; q++) need_cache = need_cache || uni((int)recs[q * 8 + 7]) == OP_MEAS;
             }
@@ -328,7 +342,107 @@ __global__ __launch_bounds__(256) void k_solo(EkfDev dv, const double *in, const
 
         // ---- the operation loop ------------------------------------------------------------------------------------------
         int slot = slot0;
-        for (int op = 0; op < nops; op++) {
+        int nops_run = nops;  // (streaming: 1 for every fetched command, whose record lies in recs[0..7])
+        for (int op = 0;; op++) {
+            if (op >= nops_run) {
+                if constexpr (!STREAM) {
+                    break;
+                } else {
+                    if (!plan.stream || end_after) break;
+                    // ---- streaming: the operation just done goes to the host mirror, the next command comes in (k_chain has the same block; one
+                    // workgroup here: wave 0 fetches, nobody is forwarded to) ---------------------------------------------------------------
+                    __syncthreads();  // (operations without a barrier of their own: nobody is still reading the record that is about to be replaced)
+                    if (wave == 0) {
+                        StreamCtl *ctl = dv.sctl;
+                        EkfMirror *mr = dv.mirror + b;
+                        if (consumed != consumed0) {
+                            const int nd = L.n_dec;
+                            const long long first = L.log_count - nd;
+                            for (int i = pub_dec + lane; i < nd; i += 64) mr->last[(first + i) % EKF_MIRROR_DECISIONS] = L.dec_buf[i];
+                            pub_dec = nd;
+                            if (lane == 0) {
+                                for (int i = 0; i < 3; i++) mr->pose[i] = rb.pose[i];
+                                for (int i = 0; i < 9; i++) mr->Prr[i] = rb.Prr[i];
+                                mr->n_lm = n_lm;
+                                mr->stats = L.st;
+                                if (dv.status[b] != 0) mr->status = dv.status[b];
+                                mr->log_count = L.log_count;
+                            }
+                            __atomic_thread_fence(__ATOMIC_RELEASE);  // (every lane, for its own stores)
+                            if (lane == 0) __hip_atomic_store(&mr->seq, (long long)consumed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        }
+                        const StreamCmd *cmd = &ctl->cmd[(consumed + 1) % EKF_STREAM_RING];
+                        const unsigned long long launch = (unsigned long long)(unsigned)plan.stream;
+                        const unsigned ctag = (unsigned)((consumed + 1) & 0xffffffffull);
+                        int verdict = 0;  // 1: a command, 2: leave
+                        unsigned long long gq = 0, t0, t1;
+                        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+                        const unsigned long long idle_ticks = plan.inl_n ? (unsigned long long)plan.inl[0] : (unsigned long long)EKF_STREAM_IDLE_TICKS;  // (inl_n: the debug library's test hooks)
+                        bool ok = lane > 16;
+                        for (unsigned round = 0;; round++) {  // (one cache line of host memory per round: the command's first, flags granule g[0] included)
+                            unsigned long long stp = 0;
+                            if (!ok && lane < 8) {
+                                gq = __hip_atomic_load(&cmd->g[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                ok = (unsigned)(gq >> 32) == ctag;
+                            } else if (lane == 17 && (round & 3) == 3) {
+                                stp = __hip_atomic_load(&ctl->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            }
+                            if (__any(lane == 0 && ok)) {
+                                verdict = 1;
+                                break;
+                            }
+                            if (__any(lane == 17 && stp == launch)) {
+                                verdict = 2;
+                                break;
+                            }
+                            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+                            if (t1 - t0 > idle_ticks) {
+                                if (plan.inl_n & 2) {  // (test hook: leave without the second look)
+                                    verdict = 2;
+                                    break;
+                                }
+                                if (lane == 0) __hip_atomic_store(&ctl->state, (launch << 2) | EKF_STREAM_EXITING, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                __atomic_thread_fence(__ATOMIC_SEQ_CST);
+                                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                                if (lane == 0) {
+                                    gq = __hip_atomic_load(&cmd->g[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                    ok = (unsigned)(gq >> 32) == ctag;
+                                }
+                                if (__any(lane == 0 && ok)) {
+                                    if (lane == 0) __hip_atomic_store(&ctl->state, (launch << 2) | EKF_STREAM_RUNNING, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                    verdict = 1;
+                                } else {
+                                    verdict = 2;
+                                }
+                                break;
+                            }
+                        }
+                        if (verdict == 1) {
+                            long spins = 0;
+                            for (;;) {  // the rest of the command, every granule re-read until it carries the tag (normally at once)
+                                if (!ok) {
+                                    gq = __hip_atomic_load(&cmd->g[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                    ok = (unsigned)(gq >> 32) == ctag;
+                                }
+                                if (__all(ok)) break;
+                                if (++spins > (1L << 18)) {  // bounded
+                                    if (lane == 0) dv.status[b] = EKF_ERR_TIMEOUT, mr->status = EKF_ERR_TIMEOUT;
+                                    verdict = 2;
+                                    break;
+                                }
+                            }
+                        }
+                        verdict = uni(verdict);
+                        if (verdict == 1 && lane >= 1 && lane <= 16) ((unsigned *)recs)[lane - 1] = (unsigned)gq;  // (words 2i, 2i + 1 are record value i)
+                        if (lane == 0) L.scmd = verdict == 1 ? (int)(gq & 0xffffffffull) : (int)EKF_STREAM_EXIT;
+                    }
+                    __syncthreads();
+                    if (uni(L.scmd) & EKF_STREAM_EXIT) break;
+                    consumed++;
+                    end_after = (uni(L.scmd) & EKF_STREAM_END_AFTER) != 0;
+                    op = 0, nops_run = 1;
+                }
+            }
             const double *rec = recs + op * 8;
             const int type = uni((int)rec[7]);
 
@@ -776,7 +890,7 @@ __global__ __launch_bounds__(256) void k_solo(EkfDev dv, const double *in, const
         // (k_flush_rb's whole-tile form).  No second kernel, no launch gaps, the landmark and the robot block stay in registers across
         // windows -- and the filters of a batch drift apart in phase (ChainSeg::stagger), so that while some stream their tiles the
         // others run their latency-bound measurement loops: HBM sees a steady third of the traffic instead of bursts of all of it.
-        if (self_pass) {
+        if ((STREAM && plan.stream) ? (end_after && segs[seg].self_pass != 0) : (self_pass != 0)) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's slot rows have left
             __syncthreads();                                  // ... everybody's have
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // (the CU's L1 may hold the rows of the window before, and tiles this workgroup read)
@@ -943,7 +1057,15 @@ __global__ __launch_bounds__(256) void k_solo(EkfDev dv, const double *in, const
                 }
                 // everything above is in host memory before the sequence number is: a host thread spinning on seq reads a complete mirror
                 __atomic_thread_fence(__ATOMIC_RELEASE);
-                if (lane == 0) __hip_atomic_store(&mr->seq, last_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (lane == 0) __hip_atomic_store(&mr->seq, (STREAM && plan.stream) ? (long long)consumed : last_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if constexpr (STREAM) {
+                    if (plan.stream && lane == 0) {  // the launch has left: what it consumed, then the state word
+                        StreamCtl *ctl = dv.sctl;
+                        __hip_atomic_store(&ctl->consumed, consumed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        __atomic_thread_fence(__ATOMIC_RELEASE);
+                        __hip_atomic_store(&ctl->state, ((unsigned long long)(unsigned)plan.stream << 2) | EKF_STREAM_EXITED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+                }
             }
         }
         if (seg + 1 < nseg) __syncthreads();

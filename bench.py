@@ -468,8 +468,9 @@ def immediate_leg(pkg, dev_id):
     if not os.path.exists(replay):
         return {"error": "compat/replay is not built"}
     out = {"unit": "us per 5-call step (doPropagation + 4 doUpdate, C++ shim, host clock)", "call_pattern": "slam.cpp:136-170"}
-    for name, N in (("n1024", 1024), ("n4096", 4096)):
-        _, _, _, _, seed, extent, min_sep = WORKLOADS[name]
+    for name, N in (("n50", 50), ("n1024", 1024), ("n4096", 4096)):
+        # (n50: the reference's own scale, BASELINE.json config 1 -- one workgroup, k_solo; constant landmark density as in tests/test_compat.py)
+        _, _, _, _, seed, extent, min_sep = WORKLOADS[name] if name in WORKLOADS else (0, 0, 0, 0, 1, 50.0 * (N / 4096.0) ** 0.5, 1.0)
         x0, P0 = pkg.scenarios.injected_state(N, seed=seed, extent=extent)
         sc = pkg.scenarios.steady_script(x0, steps=120, M=4, seed=seed + 7919, min_separation=min_sep)
         with tempfile.TemporaryDirectory() as td:
@@ -490,7 +491,8 @@ def immediate_leg(pkg, dev_id):
                 continue
             t = p.stdout.split("timing")[1].split()
             med = float(t[3])
-            out[name] = {"median": med, "p90": float(t[5]), "max": float(t[7]), "iterations": int(t[1]), "steps_per_s": 1e6 / med}
+            out[name] = {"median": med, "p90": float(t[5]), "max": float(t[7]), "iterations": int(t[1]), "steps_per_s": 1e6 / med,
+                         "streamed": "streaming 1" in p.stdout}  # (the calls travelled to a resident launch: DESIGN.md 4.4)
     return out
 
 

@@ -225,3 +225,52 @@ def test_commands_a_leaving_launch_did_not_see_are_picked_up(pipeline_mode, idle
     assert r["same_decisions"] and r["n_dec"] == 96 and r["old"] == r["old_s"], r
     assert r["dpose"] <= 1e-11 and r["dx"] <= 1e-11 and r["dP"] <= 1e-12, r
     assert r["starts"] > 40, r  # (24 steps of 6-7 calls with Python between them: the launch leaves after almost every call)
+
+
+@pytest.mark.parametrize("capacity,max_pending,steps", [(64, 16, 300), (256, 32, 260), (256, 24, 200), (200, 5, 150)])
+def test_small_maps_stream_through_the_one_workgroup_kernel(pkg, oc, monkeypatch, pipeline_mode, capacity, max_pending, steps):
+    """Maps of up to 256 landmarks -- the reference's own scale (config 1: N = 50) -- are run by k_solo; its streaming instantiation
+    fetches the calls itself (one workgroup: nobody to forward to) and, where the handle's launches fold the windows they fill, folds the
+    window behind the command that closes it and leaves.  A config-1 lifecycle from x = 0, P = 0 (New / Old / Ignore, compass) call for
+    call through the KalmanFilter mirror against the oracle, with streaming and with one launch per call; long windows (the first half in
+    accumulation registers) included."""
+    if pipeline_mode != "inplace":
+        pytest.skip("k_solo runs handles with the pass in place")
+    script = pkg.scenarios.lifecycle_script(steps=steps, compass_every=9, n_landmarks=min(capacity - 8, 120))
+    finals = {}
+    for stream in ("1", "0"):
+        monkeypatch.setenv("EKF_STREAM", stream)
+        kf = pkg.KalmanFilter(capacity_landmarks=capacity, max_pending=max_pending)
+        x, P = np.zeros(3), np.zeros((3, 3))
+        hist = {1: 0, 2: 0, 3: 0}
+        try:
+            for i, st in enumerate(script):
+                rot_deg = st["w"] * 180.0 / 3.141592654
+                kf.doPropagation(st["dt"], st["v"] * 1000.0, rot_deg)
+                v, w = (st["v"] * 1000.0) / 1000.0, rot_deg * 3.141592654 / 180.0
+                x, P = oc.propagate(x, P, v, w, oc.make_Q(v), st["dt"])
+                if st["compass"] is not None:
+                    kf.doUpdateCompass(st["compass"], 0.0005)
+                    x, P = oc.compass(x, P, st["compass"], 0.0005)
+                for fx, fy in st["feats_mm"]:
+                    z, R = oc.make_measurement(fx, fy)
+                    kf.doUpdate(z.reshape(2, 1), R)
+                    x, P, dec, mat, mah = oc.update(x, P, z.reshape(2, 1), R)
+                    g = kf.last_decisions[0]
+                    assert (g[0], g[1]) == (dec[0], mat[0]), (stream, i, g, dec, mat, mah)
+                    hist[dec[0]] += 1
+                assert kf.Num_Landmarks == (x.size - 3) // 2
+                assert abs(kf.X - x[0]) < 1e-9 and abs(kf.Y - x[1]) < 1e-9 and abs(kf.Phi - x[2]) < 1e-9
+                if i % 70 == 69:
+                    xg, Pg = kf.state()
+                    assert_state_close(xg, Pg, x, P, "stream %s step %d" % (stream, i))
+            on, starts, ops = stream_counts(kf._f)
+            assert on == int(stream) and (starts > 3 and ops > steps if stream == "1" else ops == 0)
+            xg, Pg = kf.state()
+            assert_state_close(xg, Pg, x, P, "final")
+            assert_bitwise_symmetric(Pg)
+            finals[stream] = (xg, Pg)
+            assert hist[1] >= 10 and hist[2] >= 100, hist
+        finally:
+            kf._f.close()
+    assert np.abs(finals["0"][0] - finals["1"][0]).max() <= 1e-11 and np.abs(finals["0"][1] - finals["1"][1]).max() <= 1e-12 * np.abs(finals["0"][1]).max()
