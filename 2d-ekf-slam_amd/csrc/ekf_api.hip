@@ -371,7 +371,7 @@ static int create_impl(ekf_batch *h, int batch, int capacity_landmarks, int devi
         if (g_max < 1) g_max = 1;
         long lpw_min = ((capacity_landmarks + g_max - 1) / g_max + 63) / 64 * 64;  // (the LDS cache is laid out in chunks of 64 landmarks)
         want_overlap = (lpw_min * maxp * 2 * 32 <= lds_budget) ? 1 : 0;
-        // ... and when there is a dense pass worth hiding.  Round 4 (scripts/r04_geometry.py): with several windows per chain launch
+        // ... and when there is a dense pass worth hiding.  Round 4 (scripts/history/r04_geometry.py): with several windows per chain launch
         // the overlapped pipeline also saves the launch boundaries between chain kernel and pass, and wins from P_LL = 10 MB on
         // (N = 768: 39.2 k against 35.3 k steps/s in place; N = 1024: 38.5 k against 35.3 k; N = 2048: 37.8 k against 32.3 k; N = 512,
         // 4 MB: 37.6 k against 36.9 k -- a draw; the threshold is 8 MB).  The threshold was 128 MB in rounds 1-3, measured on one-window launches.
@@ -500,7 +500,7 @@ static int create_impl(ekf_batch *h, int batch, int capacity_landmarks, int devi
     HIP_TRY(dev_alloc_zero(&dv.Bm[0], B * dv.bm_stride, &h->device_bytes, s));
     if (h->overlap) {  // the dense pass goes buffer to buffer
         // The second buffer is shifted by 4 KB against the first so that a tile's source and destination differ in DRAM
-        // channel/bank phase: 107-108 us per pass instead of 110-111 (scripts/exp_skew.sh; EKF_BM_SKEW overrides, bytes)
+        // channel/bank phase: 107-108 us per pass instead of 110-111 (scripts/history/exp_skew.sh; EKF_BM_SKEW overrides, bytes)
         size_t skew = (getenv("EKF_BM_SKEW") ? (size_t)atol(getenv("EKF_BM_SKEW")) : (size_t)4096) / sizeof(double);
         HIP_TRY(dev_alloc_zero(&h->bm1_base, B * dv.bm_stride + skew, &h->device_bytes, s));
         dv.Bm[1] = h->bm1_base + skew;
@@ -518,7 +518,7 @@ static int create_impl(ekf_batch *h, int batch, int capacity_landmarks, int devi
     HIP_TRY(dev_alloc_zero(&dv.seg_count, EKF_PLAN_MAX, &h->device_bytes, s));
     HIP_TRY(dev_alloc_zero(&dv.bar, B * 2, &h->device_bytes, s));
 #ifdef EKF_CHAIN_STAMPS
-    HIP_TRY(dev_alloc_zero(&dv.dbg, 32 + 65 * 2048, &h->device_bytes, s));  // + publish times of every workgroup, 2048 exchanges (scripts/r04_skew.py)
+    HIP_TRY(dev_alloc_zero(&dv.dbg, 32 + 65 * 2048, &h->device_bytes, s));  // + publish times of every workgroup, 2048 exchanges (scripts/history/r04_skew.py)
 #else
     HIP_TRY(dev_alloc_zero(&dv.dbg, 32, &h->device_bytes, s));
 #endif
@@ -734,7 +734,7 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 // sizeable part of a run of a few hundred microseconds.  The host polls the stream / event for up to two milliseconds
 // (about a microsecond per query) and only then blocks.
 // ... and a blocking wait in the runtime is never entered at all: once in a few dozen waits of several milliseconds the wake-up
-// came 4-10 ms late on the gpurun boxes (scripts/r04_stall_hunt.py: hipEventSynchronize returned 10-16 ms after the start of a
+// came 4-10 ms late on the gpurun boxes (scripts/history/r04_stall_hunt.py: hipEventSynchronize returned 10-16 ms after the start of a
 // 6.9 ms region; the driver's box showed 54 ms once), which is what a robot loop must not see.  So: spin on the query for 2 ms
 // (short waits: no system call), then keep querying between naps (one core mostly asleep, wake-up bounded by the nap).
 // The naps back off with the length of the wait -- 20 us up to 10 ms (with the kernel's default 50 us timer slack a nap really lasts

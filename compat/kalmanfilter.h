@@ -51,8 +51,8 @@ public:
         // device and back plus the operation itself; what is left to choose is where the window's dense pass runs.  In place (overlap = 0)
         // the call that follows a full window waits for the pass: nothing at N = 1024 (15 us), 100 us at N = 4096.  From 2048 landmarks on
         // the pass therefore runs beside the next window's calls (overlap = 1, a second P_LL buffer): per 5-call step at N = 4096 median
-        // 70 us / p90 115 us against 65 / 163 in place; at N = 1024 in place is the faster one (62 / 77 against 66 / 104).  (Before round 6,
-        // one launch per call: 100 / 110 us median, p90 185 us at N = 4096.)
+        // 75 us / p90 88 us against 70 / 163 in place; at N = 1024 in place is the faster one (67 / 77 against 65 / 85); N = 50: 50 / 70.
+        // (Before round 6, one launch per call: 89 / 103 / 110 us median at N = 50 / 1024 / 4096, p90 185 us at N = 4096.)
         ekf_params params;
         ekf_default_params(&params);
         params.overlap = capacity_landmarks >= 2048 ? 1 : 0;

@@ -214,7 +214,7 @@ size_t ekf_device_bytes(ekf_handle h);
  * scripted run was cut into windows (tests/test_gpu_parity.py: balanced tail, odd windows). */
 int ekf_debug_windows(ekf_handle h, long long *closed_out, int *last_slots_out);
 /* Diagnostic: streaming launches started and operations posted to them since create; returns 1 when the handle streams its
- * immediate-mode calls (one filter of more than 256 landmarks; EKF_STREAM=0 switches it off), 0 when every call is a launch. */
+ * immediate-mode calls (every handle of ONE filter; EKF_STREAM=0 switches it off), 0 when every call is a launch (batches). */
 int ekf_debug_stream(ekf_handle h, long long *starts_out, long long *ops_out);
 
 /* ---- Tunables -----------------------------------------------------------------------------------

@@ -113,7 +113,7 @@ def main():
     for f, ln, gap in settle_bad[:10]:
         print("%s: global_store of an accumulation register only %d wait states behind a v_mfma (line %d; 18 needed: pt_settle)" % (f, gap, ln))
     print("k_solo: %d stores from accumulation registers, the closest %s wait states behind an MFMA; descriptors: %s" % (
-        n_stores, min_gap, {k.split("ILb")[1][0] if "ILb" in k else k: v for k, v in seen_desc.items()}))
+        n_stores, min_gap, {"".join(re.findall(r"Lb([01])E", k)) or k: v for k, v in seen_desc.items()}))
     if n_stores == 0:
         desc_bad.append(("k_solo", "no accumulation-register stores found: the listing is not what this check was written for"))
         print("k_solo: no `global_store ... a[` found -- has the in-kernel pass moved?  (check 3 needs an update)")

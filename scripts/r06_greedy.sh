@@ -12,7 +12,7 @@ echo "greedy stress rc=$?: $(tail -1 gpurun_out/r06_greedy_stress.log)"
 for rep in 1 2 3; do
   for args in "" "--steps 20 --warmup 5" "--workload n1024" "--workload batch256"; do
     for lib in $B $G; do
-      EKFSLAM_LIB=$R/$lib timeout -k 10 200 python scripts/r03/bench_with_lib.py $args 2>/dev/null | sed "s|^|$(dirname $lib | xargs basename) |"
+      EKFSLAM_LIB=$R/$lib timeout -k 10 200 python scripts/bench_with_lib.py $args 2>/dev/null | sed "s|^|$(dirname $lib | xargs basename) |"
     done
   done
 done 2>&1 | tee gpurun_out/r06_greedy_ab.log

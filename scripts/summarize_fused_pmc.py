@@ -1,5 +1,5 @@
 """Round 5: HBM bytes per WINDOW of the batch kernel that folds its own windows (k_solo<true>, no dense-pass launch): condenses the
-rocprofv3 passes of scripts/profile_batch_fused.py (scripts/collect_r05.sh fused -> gpurun_out/prof_r05_batch256_fusedpmc) into
+rocprofv3 passes of scripts/profile_batch_fused.py (scripts/history/collect_r05.sh fused -> gpurun_out/prof_r05_batch256_fusedpmc) into
 profiles/r05_batch256_fusedpmc_summary.json and profiles/traffic_batch256_fused.json.  CPU."""
 import collections, csv, glob, json, os, sys
 sys.path.insert(0, os.getcwd())
@@ -68,7 +68,7 @@ if "FETCH_SIZE" in per_disp and "WRITE_SIZE" in per_disp:
                  "algorithmic_slot_emit_bytes) is IN these counters; ratio_without_the_slot_emit is the figure comparable with traffic_batch256.json, "
                  "which counted the pass kernel alone (its operand reads, not the writes that produced them).  A per-launch = per-window figure.",
          "source": "profiles/%s_batch256_fusedpmc_summary.json" % ROUND}
-    # the measurement loop alone (scripts/r05_collect_looponly_and_bench.sh: the debug library with the dense passes skipped): what is left
+    # the measurement loop alone (scripts/history/r05_collect_looponly_and_bench.sh: the debug library with the dense passes skipped): what is left
     # after subtracting its reads is the in-kernel pass's own read traffic (tiles + operands); the pass writes the tiles and nothing else
     lo_dir = sys.argv[2] if len(sys.argv) > 2 else "gpurun_out/prof_r05_batch256_looponly"
     lf = newest(os.path.join(lo_dir, "pmc_fetch", "*/*_counter_collection.csv"))

@@ -1,4 +1,4 @@
-"""Condense a scripts/profile_r02.sh output directory into the small files committed under profiles/:
+"""Condense a scripts/history/profile_r02.sh output directory into the small files committed under profiles/:
 <tag>_kernel_stats.csv (rocprofv3 --kernel-trace --stats), <tag>_summary.json (per-kernel averages, PMC means per
 dispatch, the bench lines of the profiled runs, HBM traffic per dense-pass launch) and traffic_<workload>[_inplace].json,
 which bench.py reads back into roofline.traffic."""

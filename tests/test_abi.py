@@ -101,7 +101,7 @@ def test_register_half_of_the_long_window_is_what_the_lint_guards(built):
     # the lint does flag a compiler-generated use: feed it a doctored listing
     asm = os.path.join(ROOT, "2d-ekf-slam_amd", "lib", "asm", "ekf_kernels.s")
     text = open(asm).read()
-    at = text.index("_Z6k_soloILb1EE")
+    at = text.index("_Z6k_soloILb1ELb0EE")  # k_solo<true, false>: the long window, not streaming
     at = text.index("\n", text.index("s_waitcnt", at)) + 1
     doctored = os.path.join(ROOT, "2d-ekf-slam_amd", "lib", "asm", "doctored.s")
     open(doctored, "w").write(text[:at] + "\tv_accvgpr_write_b32 a130, v1\n" + text[at:])
