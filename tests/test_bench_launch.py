@@ -124,6 +124,24 @@ def test_the_drivers_command_prints_a_line_that_fits_the_drivers_tail(pipeline_m
     assert sec["config1_n50"]["decisions_identical"] is True
 
 
+@pytest.mark.gpu
+def test_one_gpu_batch_line_carries_the_config5_leg_record(pipeline_mode):
+    """`python bench.py --gpus 1 --workload batch256`: the weak leg of BASELINE.json config 5 (256 filters per GPU) rides on the one-GPU line
+    with everything the first 8-GPU run will report per leg: value, per-rank time, all-gather time, ranks seen, the dense pass's roofline."""
+    if pipeline_mode != "inplace":
+        pytest.skip("once is enough")
+    p = _run_bench(["--gpus", "1", "--workload", "batch256", "--steps", "32", "--warmup", "8", "--config5-steps", "32", "--no-secondary", "--no-cpu-baseline"], 900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = _one_line(p)
+    sys.path.insert(0, ROOT)
+    import bench
+    leg = line["config5"]["weak"]
+    assert set(bench.CONFIG5_LEG_KEYS) <= set(leg) and set(bench.CONFIG5_ROOFLINE_KEYS) <= set(leg["roofline"]), leg
+    assert leg["filters_total"] == 256 and leg["ranks_seen"] == 1 and len(leg["per_rank_ms"]) == 1 and leg["value"] > 1e6
+    assert leg["roofline"]["frac"] > 0.05 and leg["roofline"]["launches"] >= 4 and leg["allgather_us"] > 0
+    assert line["value"] > 1e6 and line["roofline"]["frac"] > 0.05
+
+
 _NCCL_CHILD = textwrap.dedent("""
     import json, os, sys
     sys.path.insert(0, %r)
