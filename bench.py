@@ -24,7 +24,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-def compact(o, digits=7):
+def compact(o, digits=6):
     """Floats of the JSON line rounded to `digits` significant digits (a 17-digit double is 18 characters; the driver keeps an 8 KB
     tail of the line).  `value` and `ms_per_step` at the top level are printed in full by main()."""
     if isinstance(o, float):
@@ -791,9 +791,9 @@ def main():
             except Exception as e:  # a secondary record must not cost the headline
                 secondary[name] = {"error": "%s: %s" % (type(e).__name__, e)}
         def summarise(r, unit="steps/s"):
-            out = {"workload": "%s B=%d N=%d M=%d window=%d overlap=%d steps=%d warmup=%d prime=%d" % (r["workload"], r["B"], r["N"], r["M"], r["window"], r["overlap"], r["K"], r["W"], r["prime_steps"]),
-                   "value": r["value"], "unit": unit, "ms_per_step": r["elapsed"] / r["K"] * 1e3, "device_ms_per_step": r["dev_ms"] / r["K"],
-                   "per_update_us": r["elapsed"] / (r["K"] * r["M"]) * 1e6, "device_us_per_measurement": r["dev_ms"] * 1e3 / (r["K"] * r["M"]),
+            out = {"workload": "%s B%d M%d w%d ov%d K%d W%d P%d" % (r["workload"], r["B"], r["M"], r["window"], r["overlap"], r["K"], r["W"], r["prime_steps"]),  # (batch, measurements per step, window, overlap, timed / warm-up / prime steps)
+                   "value": r["value"], "unit": unit, "ms_per_step": r["elapsed"] / r["K"] * 1e3,
+                   "device_us_per_measurement": r["dev_ms"] * 1e3 / (r["K"] * r["M"]),
                    "host_minus_device_us": r["phases_us"]["host_minus_device"],
                    "roofline": r["roofline"] if VERBOSE else slim_roofline(r["roofline"])}
             if r["latency"]:
@@ -867,7 +867,7 @@ def main():
         "mc_stats": mc_stats,
         "config5": config5,
         "secondary": secondary,
-        "multi_gpu_note": "no scaling curve measured by the builder (one-GPU boxes); --gpus N shards filters, one RCCL all-gather",
+        "multi_gpu_note": "no scaling curve measured by the builder (one-GPU boxes)",
         "ekf_environment": ekf_env,
     }
     full = {k: line[k] for k in ("value", "ms_per_step")}
@@ -904,7 +904,7 @@ def cpu_baseline(pkg, N, M, seed, extent, min_sep):
     return {"value": sample_steps / t, "unit": "steps/s", "cores": 1, "kind": "port",
             "sample": "%d step(s) of the same workload (1 Propagate + %d Old Updates) at N=%d, faithful-dense oracle, %.1f s" % (sample_steps, M, N, t),
             "seconds_per_step": {"median": float(np.median(ps)), "p10": float(np.percentile(ps, 10)), "p90": float(np.percentile(ps, 90))},
-            "host_cpus": os.cpu_count(), "host": host_cpu_record(), "compiler_flags": "gcc -O3 -march=x86-64-v3 -ffp-contract=off (oracle/Makefile)"}
+            "host": host_cpu_record(), "compiler_flags": "gcc -O3 -march=x86-64-v3 -ffp-contract=off"}
 
 
 def cgroup_cpu_quota():
@@ -1009,9 +1009,8 @@ def cpu_baseline_structured(workload, M):
             "sample": "%d step(s) of the same workload at N=%d, structured oracle, %d OpenMP threads, %.1f s"
                       % (best["sample_steps"], best["N"], best["cores"], best["seconds"]),
             "seconds_per_step": best["seconds_per_step"],
-            "pinning": {"OMP_PROC_BIND": "spread", "OMP_PLACES": "threads", "first_touch": "in the parallel region",
-                        "affinity_cpus": affinity, "cgroup_cpu_quota": quota, "host_cpus": os.cpu_count(),
-                        "threads_rule": "min(affinity mask, cgroup CPU quota)"},
+            "pinning": {"OMP_PROC_BIND": "spread", "OMP_PLACES": "threads", "first_touch": "parallel", "affinity_cpus": affinity,
+                        "cgroup_cpu_quota": quota, "threads": "min(affinity, quota)"},
             "threads_16": "= all_cores" if same else brief(runs.get("threads_16"))}
 
 
