@@ -274,3 +274,47 @@ def test_small_maps_stream_through_the_one_workgroup_kernel(pkg, oc, monkeypatch
         finally:
             kf._f.close()
     assert np.abs(finals["0"][0] - finals["1"][0]).max() <= 1e-11 and np.abs(finals["0"][1] - finals["1"][1]).max() <= 1e-12 * np.abs(finals["0"][1]).max()
+
+
+def test_two_handles_stream_side_by_side(pkg, pipeline_mode):
+    """Two one-filter handles (N = 1024 and N = 200: k_chain and k_solo) driven alternately call by call: both resident launches live at
+    the same time (the residency registry has made sure they fit), neither sees the other's commands; each must end exactly where it ends
+    when it is driven alone."""
+    def one(N, seed, steps, other=None):
+        x0, P0 = pkg.scenarios.injected_state(N, seed=seed, extent=50.0 * (N / 4096.0) ** 0.5)
+        sc = pkg.scenarios.steady_script(x0, steps=steps, M=3, seed=seed + 1, min_separation=1.0)
+        f = pkg.FilterBatch(1, N, max_pending=8, log_capacity=4096)
+        f.set_state(x0, P0)
+        return f, sc
+
+    def step(f, sc, s, decs):
+        v, w, dt = sc["ctrl"][s]
+        f.propagate(v, w, dt)
+        for m in range(3):
+            d = f.update(sc["z"][s, m].reshape(1, 1, 2), sc["R"][s, m].reshape(2, 2, order="F").reshape(1, 1, 2, 2))
+            decs.append((d[0][0][0], d[0][0][1]))
+
+    steps = 20
+    alone = []
+    for N, seed in ((1024, 71), (200, 72)):
+        f, sc = one(N, seed, steps)
+        decs = []
+        for s in range(steps):
+            step(f, sc, s, decs)
+        alone.append((decs,) + f.get_state())
+        f.close()
+    fa, sa = one(1024, 71, steps)
+    fb, sb = one(200, 72, steps)
+    da, db = [], []
+    try:
+        for s in range(steps):
+            step(fa, sa, s, da)
+            step(fb, sb, s, db)
+        assert stream_counts(fa)[0] == 1 and stream_counts(fb)[0] == 1
+        for (d0, x0, P0), (d1, f1) in zip(alone, ((da, fa), (db, fb))):
+            x1, P1 = f1.get_state()
+            assert d0 == d1
+            assert np.array_equal(x0, x1) and np.array_equal(P0, P1)  # (the same launches in the same order: bit for bit)
+    finally:
+        fa.close()
+        fb.close()
