@@ -937,9 +937,12 @@ static int close_set(ekf_batch *h, bool terminal, EnqueueList *defer);
 
 // One immediate-mode operation through the streaming launch: post the command, make sure somebody consumes it, keep the host's
 // window bookkeeping (launch_ops' for a one-operation launch).  rec: the operation's record; consumes: it takes a slot.
-static int stream_op(ekf_batch *h, const double *rec, bool consumes) {
+// n_slots: slots of the open window the command consumes (an operation: 0 or 1; a scripted chunk: its measurements -- the caller cuts
+// chunks so that none passes the end of the window).
+static int stream_op(ekf_batch *h, const double *rec, int n_slots) {
     StreamCtl *c = h->sctl_h;
-    const bool closes = consumes && h->pending + 1 >= h->dv.maxp;
+    const bool consumes = n_slots > 0;
+    const bool closes = consumes && h->pending + n_slots >= h->dv.maxp;
     const long long seq = ++h->chain_seq;
     StreamCmd *cmd = &c->cmd[(unsigned long long)seq % EKF_STREAM_RING];
     if (h->stream_alive && seq - EKF_STREAM_RING > 0) {  // the slot's previous command (seq - ring) must have been executed: a caller that posts without ever reading
@@ -981,7 +984,7 @@ static int stream_op(ekf_batch *h, const double *rec, bool consumes) {
     }
     h->mirror_by_chain = true;
     h->stats_in_mirror = true;
-    if (consumes) h->pending++;
+    if (consumes) h->pending += n_slots;
     if (closes) {
         // the launch leaves behind this operation by itself (EKF_STREAM_END_AFTER); the window's dense pass is enqueued behind it once the
         // closing command is known to have been executed (a synchronising caller would wait for it next anyway)
@@ -1169,10 +1172,37 @@ static int launch_ops(ekf_batch *h, const double *in, const int *cursor, int k0,
             if (rc) return rc;
         }
         for (int q = 0; q < nops; q++) {
-            int rc = stream_op(h, h->ring_h + (size_t)(k0 + q) * 8, consumes[q] != 0);
+            int rc = stream_op(h, h->ring_h + (size_t)(k0 + q) * 8, consumes[q] ? 1 : 0);
             if (rc) return rc;
         }
         return EKF_OK;
+    }
+    if (h->stream_calls && cursor == nullptr && in == h->script_d && nops > 0 && nops <= EKF_CHAIN_MAX_OPS) {
+        // A SHORT scripted chunk of a one-filter handle (ekf_script_run of a step or two: the per-step call pattern of BASELINE.json config 2's
+        // latency figure): one OP_SCRIPT command to the resident launch per stretch that stays inside the open window -- at most one window's
+        // worth of measurements in all, so that a chunk crosses at most one window boundary (longer runs keep the multi-segment launches,
+        // whose windows turn over without the launch leaving).
+        int slots = 0;
+        for (int q = 0; q < nops; q++) slots += consumes[q] ? 1 : 0;
+        if (slots <= h->dv.maxp) {
+            if (h->pending == h->dv.maxp) {
+                int rc = close_set(h);
+                if (rc) return rc;
+            }
+            int q0 = 0;
+            while (q0 < nops) {
+                int q1 = q0, used = 0;
+                while (q1 < nops && !(consumes[q1] && h->pending + used == h->dv.maxp)) used += consumes[q1] ? 1 : 0, q1++;  // (up to, and including, the measurement that fills the window)
+                double rec[8] = {0, 0, 0, 0, 0, 0, 0, (double)OP_SCRIPT};
+                const long long bits = (long long)(size_t)h->script_d;
+                memcpy(&rec[0], &bits, sizeof bits);
+                rec[1] = (double)(k0 + q0), rec[2] = (double)(q1 - q0);
+                int rc = stream_op(h, rec, used);
+                if (rc) return rc;
+                q0 = q1;
+            }
+            return EKF_OK;
+        }
     }
     {
         int rc = stream_stop(h);
@@ -2101,14 +2131,14 @@ extern "C" int ekf_script_run(ekf_handle h, int first_step, int n_steps, int use
     if (!h || !h->script_d) return set_error(EKF_ERR_STATE, "no script loaded");
     if (first_step < 0 || n_steps < 0 || first_step + n_steps > h->script_steps) return set_error(EKF_ERR_BAD_ARG, "step range outside the script");
     HIP_TRY(hipSetDevice(h->device));
-    { int rc_ = stream_stop(h); if (rc_) return rc_; }  // (a resident streaming launch leaves first)
+    // (a resident streaming launch takes a short run itself -- launch_ops, OP_SCRIPT -- and leaves first for everything else)
     int ops = ops_per_step(h);
     int s = first_step, end = first_step + n_steps;
     if (use_graph && !h->overlap) {  // (the two-stream pipeline is not captured: plain launches)
         int S = graph_block_steps(h);
         if (end - s >= S) {
             // a graph starts from the settled state (its predecessor in the stream has fully finished)
-            int rc = close_set(h);
+            int rc = close_set(h);  // (a resident streaming launch leaves here)
             if (rc) return rc;
             GraphEntry *ge = nullptr;
             for (auto &g : h->graphs)

@@ -38,7 +38,8 @@
 #define EKF_REC_DOUBLES (2 * EKF_REC_HEAD + 16)
 
 // op records: 8 doubles per (op, filter); r[7] is the type
-enum { OP_NOP = 0, OP_PROP = 1, OP_MEAS = 2, OP_COMPASS = 3, OP_TRUTH = 4, OP_SKIP_SLOT = 5 };
+enum { OP_NOP = 0, OP_PROP = 1, OP_MEAS = 2, OP_COMPASS = 3, OP_TRUTH = 4, OP_SKIP_SLOT = 5,
+       OP_SCRIPT = 6 };  // (streamed commands only) run operations [r[1], r[1] + r[2]) of the record array whose device address is the bit pattern of r[0]: a short scripted chunk
 // header decisions (internal)
 enum { HDR_NONE = 0, HDR_NEW = 1, HDR_OLD = 2, HDR_IGNORE = 3, HDR_COMPASS = 4, HDR_NEW_NOFIT = 5 };
 

@@ -1082,6 +1082,17 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                 consumed++;
                 end_after = (uni(L.scmd) & EKF_STREAM_END_AFTER) != 0;
                 op = 0, nops_run = 1;
+                if (uni((int)recs[7]) == OP_SCRIPT) {
+                    // a short scripted chunk (ekf_script_run of a step or two: the per-step call pattern): its records lie in device memory, the
+                    // command names them; they are staged like a segment's (no look-ahead: a chunk is a step or two), the mirror follows the chunk
+                    const double *sp = (const double *)(size_t)__double_as_longlong(recs[0]);
+                    const int sk0 = uni((int)recs[1]), sn = uni((int)recs[2]);
+                    __syncthreads();  // (everybody has read the command's header out of recs[0..7])
+                    for (int q = tid; q < sn * 8; q += bd) recs[q] = op_record(sp, nullptr, sk0 + (q >> 3), dv.B, b)[q & 7];
+                    if (tid < sn) L.ap_tab[tid] = -1;
+                    __syncthreads();
+                    nops_run = sn;
+                }
             }
         }
         const double *rec = recs + op * 8;

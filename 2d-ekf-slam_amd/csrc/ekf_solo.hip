@@ -441,6 +441,14 @@ __global__ __launch_bounds__(256) void k_solo(EkfDev dv, const double *in, const
                     consumed++;
                     end_after = (uni(L.scmd) & EKF_STREAM_END_AFTER) != 0;
                     op = 0, nops_run = 1;
+                    if (uni((int)recs[7]) == OP_SCRIPT) {  // a short scripted chunk: its records from device memory (k_chain has the same block)
+                        const double *sp = (const double *)(size_t)__double_as_longlong(recs[0]);
+                        const int sk0 = uni((int)recs[1]), sn = uni((int)recs[2]);
+                        __syncthreads();  // (everybody has read the command's header out of recs[0..7])
+                        for (int q = tid; q < sn * 8; q += bd) recs[q] = op_record(sp, nullptr, sk0 + (q >> 3), dv.B, b)[q & 7];
+                        __syncthreads();
+                        nops_run = sn;
+                    }
                 }
             }
             const double *rec = recs + op * 8;

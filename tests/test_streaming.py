@@ -318,3 +318,48 @@ def test_two_handles_stream_side_by_side(pkg, pipeline_mode):
     finally:
         fa.close()
         fb.close()
+
+
+@pytest.mark.parametrize("N,max_pending,M,per_call", [(1024, 16, 4, 1), (1024, 8, 3, 1), (200, 16, 4, 1), (256, 32, 4, 2), (1024, 6, 4, 1), (700, 1, 2, 1)])
+def test_scripted_steps_one_call_at_a_time_stream_as_chunks(pkg, oc, monkeypatch, pipeline_mode, N, max_pending, M, per_call):
+    """ekf_script_run of a step or two per call (BASELINE.json config 2's per-step latency pattern): each call is ONE command to the resident
+    launch (OP_SCRIPT: the records stay in device memory), cut where a window fills.  Against the oracle and against one launch per call;
+    windows that a step crosses (6 slots, 4 measurements per step), a window of one, long windows of k_solo included."""
+    steps = 24
+    x0, P0 = pkg.scenarios.injected_state(N, seed=300 + N, extent=50.0 * (N / 4096.0) ** 0.5)
+    sc = pkg.scenarios.steady_script(x0, steps=steps, M=M, seed=301 + N, min_separation=1.0)
+    outs = {}
+    for stream in ("1", "0"):
+        monkeypatch.setenv("EKF_STREAM", stream)
+        f = pkg.FilterBatch(1, N, max_pending=max_pending, log_capacity=4096)
+        try:
+            f.set_state(x0, P0)
+            f.script_load(sc["ctrl"][:, None, :], sc["z"][:, :, None, :], sc["R"][:, :, None, :], truth=sc["truth"][:, None, :])
+            poses = []
+            for s in range(0, steps, per_call):
+                f.script_run(s, per_call)
+                poses.append(f.poses()[0].copy())
+            on, starts, ops = stream_counts(f)
+            # (a call whose measurements exceed a whole window keeps the multi-segment launch: the window of one, here)
+            want_streamed = stream == "1" and M * per_call <= max_pending
+            assert on == int(stream) and (ops >= steps // per_call if want_streamed else ops == 0), (on, starts, ops)
+            dec = f.decisions(0, steps * M)
+            st = f.stats()[0]
+            outs[stream] = (np.array(poses), dec) + f.get_state() + (st,)
+        finally:
+            f.close()
+    x, P, decs = x0, P0, []
+    for s in range(steps):
+        v, w, dt = sc["ctrl"][s]
+        x, P = oc.propagate(x, P, v, w, oc.make_Q(v), dt)
+        for m in range(M):
+            x, P, d, mt, _ = oc.update(x, P, sc["z"][s, m].reshape(2, 1), sc["R"][s, m].reshape(2, 2, order="F"))
+            decs.append((d[0], mt[0]))
+    for stream in ("1", "0"):
+        poses, dec, xg, Pg, st = outs[stream]
+        assert [(d[0], d[1]) for d in dec] == decs
+        assert_state_close(xg, Pg, x, P, "scripted steps, stream %s" % stream)
+        assert_bitwise_symmetric(Pg)
+        assert st["n_old"] == steps * M and st["nees_count"] == steps
+    assert np.abs(outs["0"][0] - outs["1"][0]).max() <= 1e-11
+    assert np.abs(outs["0"][2] - outs["1"][2]).max() <= 1e-11 and np.abs(outs["0"][3] - outs["1"][3]).max() <= 1e-12 * np.abs(outs["0"][3]).max()
