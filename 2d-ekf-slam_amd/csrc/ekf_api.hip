@@ -1179,12 +1179,13 @@ static int launch_ops(ekf_batch *h, const double *in, const int *cursor, int k0,
     }
     if (h->stream_calls && cursor == nullptr && in == h->script_d && nops > 0 && nops <= EKF_CHAIN_MAX_OPS) {
         // A SHORT scripted chunk of a one-filter handle (ekf_script_run of a step or two: the per-step call pattern of BASELINE.json config 2's
-        // latency figure): one OP_SCRIPT command to the resident launch per stretch that stays inside the open window -- at most one window's
-        // worth of measurements in all, so that a chunk crosses at most one window boundary (longer runs keep the multi-segment launches,
-        // whose windows turn over without the launch leaving).
+        // latency figure): one OP_SCRIPT command to the resident launch per stretch that stays inside the open window -- at most HALF a window
+        // of measurements in all: a step or two.  Whole windows and longer runs keep the multi-segment launches (their windows turn over
+        // without the launch leaving, a window they fill exactly stays open for the next call -- what bench.py's timed regions and its
+        // one-window `alone` runs rely on).
         int slots = 0;
         for (int q = 0; q < nops; q++) slots += consumes[q] ? 1 : 0;
-        if (slots <= h->dv.maxp) {
+        if (2 * slots <= h->dv.maxp) {
             if (h->pending == h->dv.maxp) {
                 int rc = close_set(h);
                 if (rc) return rc;

@@ -173,7 +173,7 @@ int ekf_broadcast_state(ekf_handle h);
 int ekf_script_load(ekf_handle h, int steps, int M, const double *ctrl, const double *z, const double *R,
                     const unsigned char *valid, const double *truth);
 /* use_graph != 0 replays the steps through captured HIP graphs (blocks of a few steps; the remainder
- * goes out as plain launches).  On a handle of ONE filter a short run -- at most one window's worth of measurements, i.e. a step or
+ * goes out as plain launches).  On a handle of ONE filter a short run -- at most half a window of measurements, i.e. a step or
  * two per call -- travels as one command to the resident streaming launch (see "Tunables": EKF_STREAM): 30 us per step at N = 1024
  * where a launch per call costs 42. */
 int ekf_script_run(ekf_handle h, int first_step, int n_steps, int use_graph);

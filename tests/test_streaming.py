@@ -340,8 +340,8 @@ def test_scripted_steps_one_call_at_a_time_stream_as_chunks(pkg, oc, monkeypatch
                 f.script_run(s, per_call)
                 poses.append(f.poses()[0].copy())
             on, starts, ops = stream_counts(f)
-            # (a call whose measurements exceed a whole window keeps the multi-segment launch: the window of one, here)
-            want_streamed = stream == "1" and M * per_call <= max_pending
+            # (a call with more than half a window of measurements keeps the multi-segment launch: the windows of 6 and of 1, here)
+            want_streamed = stream == "1" and 2 * M * per_call <= max_pending
             assert on == int(stream) and (ops >= steps // per_call if want_streamed else ops == 0), (on, starts, ops)
             dec = f.decisions(0, steps * M)
             st = f.stats()[0]
