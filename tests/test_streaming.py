@@ -22,8 +22,18 @@ def stream_counts(f):
     return on, a.value, b.value
 
 
-def drive(pkg, N, steps, M, max_pending, seed, gaps=None, compass=True, reads=False, x0P0=None):
-    """`steps` steps of propagate + M single-measurement updates (+ compass, + truth) as immediate calls; gaps: seconds slept before some calls."""
+def _pause(seconds, busy):
+    if not busy:
+        time.sleep(seconds)
+        return
+    t_end = time.perf_counter() + seconds  # (a sleep of 100 us really lasts 150-170: the spin hits the launch's idle time to a microsecond or two)
+    while time.perf_counter() < t_end:
+        pass
+
+
+def drive(pkg, N, steps, M, max_pending, seed, gaps=None, compass=True, reads=False, x0P0=None, busy=False):
+    """`steps` steps of propagate + M single-measurement updates (+ compass, + truth) as immediate calls; gaps: seconds paused before some
+    calls (slept, or -- busy -- spun)."""
     rng = np.random.default_rng(seed)
     x0, P0 = x0P0 if x0P0 is not None else pkg.scenarios.injected_state(N, seed=seed, extent=50.0 * (N / 4096.0) ** 0.5)
     sc = pkg.scenarios.steady_script(x0, steps=steps, M=M, seed=seed + 1, min_separation=1.0)
@@ -33,12 +43,12 @@ def drive(pkg, N, steps, M, max_pending, seed, gaps=None, compass=True, reads=Fa
     for s in range(steps):
         v, w, dt = sc["ctrl"][s]
         if gaps is not None and rng.random() < 0.5:
-            time.sleep(float(rng.choice(gaps)))
+            _pause(float(rng.choice(gaps)), busy)
         f.propagate(v, w, dt)
         poses.append(f.poses()[0].copy())
         for m in range(M):
             if gaps is not None and rng.random() < 0.3:
-                time.sleep(float(rng.choice(gaps)))
+                _pause(float(rng.choice(gaps)), busy)
             d = f.update(sc["z"][s, m].reshape(1, 1, 2), sc["R"][s, m].reshape(2, 2, order="F").reshape(1, 1, 2, 2))
             decs.append((d[0][0][0], d[0][0][1]))
         if compass and s % 3 == 1:
@@ -92,17 +102,20 @@ def test_streamed_calls_against_the_oracle(pkg, oc, pipeline_mode):
     assert_bitwise_symmetric(r["P"])
 
 
-@pytest.mark.parametrize("seed", range(4))
+@pytest.mark.parametrize("seed", range(6))
 def test_the_launch_leaves_by_itself_and_comes_back_without_losing_a_command(pkg, monkeypatch, pipeline_mode, seed):
     """Pauses of 0 ... 400 us between calls, around the launch's idle time (100 us): it leaves by itself again and again, sometimes while
     the next command is being posted (the state word / command slot handshake), and synchronising reads in the middle of windows make
     it leave on request.  Results as with one launch per call."""
     gaps = [0.0, 20e-6, 60e-6, 90e-6, 100e-6, 110e-6, 130e-6, 200e-6, 400e-6]
+    busy = seed >= 4  # (the last two seeds spin instead of sleeping, in steps of a microsecond around the launch's 100 us: the post lands INSIDE its leaving)
+    if busy:
+        gaps = [1e-6 * g for g in (80, 90, 94, 96, 97, 98, 99, 100, 101, 102, 103, 104, 106, 110, 120)]
     outs = {}
     init = None
     for stream in ("0", "1"):
         monkeypatch.setenv("EKF_STREAM", stream)
-        outs[stream] = drive(pkg, 1024, 30, 3, 8, seed=900 + seed, gaps=gaps if stream == "1" else None, reads=True, x0P0=init)
+        outs[stream] = drive(pkg, 1024, 30, 3, 8, seed=900 + seed, gaps=gaps if stream == "1" else None, reads=True, x0P0=init, busy=busy)
         init = (outs[stream]["x0"], outs[stream]["P0"])
     a, b = outs["0"], outs["1"]
     assert b["on"] == 1 and b["starts"] > 6, b["starts"]  # (idle exits and the reads' stops)
