@@ -210,3 +210,36 @@ def test_rccl_all_gather_of_device_written_stats_one_rank(pipeline_mode):
     assert np.array_equal(rccl, host), np.abs(rccl - host).max()
     assert np.array_equal(np.array(r["padded"]), host)
     assert r["allreduce"] == 1.25
+
+
+def test_bench_record_helpers_on_cpu(tmp_path, monkeypatch):
+    """The pieces of the JSON line that need no GPU: floats rounded to six significant digits (NaN / inf become null), the config-5 leg record
+    (value from total filters, steps and the slowest rank's time; ranks seen from the gathered rows), the prime-run rule (at least three
+    windows, the timed region's length up to 64 steps), and the chain record's replay guard (a profile of other kernel sources is not replayed)."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    c = bench.compact({"a": 1.23456789012, "b": [float("nan"), float("inf"), 3], "c": {"d": 6.02214076e23, "e": "text", "f": None}})
+    assert c == {"a": 1.23457, "b": [None, None, 3], "c": {"d": 6.02214e23, "e": "text", "f": None}}
+    leg = bench.config5_leg_record(2048, 683, 3, 200, 0.05, 2048, [50.0, 49.0, 48.5], 31.0, {"bound": "hbm", "achieved": 1900.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.2375,
+                                                                                           "traffic": None, "kernel": "k", "bytes_per_launch": 1, "launches": 7, "avg_launch_us": 290.0, "fused_pass": True})
+    assert leg["value"] == 2048 * 200 / 0.05 and leg["ranks_seen"] == 3 and leg["roofline"]["frac"] == 0.2375 and leg["roofline"]["fused_pass"] is True
+    assert set(bench.CONFIG5_LEG_KEYS) <= set(leg) and set(bench.CONFIG5_ROOFLINE_KEYS) <= set(leg["roofline"])
+    assert bench.prime_steps_for(32, 4, 20) == 24 and bench.prime_steps_for(16, 4, 512) == 64 and bench.prime_steps_for(32, 1, 20) == 96 and bench.prime_steps_for(16, 0, 20) == 0
+    assert bench.window_for("n1024", 0) == 16 and bench.window_for("n4096", 0) == 32 and bench.window_for("n4096", 8) == 8
+    # the chain record: replayed only from a profile of THESE kernel sources, at the same window and pipeline mode
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    (tmp_path / "profiles").mkdir()
+    stamps = {"max_pending": 32, "overlap": 1, "first_worker_sum_us": 6.9,
+              "first_worker_us": {k: 0.5 for k in ("sweep_argmin_publish", "wait_pick", "gate_bookkeeping", "wait_staged_record", "wait_pll_entries", "fold",
+                                                   "gain_stores_or_robot_block", "between_measurements", "end_barrier", "segment_prologue_share")}}
+    prof = {"kernel_source_sha16": "0123456789abcdef", "stamps": stamps, "hop_us": 0.75, "floor_us": 5.25, "floor_us_idle": 4.4}
+    (tmp_path / "profiles" / "chain_n4096.json").write_text(json.dumps(prof))
+    monkeypatch.setattr(bench, "kernel_source_digest", lambda: "fedcba9876543210")
+    stale = bench.chain_record("n4096", 32, 1, 6.3, 6.4)
+    assert stale["floor_us"] is None and stale["split_us"] is None and "stale" in stale["source"] and stale["us_per_measurement"] == {"alone": 6.3, "in_pipeline": 6.4}
+    monkeypatch.setattr(bench, "kernel_source_digest", lambda: "0123456789abcdef")
+    fresh = bench.chain_record("n4096", 32, 1, 6.3, 6.4)
+    assert fresh["floor_us"] == 5.25 and abs(fresh["floor_over_measured"] - 5.25 / 6.4) < 1e-12 and fresh["split_us"]["fold"] == 0.5
+    other_window = bench.chain_record("n4096", 16, 1, 6.3, 6.4)
+    assert other_window["floor_us"] is None  # (a profile taken at another window says nothing about this run)
