@@ -179,12 +179,13 @@ def test_immediate_mode_latency_is_bounded(replay_bin, pkg, tmp_path, pipeline_m
     """The path slam.cpp really uses: one synchronising call at a time with the public mirrors refreshed after each
     (kalmanfilter.cpp:46-48,85-89).  Round 6: for maps above 256 landmarks the calls are commands to a resident streaming launch
     (N = 1024 / 4096: 62-70 us per 5-call step from C++, p90 77 / 115 us; one launch per call cost 100 / 110 us, p90 185 us); maps of up to
-    256 landmarks keep one k_solo launch per call (85 us at N = 50).  The C++ bounds: median 150 us (200 in round 5, 600 before), p90
-    250 us where the calls stream.  Both hosts: the C++ replay driver and the Python mirror (ctypes and NumPy conversions: 200 us)."""
+    256 landmarks stream through k_solo (50 us at N = 50).  Measured on idle boxes: C++ 50 / 67 / 75 us per step, Python 100-130 us.  The
+    bounds below are tripwires for a regression to one launch per call on a slow or shared host, not the measurement (bench.py's immediate
+    leg is): C++ median 200 us, p90 400 us where the calls stream; the Python mirror (ctypes and NumPy conversions) 300 us."""
     M, steps = 4, 80
     x0, P0 = pkg.scenarios.injected_state(N, seed=1, extent=50.0 * (N / 4096.0) ** 0.5)  # constant landmark density
     sc = pkg.scenarios.steady_script(x0, steps=steps, M=M, seed=2, min_separation=1.0)
-    bound_us = 150.0
+    bound_us = 200.0
     # C++: compat/replay --timing, starting from the injected state; measurements handed over as robot-frame mm features
     rec = tmp_path / "rec.txt"
     with open(rec, "w") as f:
@@ -218,15 +219,15 @@ def test_immediate_mode_latency_is_bounded(replay_bin, pkg, tmp_path, pipeline_m
         kf._f.close()  # (a failing assertion below must not leave the handle's chain workgroups claimed for the rest of the suite)
     median_py = float(np.median(per_step[16:]))
     print("immediate mode N=%d: %.0f us/step C++ (p90 %.0f), %.0f us/step Python" % (N, median_cpp, p90_cpp, median_py))
-    assert median_cpp < bound_us and median_py < 200.0, (N, median_cpp, median_py)
+    assert median_cpp < bound_us and median_py < 300.0, (N, median_cpp, median_py)
     if N > 256:
         assert "streaming 1" in out.stdout, out.stdout[-300:]
         # (the p90 is the step behind a full window: with the pass forced in place -- this suite's "inplace" mode overrides the shim's choice
         # of the overlapped pipeline from 2048 landmarks on -- that step waits 100 us for the pass at N = 4096)
-        # (p90 bound 250 us: 77-115 us on an idle box; the step behind a full window carries five host-side HIP calls -- event, stream wait,
+        # (p90 bound 400 us: 77-115 us on an idle box; the step behind a full window carries five host-side HIP calls -- event, stream wait,
         # pass, mark, the next streaming launch -- and a busy host stretches those, 173 us seen once on a shared pod)
         if not (N >= 2048 and pipeline_mode == "inplace"):
-            assert p90_cpp < 250.0, (N, p90_cpp, out.stdout[-300:])
+            assert p90_cpp < 400.0, (N, p90_cpp, out.stdout[-300:])
 
 
 def test_compat_featuredetector_header_keeps_the_reference_interface():
