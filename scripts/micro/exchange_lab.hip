@@ -5,6 +5,9 @@
 // workgroup l's three granules, relaxed agent-scope loads, until every lane sees the tag) and reduces with a DPP-free shuffle arg-min.
 // `work` dependent fp64 FMAs in front of every publish stand in for the sweep, so that the participants arrive as skewed as real ones (0 = none).
 // Reported: microseconds per exchange (the slowest workgroup's), idle chip and beside a stream on the other CUs, G = 8 / 16 / 32 / 64.
+// Second question (round 6): is the fan-in on a head's cache line part of the price?  COPIES > 1: every publisher writes its head to COPIES
+// places (lane c of the publishing wave writes copy c: the same three store instructions), a poller reads copy (its XCC id mod COPIES) -- 64
+// readers per line become 64 / COPIES.
 // Build: hipcc -O3 --offload-arch=gfx950 -o exchange_lab exchange_lab.hip
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -24,26 +27,32 @@ __global__ __launch_bounds__(256) void k_stream(const double2 *src, double2 *dst
         for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
 }
 
-// records: [parity][G][16] unsigned long long (128 bytes per record); granules 0..2 = {lo32 | tag << 32}, {hi32 | tag << 32}, {index | tag << 32}
-__global__ __launch_bounds__(64) void k_exchange(unsigned long long *rec, int G, int iters, int work, long long *out, double *sink) {
+__device__ __forceinline__ unsigned xcc_id() {
+    unsigned v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    return v & 0xf;
+}
+// records: [parity][copy][G][16] unsigned long long (128 bytes per record); granules 0..2 = {lo32 | tag << 32}, {hi32 | tag << 32}, {index | tag << 32}
+__global__ __launch_bounds__(64) void k_exchange(unsigned long long *rec, int G, int iters, int work, long long *out, double *sink, int copies) {
     extern __shared__ char lds_pad[];  // (sized by the host so that one workgroup fills a CU, as a chain workgroup does)
     const int g = blockIdx.x, lane = threadIdx.x;
     if (lane == 0) lds_pad[0] = 0;
     double acc = 1.0 + g * 1e-3;
+    const int my_copy = (int)(xcc_id() % (unsigned)copies);
     unsigned long long t0, t1;
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
     for (int it = 1; it <= iters; it++) {
         // the "sweep": dependent fp64 chain, slightly different per workgroup
         for (int w = 0; w < work + (g & 3); w++) acc = acc * 1.0000001 + 1e-9;
         const unsigned long long tag = (unsigned long long)(unsigned)it << 32;
-        unsigned long long *mine = rec + ((size_t)(it & 1) * G + g) * 16;
-        if (lane == 0) {
+        unsigned long long *mine = rec + (((size_t)(it & 1) * copies + (lane < copies ? lane : 0)) * G + g) * 16;
+        if (lane < copies) {
             const unsigned long long bits = (unsigned long long)__double_as_longlong(acc);
             __hip_atomic_store(mine + 0, (bits & 0xffffffffull) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(mine + 1, (bits >> 32) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(mine + 2, (unsigned long long)(unsigned)g | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        const unsigned long long *hd = rec + ((size_t)(it & 1) * G + (lane < G ? lane : 0)) * 16;
+        const unsigned long long *hd = rec + (((size_t)(it & 1) * copies + my_copy) * G + (lane < G ? lane : 0)) * 16;
         unsigned long long h0 = 0, h1 = 0, h2 = 0;
         bool ok = lane >= G;
         long spins = 0;
@@ -73,7 +82,7 @@ int main() {
     unsigned long long *rec;
     long long *ticks;
     double *sink;
-    CK(hipMalloc(&rec, 2 * 64 * 16 * 8));
+    CK(hipMalloc(&rec, 2 * 8 * 64 * 16 * 8));
     CK(hipMalloc(&ticks, 64 * 8));
     CK(hipMalloc(&sink, 64 * 8));
     double2 *sa, *sb;
@@ -87,12 +96,14 @@ int main() {
     const int iters = 4000;
     for (int work : {0, 60}) {  // 60 dependent FMAs of 13 ns = 0.8 us: about the sweep's length
         for (int load = 0; load < 2; load++) {
+            for (int copies : {1, 8, 2})
             for (int G : {2, 8, 16, 32, 64}) {
+                if (copies > 1 && G < 32) continue;
                 double best = 1e9, worst = 0;
                 for (int rep = 0; rep < 3; rep++) {
-                    CK(hipMemset(rec, 0, 2 * 64 * 16 * 8));
+                    CK(hipMemset(rec, 0, 2 * 8 * 64 * 16 * 8));
                     if (load) hipLaunchKernelGGL(k_stream, dim3(1792), dim3(256), 0, s2, (const double2 *)sa, sb, sn, 6);
-                    hipLaunchKernelGGL(k_exchange, dim3(G), dim3(64), 100 * 1024, 0, rec, G, iters, work, ticks, sink);
+                    hipLaunchKernelGGL(k_exchange, dim3(G), dim3(64), 100 * 1024, 0, rec, G, iters, work, ticks, sink, copies);
                     CK(hipStreamSynchronize(0));
                     CK(hipStreamSynchronize(s2));
                     std::vector<long long> t(G);
@@ -101,7 +112,7 @@ int main() {
                     for (int g = 0; g < G; g++) slow = t[g] * 0.01 / iters > slow ? t[g] * 0.01 / iters : slow;
                     best = slow < best ? slow : best, worst = slow > worst ? slow : worst;
                 }
-                printf("exchange of %2d participants, %s, %2d FMAs of sweep in front: %.3f .. %.3f us per exchange (sweep included: %.2f us of it)\n", G,
+                printf("exchange of %2d participants, %d cop%s of every head, %s, %2d FMAs of sweep in front: %.3f .. %.3f us per exchange (sweep included: %.2f us of it)\n", G, copies, copies > 1 ? "ies" : "y",
                        load ? "beside a stream" : "idle chip     ", work, best, worst, work * 0.0134);
             }
         }
