@@ -496,6 +496,33 @@ def immediate_leg(pkg, dev_id):
     return out
 
 
+def features_leg(pkg, dev_id, n_scans=4096, calls=3):
+    """SURVEY.md 8(f) rank 4, the perception front end that feeds the path (houghtransform.cpp:40-280, featuredetector.cpp:74-289) batched
+    over many simulated scans: k_features, one workgroup per scan of 181 readings.  Integer / byte work bound by the reference's
+    order-dependent peak selection and LDS atomics (4.3 KB in, < 1 KB out per scan: nowhere near HBM), so the record is scans/s of the
+    kernel (the library's own hipEvents) with the share of a workgroup's time spent behind the selection; parity is the tests' business
+    (tests/test_features.py: votes, peaks, lines bit for bit against the oracle), the leg only checks that repeated scans repeat.  DESIGN.md 4.6."""
+    import numpy as np
+    base = [pkg.scenarios.simulated_scan(1000 + s) for s in range(64)]
+    scans = base * (n_scans // 64)
+    fx = pkg.FeatureExtractor(len(scans), max_points=181, max_corners=16, device=dev_id)
+    try:
+        best = None
+        for _ in range(calls):
+            corners, n = fx.extract(scans)
+            ms = fx.kernel_ms()
+            best = ms if best is None or ms < best else best
+        tail = fx.tail_share()
+    finally:
+        fx.close()
+    n = np.asarray(n)
+    assert np.array_equal(n[:64], n[64:128]), "the same scans give the same corners"
+    out = {"unit": "scans/s of 181 readings", "reference": "houghtransform.cpp:40-280,featuredetector.cpp:74-289", "bound": "latency",
+           "scans": len(scans), "kernel_ms": best, "value": len(scans) / best * 1e3, "tail_share": tail, "corners": int(n.sum()),
+           "frac_of_hbm_peak": len(scans) * (181 * 3 * 8 + 16 * 2 * 8 + 4) / (best * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    return out
+
+
 def propagate_only_leg(pkg, dev_id, K=2048, W=64):
     """BASELINE.json config 3's "roofline for propagate" (Propagate.cpp:15-75, the row update of :53-60): K scripted steps with NO
     measurement (M = 0) at N = 4096 and N = 1024.  Propagate touches the 3x3 robot block and the three robot rows only --
@@ -808,6 +835,7 @@ def main():
         leg("config1_n50", lambda: config1_leg(pkg, dev_id))
         leg("immediate_calls", lambda: immediate_leg(pkg, dev_id))
         leg("propagate_only", lambda: propagate_only_leg(pkg, dev_id))
+        leg("features", lambda: features_leg(pkg, dev_id))
         print(json.dumps({"secondary": secondary}))
         return
 
