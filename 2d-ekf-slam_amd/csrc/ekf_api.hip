@@ -120,6 +120,8 @@ struct ekf_batch {
     // streaming immediate-mode calls (one-filter handles run by k_chain<true>; EKF_STREAM=0 switches them off): a resident launch consumes
     // the calls' operations from a host-mapped command ring (ekf_device.h: StreamCtl)
     StreamCtl *sctl_h = nullptr;  // host view of dv.sctl
+    StreamCtl *sring_h = nullptr; // host view of dv.sring: sctl_h, or the device allocation itself (written through the BAR; never read by the host)
+    bool sring_in_hbm = false;
     bool stream_calls = false;    // the handle streams its immediate-mode calls
     bool stream_alive = false;    // a streaming launch has been started and not been told (or seen) to leave
     int stream_launch = 0;        // number of the newest streaming launch (ChainPlan::stream)
@@ -536,6 +538,23 @@ static int create_impl(ekf_batch *h, int batch, int capacity_landmarks, int devi
     HIP_TRY(hipHostMalloc((void **)&h->sctl_h, sizeof(StreamCtl), hipHostMallocMapped));
     memset(h->sctl_h, 0, sizeof(StreamCtl));
     HIP_TRY(hipHostGetDevicePointer((void **)&dv.sctl, h->sctl_h, 0));
+    {
+        // the command ring in device memory where the host can write it (large BAR; EKF_STREAM_RING_HOST=1 keeps it in host memory)
+        int large_bar = 0;
+        if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, h->device) != hipSuccess) large_bar = 0, (void)hipGetLastError();
+        const bool want_host = getenv("EKF_STREAM_RING_HOST") && atoi(getenv("EKF_STREAM_RING_HOST")) != 0;
+        dv.sring = dv.sctl, h->sring_h = h->sctl_h;
+        if (large_bar && !want_host) {
+            StreamCtl *d = nullptr;
+            if (hipExtMallocWithFlags((void **)&d, sizeof(StreamCtl), hipDeviceMallocFinegrained) == hipSuccess) {
+                HIP_TRY(hipMemsetAsync(d, 0, sizeof(StreamCtl), s));
+                h->device_bytes += sizeof(StreamCtl);
+                dv.sring = d, h->sring_h = d, h->sring_in_hbm = true;
+            } else {
+                (void)hipGetLastError();
+            }
+        }
+    }
     size_t rec_bytes = B * 8 * sizeof(double);
     long ring_ops = (long)((16u << 20) / rec_bytes);
     if (ring_ops > 1024) ring_ops = 1024;
@@ -695,6 +714,7 @@ extern "C" int ekf_destroy(ekf_handle h) {
         if (m) hipFree(m);
     if (h->script_d) hipFree(h->script_d);
     if (h->ring_h) hipHostFree(h->ring_h);
+    if (h->sring_in_hbm) hipFree(h->dv.sring);
     if (h->sctl_h) hipHostFree(h->sctl_h);
     if (h->dv.sfw) hipFree(h->dv.sfw);
     if (h->mirror_h) hipHostFree(h->mirror_h);
@@ -928,7 +948,8 @@ static int stream_stop(ekf_batch *h) {
     // host memory may be served in either order: a stop seen without the command posted in front of it would leave that command behind)
     int rc = stream_wait_consumed(h, h->stream_last_seq);
     h->stream_alive = false;
-    __atomic_store_n(&h->sctl_h->stop, (unsigned long long)(unsigned)h->stream_launch, __ATOMIC_SEQ_CST);
+    __atomic_store_n(&h->sring_h->stop, (unsigned long long)(unsigned)h->stream_launch, __ATOMIC_SEQ_CST);
+    __builtin_ia32_sfence();  // (a ring in device memory is written through a write-combining mapping: out now)
     HIP_TRY(stream_wait(h->s_chain));
     return rc;
 }
@@ -944,7 +965,7 @@ static int stream_op(ekf_batch *h, const double *rec, int n_slots) {
     const bool consumes = n_slots > 0;
     const bool closes = consumes && h->pending + n_slots >= h->dv.maxp;
     const long long seq = ++h->chain_seq;
-    StreamCmd *cmd = &c->cmd[(unsigned long long)seq % EKF_STREAM_RING];
+    StreamCmd *cmd = &h->sring_h->cmd[(unsigned long long)seq % EKF_STREAM_RING];
     if (h->stream_alive && seq - EKF_STREAM_RING > 0) {  // the slot's previous command (seq - ring) must have been executed: a caller that posts without ever reading
         int rc = stream_wait_consumed(h, seq - EKF_STREAM_RING);
         if (rc) {
@@ -963,6 +984,7 @@ static int stream_op(ekf_batch *h, const double *rec, int n_slots) {
             __atomic_store_n(&cmd->g[2 + 2 * i], (bits >> 32) | tg, __ATOMIC_RELAXED);
         }
         __atomic_store_n(&cmd->g[0], (unsigned long long)(closes ? EKF_STREAM_END_AFTER : 0) | tg, __ATOMIC_RELEASE);
+        __builtin_ia32_sfence();  // (a ring in device memory is written through a write-combining mapping: the command leaves the write buffers now)
     }
     h->stream_ops++;
     h->stream_last_seq = seq;
@@ -2210,6 +2232,11 @@ extern "C" int ekf_debug_stream(ekf_handle h, long long *starts, long long *ops)
     *starts = h->stream_starts;
     *ops = h->stream_ops;
     return h->stream_calls ? 1 : 0;
+}
+
+extern "C" int ekf_debug_stream_ring(ekf_handle h) {
+    if (!h) return set_error(EKF_ERR_BAD_ARG, "null argument");
+    return h->sring_in_hbm ? 1 : 0;
 }
 
 extern "C" int ekf_debug_stamps(ekf_handle h, long long *out16, int reset) {

@@ -91,7 +91,7 @@ struct ChainPlan {
                                     // with the kernel arguments instead of the host-mapped input ring: the kernel's first trip to host memory
                                     // (its arguments) brings the record along, where the ring costs a second, dependent one
     int stream;                     // != 0: a STREAMING launch (k_chain<true, true>, round 6), the value is its launch number: one segment with no
-                                    // operations of its own; the operations arrive one by one through the host-mapped command ring (StreamCtl),
+                                    // operations of its own; the operations arrive one by one through the command ring (StreamCtl, EkfDev::sring),
                                     // s[0].seq is the number of the last command consumed BEFORE this launch
     ChainSeg s[EKF_PLAN_MAX];
     double inl[8];
@@ -100,8 +100,8 @@ struct ChainPlan {
 // ---- streaming immediate-mode calls (round 6) -----------------------------------------------------------------------------------
 // The reference drives the filter one synchronising call per operation (slam.cpp:136-170).  As one kernel launch per call that is
 // ~20 us per call around 1-7 us of device work: launch, dispatch, the workgroups' state reload (landmark registers, the own-row cache
-// of the open window), completion.  A streaming launch stays resident instead: workgroup 0's control lane polls a command ring in
-// host-mapped memory, forwards each command to the filter's other workgroups through device memory, the operation runs exactly as
+// of the open window), completion.  A streaming launch stays resident instead: workgroup 0's control lane polls a command ring (in
+// device memory the host writes through the BAR, or in host-mapped memory: EkfDev::sring), forwards each command to the filter's other workgroups through device memory, the operation runs exactly as
 // it does inside a scripted segment, and workgroup 0 publishes the host mirror (pose, robot block, counts, decisions, sequence
 // number) after EVERY operation.  The kernel leaves when the host says so (the window is full: the dense pass must run; any API call
 // that needs the stream), or by itself after EKF_STREAM_IDLE_TICKS without a command.
@@ -164,7 +164,10 @@ struct EkfDev {
     int *bar;          // [B][2]: [0] = cross-workgroup exchanges done so far (tags of the records continue from it)
     long long *dbg;    // [32] diagnostics: tick counters of the control lane [0..7] and of the first worker [16..23] (EKF_CHAIN_STAMPS), first bad index [8..11] (EKF_CHAIN_CHECK)
     double *part;      // [B][2][nrec][EKF_REC_DOUBLES]: arg-min records (per workgroup; k_chain<true>: per owner wave), double-buffered by exchange parity
-    StreamCtl *sctl;   // streaming launches (one-filter handles): the host-mapped command ring and state word, device view
+    StreamCtl *sctl;   // streaming launches (one-filter handles): the host-mapped block whose state word and consumed count the launch writes, device view
+    StreamCtl *sring;  // ... and the block whose command ring and stop word the host writes and the launch polls: DEVICE memory (fine-grained) the host
+                       // writes through the PCIe BAR where the device has a large BAR -- a poll is a local read instead of a read of host memory across
+                       // PCIe (scripts/micro/bar_lab.hip: 0.5 us per trip, and reads of several lines overlap) -- else the same host-mapped block as sctl
     unsigned long long *sfw;  // [32 granules + 1]: workgroup 0's forward of the current command to the filter's other workgroups (10 values as tagged
                               // 16-byte granule pairs), [32] = how many workgroups have read a forward so far (all launches)
     ekf_decision *log;

@@ -959,7 +959,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                     double val = 0;
                     if (lead) {
                         StreamCtl *ctl = dv.sctl;
-                        const StreamCmd *cmd = &ctl->cmd[(consumed + 1) % EKF_STREAM_RING];
+                        const StreamCmd *cmd = &dv.sring->cmd[(consumed + 1) % EKF_STREAM_RING];
                         const unsigned long long launch = (unsigned long long)(unsigned)plan.stream;
                         const unsigned ctag = (unsigned)((consumed + 1) & 0xffffffffull);  // the tag every granule of command consumed + 1 carries
                         int verdict = 0;  // 1: a command, 2: leave
@@ -972,13 +972,16 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                         asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
                         const unsigned long long idle_ticks = plan.inl_n ? (unsigned long long)plan.inl[0] : (unsigned long long)EKF_STREAM_IDLE_TICKS;  // (inl_n: the debug library's test hooks)
                         bool ok = lane > 16;
+                        // (a ring in device memory: reads of its three lines overlap, so every round polls the whole command -- all seventeen granules -- and
+                        // the fetch of "the other two lines" below finds them there; a ring in host memory: the first line only, see above)
+                        const int poll_lanes = dv.sring != dv.sctl ? 17 : 8;
                         for (unsigned round = 0;; round++) {
                             unsigned long long stp = 0;
-                            if (!ok && lane < 8) {
+                            if (!ok && lane < poll_lanes) {
                                 gq = __hip_atomic_load(&cmd->g[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                                 ok = (unsigned)(gq >> 32) == ctag;
                             } else if (lane == 17 && (round & 3) == 3) {
-                                stp = __hip_atomic_load(&ctl->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                stp = __hip_atomic_load(&dv.sring->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                             }
                             // (the command first: what the host posted before it asked the launch to stop is consumed before the launch leaves)
                             if (__any(lane == 0 && ok)) {

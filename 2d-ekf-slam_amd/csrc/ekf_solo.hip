@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256) void k_solo(EkfDev dv, const double *in, const
                             __atomic_thread_fence(__ATOMIC_RELEASE);  // (every lane, for its own stores)
                             if (lane == 0) __hip_atomic_store(&mr->seq, (long long)consumed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                         }
-                        const StreamCmd *cmd = &ctl->cmd[(consumed + 1) % EKF_STREAM_RING];
+                        const StreamCmd *cmd = &dv.sring->cmd[(consumed + 1) % EKF_STREAM_RING];
                         const unsigned long long launch = (unsigned long long)(unsigned)plan.stream;
                         const unsigned ctag = (unsigned)((consumed + 1) & 0xffffffffull);
                         int verdict = 0;  // 1: a command, 2: leave
@@ -379,13 +379,16 @@ __global__ __launch_bounds__(256) void k_solo(EkfDev dv, const double *in, const
                         asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
                         const unsigned long long idle_ticks = plan.inl_n ? (unsigned long long)plan.inl[0] : (unsigned long long)EKF_STREAM_IDLE_TICKS;  // (inl_n: the debug library's test hooks)
                         bool ok = lane > 16;
+                        // (a ring in device memory: reads of its three lines overlap, so every round polls the whole command -- all seventeen granules -- and
+                        // the fetch of "the other two lines" below finds them there; a ring in host memory: the first line only, see above)
+                        const int poll_lanes = dv.sring != dv.sctl ? 17 : 8;
                         for (unsigned round = 0;; round++) {  // (one cache line of host memory per round: the command's first, flags granule g[0] included)
                             unsigned long long stp = 0;
-                            if (!ok && lane < 8) {
+                            if (!ok && lane < poll_lanes) {
                                 gq = __hip_atomic_load(&cmd->g[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                                 ok = (unsigned)(gq >> 32) == ctag;
                             } else if (lane == 17 && (round & 3) == 3) {
-                                stp = __hip_atomic_load(&ctl->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                stp = __hip_atomic_load(&dv.sring->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                             }
                             if (__any(lane == 0 && ok)) {
                                 verdict = 1;

@@ -22,7 +22,7 @@ ABI_SYMBOLS = [
     "ekf_batch_update_compass", "ekf_batch_get_pose", "ekf_batch_num_landmarks", "ekf_get_state", "ekf_set_state",
     "ekf_broadcast_state", "ekf_script_load", "ekf_script_run", "ekf_sync", "ekf_flush", "ekf_close_window", "ekf_timer_start",
     "ekf_timer_stop", "ekf_flush_profile", "ekf_flush_profile_read", "ekf_fused_pass", "ekf_get_decisions", "ekf_get_stats",
-    "ekf_reset_stats", "ekf_stats_means_device", "ekf_record_truth", "ekf_stream", "ekf_device_bytes", "ekf_debug_windows", "ekf_debug_stream",
+    "ekf_reset_stats", "ekf_stats_means_device", "ekf_record_truth", "ekf_stream", "ekf_device_bytes", "ekf_debug_windows", "ekf_debug_stream", "ekf_debug_stream_ring",
 ]
 
 

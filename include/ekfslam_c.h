@@ -218,6 +218,9 @@ int ekf_debug_windows(ekf_handle h, long long *closed_out, int *last_slots_out);
 /* Diagnostic: streaming launches started and operations posted to them since create; returns 1 when the handle streams its
  * immediate-mode calls (every handle of ONE filter; EKF_STREAM=0 switches it off), 0 when every call is a launch (batches). */
 int ekf_debug_stream(ekf_handle h, long long *starts_out, long long *ops_out);
+/* Diagnostic: 1 when the streamed commands' ring lives in device memory the host writes through the PCIe BAR (large-BAR devices), 0 when in
+ * host-mapped memory (no large BAR, or EKF_STREAM_RING_HOST=1). */
+int ekf_debug_stream_ring(ekf_handle h);
 
 /* ---- Tunables -----------------------------------------------------------------------------------
  * Environment variables read once per handle at ekf_create / ekf_batch_create by the PRODUCT library.  They change scheduling
@@ -231,8 +234,10 @@ int ekf_debug_stream(ekf_handle h, long long *starts_out, long long *ops_out);
  *   EKF_CHAIN_WGS, EKF_CHAIN_CUS   chain workgroups per filter / CUs kept for them beside an overlapped pass
  *   EKF_INLINE_REC=0       immediate-mode records travel through the host-mapped ring instead of the kernel arguments
  *   EKF_STREAM=0           immediate-mode calls of a one-filter handle are one launch each (default: a resident launch consumes them
- *                          from a host-mapped command ring and publishes the host mirror after every operation; it leaves when the
+ *                          from a command ring and publishes the host mirror after every operation; it leaves when the
  *                          window is full, when another entry point needs the stream, or after 100 us without a call)
+ *   EKF_STREAM_RING_HOST=1 the streamed commands' ring stays in host-mapped memory (default where the device has a large BAR: in device memory,
+ *                          written by the host through the BAR, polled by the launch as a local read)
  *   EKF_XCD_MAP=0, EKF_BATCH_INTERLEAVE=0, EKF_FLUSH_ALTERNATE=0   dense-pass tile order experiments
  *   EKF_SOLO=0, EKF_SOLO_FUSE=0, EKF_SOLO_LONG_WINDOW=0, EKF_SOLO_GROUPS=n   one-workgroup filters: general kernel / separate pass launches / short window / phase groups
  *   EKF_INKERNEL_WAIT=0    chain launches wait for their pass by stream event instead of in-kernel

@@ -1,6 +1,6 @@
 """Streaming immediate-mode calls (round 6; csrc/ekf_device.h "streaming immediate-mode calls", k_chain<true, true>): a one-filter handle of
 more than 256 landmarks runs its per-call operations -- the reference's own call pattern, slam.cpp:136-170 -- through ONE resident launch
-that consumes commands from a host-mapped ring, instead of one launch per call.  Same operations in the same order: decisions must be
+that consumes commands from a ring the host writes (in device memory through the BAR, or host-mapped), instead of one launch per call.  Same operations in the same order: decisions must be
 identical and states equal up to the rounding of another template instantiation (as between k_chain<true> and k_chain<false>), against
 EKF_STREAM=0 and against the oracle; the launch must leave and come back cleanly (idle time-out, full windows, every entry point that
 needs the stream), and a command posted while the launch is leaving by itself must not be lost."""
@@ -57,10 +57,12 @@ def drive(pkg, N, steps, M, max_pending, seed, gaps=None, compass=True, reads=Fa
         if reads and s % 5 == 4:
             f.get_state()  # (a synchronising read in the middle of a window: the launch leaves, the next call starts another)
     on, starts, ops = stream_counts(f)
+    f.L.ekf_debug_stream_ring.argtypes = [ctypes.c_void_p]
+    ring = f.L.ekf_debug_stream_ring(f.h)
     x, P = f.get_state()
     st = f.stats()[0]
     f.close()
-    return dict(decs=decs, poses=np.array(poses), x=x, P=P, stats=st, on=on, starts=starts, ops=ops, x0=x0, P0=P0, sc=sc)
+    return dict(decs=decs, poses=np.array(poses), x=x, P=P, stats=st, on=on, starts=starts, ops=ops, x0=x0, P0=P0, sc=sc, ring=ring)
 
 
 @pytest.mark.parametrize("N,max_pending,steps", [(1024, 16, 14), (4096, 16, 10), (4096, 32, 18), (600, 7, 9)])
@@ -100,6 +102,33 @@ def test_streamed_calls_against_the_oracle(pkg, oc, pipeline_mode):
     assert r["decs"] == decs
     assert_state_close(r["x"], r["P"], x, P, "streamed calls, N = 1024")
     assert_bitwise_symmetric(r["P"])
+
+
+@pytest.mark.parametrize("N,max_pending,busy", [(1024, 8, False), (1024, 8, True), (200, 16, True), (4096, 32, False)])
+def test_the_command_ring_in_device_memory_and_in_host_memory(pkg, monkeypatch, pipeline_mode, N, max_pending, busy):
+    """Where the device has a large BAR the streamed commands' ring lives in device memory and the host writes it through the BAR (a poll is a
+    local read; scripts/micro/bar_lab.hip); EKF_STREAM_RING_HOST=1 keeps it in host-mapped memory, the only form elsewhere.  Both against one
+    launch per call, with pauses around the launch's idle time so that commands are posted while it leaves (the handshake's host-to-device
+    leg is a posted PCIe write now: the safety net under it, stream_wait_consumed, is what makes that safe)."""
+    gaps = [1e-6 * g for g in (0, 40, 90, 96, 98, 100, 102, 104, 110, 150, 300)]
+    outs = {}
+    init = None
+    for mode in ("launches", "host", "device"):
+        monkeypatch.setenv("EKF_STREAM", "0" if mode == "launches" else "1")
+        monkeypatch.setenv("EKF_STREAM_RING_HOST", "1" if mode == "host" else "0")
+        outs[mode] = drive(pkg, N, 24, 3, max_pending, seed=4200 + N, gaps=None if mode == "launches" else gaps, reads=True, x0P0=init, busy=busy)
+        init = (outs[mode]["x0"], outs[mode]["P0"])
+    a = outs["launches"]
+    assert outs["host"]["ring"] == 0 and outs["device"]["ring"] in (0, 1)  # (1 on every large-BAR device: all MI355X boxes of this pool)
+    for mode in ("host", "device"):
+        b = outs[mode]
+        assert b["on"] == 1 and b["starts"] > 4, (mode, b["starts"])
+        assert a["decs"] == b["decs"], mode
+        assert np.abs(a["poses"] - b["poses"]).max() <= 1e-11
+        assert np.abs(a["x"] - b["x"]).max() <= 1e-11 * max(1.0, np.abs(a["x"]).max()) and np.abs(a["P"] - b["P"]).max() <= 1e-12 * np.abs(a["P"]).max()
+        assert_bitwise_symmetric(b["P"])
+    # the two rings run the same instantiation: bit for bit
+    assert np.array_equal(outs["host"]["x"], outs["device"]["x"]) and np.array_equal(outs["host"]["P"], outs["device"]["P"])
 
 
 @pytest.mark.parametrize("seed", range(6))
