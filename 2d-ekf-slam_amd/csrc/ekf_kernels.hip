@@ -968,6 +968,20 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                         // waiting loop touches ONE line: the command's first, which holds the flags granule g[0] (written last by the host) and the
                         // first seven record granules; the stop word is looked at every fourth round.  When the flags carry the tag, lanes 8..16 fetch
                         // the other two lines once.  Every granule is re-read until it carries the command's tag: no ordering assumption anywhere.
+                        // every other workgroup has read the previous forward (normally long ago): the slot may be overwritten.  Looked at HERE, while
+                        // the host is still busy with the answer to the command before, not between the arrival of the next one and its forward
+                        // (a read of the counter is half a microsecond)
+                        if (lane == 0) {
+                            if (n_fw == 0) ack_base = __hip_atomic_load(dv.sfw + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            long spins = 0;
+                            while (__hip_atomic_load(dv.sfw + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ack_base < n_fw * (unsigned long long)(G - 1)) {
+                                __builtin_amdgcn_s_sleep(1);
+                                if (++spins > (1L << 22)) {  // bounded
+                                    dv.status[b] = EKF_ERR_TIMEOUT, dv.mirror[b].status = EKF_ERR_TIMEOUT, L.abort = 1;
+                                    break;
+                                }
+                            }
+                        }
                         unsigned long long gq = 0, t0, t1;
                         asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
                         const unsigned long long idle_ticks = plan.inl_n ? (unsigned long long)plan.inl[0] : (unsigned long long)EKF_STREAM_IDLE_TICKS;  // (inl_n: the debug library's test hooks)
@@ -1034,19 +1048,7 @@ __global__ __launch_bounds__(EKF_CHAIN_MAX_THREADS) void k_chain(EkfDev dv, cons
                         }
                         if (verdict == 1 && lane >= 1 && lane <= 16) ((unsigned *)recs)[lane - 1] = (unsigned)gq;  // (little-endian: words 2i, 2i + 1 are record value i)
                         const unsigned long long fl = __shfl(gq, 0) & 0xffffffffull;
-                        if (lane == 0) {
-                            // every other workgroup has read the previous forward (normally long ago): the slot may be overwritten
-                            if (n_fw == 0) ack_base = __hip_atomic_load(dv.sfw + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            long spins = 0;
-                            while (__hip_atomic_load(dv.sfw + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ack_base < n_fw * (unsigned long long)(G - 1)) {
-                                __builtin_amdgcn_s_sleep(1);
-                                if (++spins > (1L << 22)) {  // bounded
-                                    dv.status[b] = EKF_ERR_TIMEOUT, dv.mirror[b].status = EKF_ERR_TIMEOUT, L.abort = 1;
-                                    break;
-                                }
-                            }
-                            n_fw++;
-                        }
+                        n_fw++;
                         verdict = uni(verdict);
                         if (uni(L.abort)) verdict = 2;
                         if (verdict == 1) {
