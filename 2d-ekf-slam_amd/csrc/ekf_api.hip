@@ -948,8 +948,10 @@ static int stream_stop(ekf_batch *h) {
     // host memory may be served in either order: a stop seen without the command posted in front of it would leave that command behind)
     int rc = stream_wait_consumed(h, h->stream_last_seq);
     h->stream_alive = false;
-    __atomic_store_n(&h->sring_h->stop, (unsigned long long)(unsigned)h->stream_launch, __ATOMIC_SEQ_CST);
-    __builtin_ia32_sfence();  // (a ring in device memory is written through a write-combining mapping: out now)
+    // (a plain store: the word may live in device memory behind the BAR, where a sequentially consistent store -- an xchg on x86 -- would be a
+    // locked read-modify-write across PCIe; the mapping is write-combining: the fence sends it out now)
+    __atomic_store_n(&h->sring_h->stop, (unsigned long long)(unsigned)h->stream_launch, __ATOMIC_RELAXED);
+    __builtin_ia32_sfence();
     HIP_TRY(stream_wait(h->s_chain));
     return rc;
 }

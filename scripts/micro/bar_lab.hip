@@ -15,12 +15,18 @@
 #include <emmintrin.h>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s failed: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
-__global__ void k_poll(volatile unsigned long long *cmd, volatile unsigned long long *answer, int n) {
+// payload > 0: the answer is a MIRROR -- `payload` doubles in host memory, a release fence, then the sequence word (what the streaming launch
+// publishes after every operation: pose, robot block, counters, newest decisions); payload = 0: the sequence word alone
+__global__ void k_poll(volatile unsigned long long *cmd, volatile unsigned long long *answer, int n, int payload) {
     if (threadIdx.x != 0) return;
     for (unsigned long long want = 1; want <= (unsigned long long)n; want++) {
         long spins = 0;
         while (__hip_atomic_load((unsigned long long *)cmd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != want) {
             if (++spins > (1L << 24)) return;  // bounded: the grid always drains
+        }
+        if (payload > 0) {
+            for (int i = 0; i < payload; i++) ((volatile double *)answer)[16 + i] = (double)want + i;
+            __atomic_thread_fence(__ATOMIC_RELEASE);
         }
         __hip_atomic_store((unsigned long long *)answer, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
@@ -29,11 +35,11 @@ __global__ void k_poll(volatile unsigned long long *cmd, volatile unsigned long 
 static sigjmp_buf jb;
 static void on_segv(int) { siglongjmp(jb, 1); }
 
-static void run(const char *name, unsigned long long *cmd_host_view, unsigned long long *cmd_dev_view, unsigned long long *ans_h, unsigned long long *ans_d) {
+static void run(const char *name, unsigned long long *cmd_host_view, unsigned long long *cmd_dev_view, unsigned long long *ans_h, unsigned long long *ans_d, int payload = 0) {
     const int n = 20000;
     *ans_h = 0;
     std::vector<double> us(n);
-    hipLaunchKernelGGL(k_poll, dim3(1), dim3(64), 0, 0, cmd_dev_view, ans_d, n);
+    hipLaunchKernelGGL(k_poll, dim3(1), dim3(64), 0, 0, cmd_dev_view, ans_d, n, payload);
     for (int i = 1; i <= n; i++) {
         auto t0 = std::chrono::steady_clock::now();
         __atomic_store_n(cmd_host_view, (unsigned long long)i, __ATOMIC_RELAXED);
@@ -69,6 +75,12 @@ int main() {
         (void)probe;
         printf("device memory is host-readable here\n");
         run("command in device memory (host writes via BAR)", dev, dev, ans_h, ans_d);
+        CK(hipMemset(dev, 0, 4096));
+        CK(hipDeviceSynchronize());
+        run("... answer = 24 doubles + fence + sequence word", dev, dev, ans_h, ans_d, 24);
+        CK(hipMemset(dev, 0, 4096));
+        CK(hipDeviceSynchronize());
+        run("... answer = 60 doubles + fence + sequence word", dev, dev, ans_h, ans_d, 60);
     } else {
         printf("device memory is NOT host-accessible here (fault on the first host access)\n");
     }
