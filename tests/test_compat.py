@@ -179,7 +179,7 @@ def test_immediate_mode_latency_is_bounded(replay_bin, pkg, tmp_path, pipeline_m
     """The path slam.cpp really uses: one synchronising call at a time with the public mirrors refreshed after each
     (kalmanfilter.cpp:46-48,85-89).  Round 6: for maps above 256 landmarks the calls are commands to a resident streaming launch
     (N = 1024 / 4096: 62-70 us per 5-call step from C++, p90 77 / 115 us; one launch per call cost 100 / 110 us, p90 185 us); maps of up to
-    256 landmarks stream through k_solo (43 us at N = 50).  Measured on idle boxes: C++ 43 / 62 / 67 us per step, Python 100-130 us.  The
+    256 landmarks stream through k_solo (42 us at N = 50).  Measured on idle boxes: C++ 42 / 58 / 65 us per step, Python 100-130 us.  The
     bounds below are tripwires for a regression to one launch per call on a slow or shared host, not the measurement (bench.py's immediate
     leg is): C++ median 200 us, p90 400 us where the calls stream; the Python mirror (ctypes and NumPy conversions) 300 us."""
     M, steps = 4, 80
