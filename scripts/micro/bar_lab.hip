@@ -17,16 +17,24 @@
 
 // payload > 0: the answer is a MIRROR -- `payload` doubles in host memory, a release fence, then the sequence word (what the streaming launch
 // publishes after every operation: pose, robot block, counters, newest decisions); payload = 0: the sequence word alone
-__global__ void k_poll(volatile unsigned long long *cmd, volatile unsigned long long *answer, int n, int payload) {
+__global__ void k_poll(volatile unsigned long long *cmd, volatile unsigned long long *answer, int n, int payload, int mode) {
     if (threadIdx.x != 0) return;
     for (unsigned long long want = 1; want <= (unsigned long long)n; want++) {
         long spins = 0;
         while (__hip_atomic_load((unsigned long long *)cmd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != want) {
             if (++spins > (1L << 24)) return;  // bounded: the grid always drains
         }
-        if (payload > 0) {
+        if (payload > 0 && mode == 0) {         // volatile stores: the compiler waits for every one (a store's acknowledgement from host memory: 0.47 us)
             for (int i = 0; i < payload; i++) ((volatile double *)answer)[16 + i] = (double)want + i;
             __atomic_thread_fence(__ATOMIC_RELEASE);
+        } else if (payload > 0 && mode == 1) {  // the product's way: plain stores, then a system-scope release fence (buffer_wbl2 + s_waitcnt)
+            double *m = (double *)answer + 16;
+            for (int i = 0; i < payload; i++) m[i] = (double)want + i;
+            __atomic_thread_fence(__ATOMIC_RELEASE);
+        } else if (payload > 0) {               // write-through system-scope stores, then their acknowledgements only (no L2 write-back)
+            unsigned long long *m = (unsigned long long *)answer + 16;
+            for (int i = 0; i < payload; i++) __hip_atomic_store(m + i, (unsigned long long)__double_as_longlong((double)want + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __hip_atomic_store((unsigned long long *)answer, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
@@ -35,11 +43,11 @@ __global__ void k_poll(volatile unsigned long long *cmd, volatile unsigned long 
 static sigjmp_buf jb;
 static void on_segv(int) { siglongjmp(jb, 1); }
 
-static void run(const char *name, unsigned long long *cmd_host_view, unsigned long long *cmd_dev_view, unsigned long long *ans_h, unsigned long long *ans_d, int payload = 0) {
+static void run(const char *name, unsigned long long *cmd_host_view, unsigned long long *cmd_dev_view, unsigned long long *ans_h, unsigned long long *ans_d, int payload = 0, int mode = 0) {
     const int n = 20000;
     *ans_h = 0;
     std::vector<double> us(n);
-    hipLaunchKernelGGL(k_poll, dim3(1), dim3(64), 0, 0, cmd_dev_view, ans_d, n, payload);
+    hipLaunchKernelGGL(k_poll, dim3(1), dim3(64), 0, 0, cmd_dev_view, ans_d, n, payload, mode);
     for (int i = 1; i <= n; i++) {
         auto t0 = std::chrono::steady_clock::now();
         __atomic_store_n(cmd_host_view, (unsigned long long)i, __ATOMIC_RELAXED);
@@ -81,6 +89,14 @@ int main() {
         CK(hipMemset(dev, 0, 4096));
         CK(hipDeviceSynchronize());
         run("... answer = 60 doubles + fence + sequence word", dev, dev, ans_h, ans_d, 60);
+        for (int mode = 1; mode <= 2; mode++) {
+            CK(hipMemset(dev, 0, 4096));
+            CK(hipDeviceSynchronize());
+            run(mode == 1 ? "... 24 plain stores + release fence + seq" : "... 24 write-through stores + waitcnt + seq", dev, dev, ans_h, ans_d, 24, mode);
+        }
+        // the host checks what it reads behind the sequence word in the write-through form (the form the product does NOT use: a mirror whose plain
+        // stores were ordered by s_waitcnt alone handed the caller zeros -- the stores stay in the L2 until a write-back)
+        printf("payload behind the last sequence word: %.1f %.1f (want %d.0 and %d.0)\n", ((double *)ans_h)[16], ((double *)ans_h)[16 + 23], 20000, 20023);
     } else {
         printf("device memory is NOT host-accessible here (fault on the first host access)\n");
     }
