@@ -94,9 +94,16 @@ int main() {
             CK(hipDeviceSynchronize());
             run(mode == 1 ? "... 24 plain stores + release fence + seq" : "... 24 write-through stores + waitcnt + seq", dev, dev, ans_h, ans_d, 24, mode);
         }
+        for (int payload : {1, 4, 12, 48}) {  // is it the number of stores, or the fence?
+            CK(hipMemset(dev, 0, 4096));
+            CK(hipDeviceSynchronize());
+            char name[96];
+            snprintf(name, sizeof name, "... %d plain stores + release fence + seq", payload);
+            run(name, dev, dev, ans_h, ans_d, payload, 1);
+        }
         // the host checks what it reads behind the sequence word in the write-through form (the form the product does NOT use: a mirror whose plain
         // stores were ordered by s_waitcnt alone handed the caller zeros -- the stores stay in the L2 until a write-back)
-        printf("payload behind the last sequence word: %.1f %.1f (want %d.0 and %d.0)\n", ((double *)ans_h)[16], ((double *)ans_h)[16 + 23], 20000, 20023);
+        printf("payload behind the last sequence word: %.1f %.1f (want %d.0 and %d.0)\n", ((double *)ans_h)[16], ((double *)ans_h)[16 + 47], 20000, 20047);
     } else {
         printf("device memory is NOT host-accessible here (fault on the first host access)\n");
     }
