@@ -937,28 +937,37 @@ __global__ __launch_bounds__(256) void k_solo(EkfDev dv, const double *in, const
                             asm volatile("" ::: "memory");
                             unsigned lv = live_all;
                             const int r_ = lane & 15, k_ = lane >> 4, e_ = k_ & 1;
-                            for (int q = 0; q < np8; q++) {
-                                const int m = lv ? __builtin_ctz(lv) : zero_slot;
-                                lv &= lv - 1;
-                                const int sl = 2 * m + (k_ >> 1);  // (per lane: the pair's first or second slot)
-                                int ty = SLOT_DEAD;
-                                double s0 = 0, s1 = 0;
-                                if (m != zero_slot && sl < slot) {
-                                    const SlotMeta mt = L.sm[sl];
-                                    ty = mt.type;
-                                    s0 = e_ ? mt.S01 : mt.S00, s1 = e_ ? mt.S11 : mt.S01;  // column e of S
+                            // (round 6) four pairs per trip: the K rows of four pairs are requested before the first is used -- the loop used
+                            // to wait for every pair's rows by themselves, sixteen exposed trips to L2 / HBM per tile row and wave
+                            for (int q0 = 0; q0 < np8; q0 += 4) {
+                                int tyq[4];
+                                double s0q[4], s1q[4];
+                                size_t rowq[4];
+                                double2_t kk[4][4];
+#pragma unroll
+                                for (int u = 0; u < 4; u++) {
+                                    const int m = lv ? __builtin_ctz(lv) : zero_slot;
+                                    lv &= lv - 1;
+                                    const int sl = 2 * m + (k_ >> 1);  // (per lane: the pair's first or second slot)
+                                    tyq[u] = SLOT_DEAD, s0q[u] = 0, s1q[u] = 0;
+                                    if (m != zero_slot && sl < slot) {
+                                        const SlotMeta mt = L.sm[sl];
+                                        tyq[u] = mt.type;
+                                        s0q[u] = e_ ? mt.S01 : mt.S00, s1q[u] = e_ ? mt.S11 : mt.S01;  // column e of S
+                                    }
+                                    rowq[u] = (size_t)m * slot_stride + ((size_t)64 * I + r_) * 4;
+#pragma unroll
+                                    for (int rb = 0; rb < 4; rb++) kk[u][rb] = *(const double2_t *)(FBc + rowq[u] + (size_t)rb * 64 + (k_ & 2));
                                 }
-                                const size_t row0 = (size_t)m * slot_stride + ((size_t)64 * I + r_) * 4;
-                                double2_t kk[4];
-                                double av[4];
 #pragma unroll
-                                for (int rb = 0; rb < 4; rb++) kk[rb] = *(const double2_t *)(FBc + row0 + (size_t)rb * 64 + (k_ & 2));
+                                for (int u = 0; u < 4; u++) {
 #pragma unroll
-                                for (int rb = 0; rb < 4; rb++) av[rb] = ty == SLOT_NEW ? FAc[row0 + (size_t)rb * 64 + k_] : 0.0;
-#pragma unroll
-                                for (int rb = 0; rb < 4; rb++) {
-                                    const double d_ = -(kk[rb].x * s0 + kk[rb].y * s1);
-                                    stage[q * 256 + rb * 64 + lo] = ty == SLOT_OLD ? d_ : av[rb];
+                                    for (int rb = 0; rb < 4; rb++) {
+                                        const double d_ = -(kk[u][rb].x * s0q[u] + kk[u][rb].y * s1q[u]);
+                                        double v_ = tyq[u] == SLOT_OLD ? d_ : 0.0;
+                                        if (tyq[u] == SLOT_NEW) v_ = FAc[rowq[u] + (size_t)rb * 64 + k_];  // (a New slot's P_xL rows: rare, fetched where they are needed)
+                                        stage[(q0 + u) * 256 + rb * 64 + lo] = v_;
+                                    }
                                 }
                             }
                             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -969,7 +978,10 @@ __global__ __launch_bounds__(256) void k_solo(EkfDev dv, const double *in, const
                         const int I = half == 0 ? rp : nT - 1 - rp;
                         if (half == 1 && I == rp) break;  // (the middle row of an odd count)
                         stage_row(I);
-                        for (int J = I; J < nT; J++) {
+                        // (round 6) columns last to first: the four waves of the workgroup start their rows on the SAME column and walk down together,
+                        // so a column's B operands (32 KiB per filter) are fetched once for the workgroup instead of once per wave at different
+                        // times -- 32 filters share an XCD's 4 MB of L2, and a filter whose waves are spread over four columns keeps 128 KiB warm
+                        for (int J = nT - 1; J >= I; J--) {
                             const bool diag = I == J;
                             const size_t t = (size_t)I * T_ - ((size_t)I * (I - 1)) / 2 + (size_t)(J - I);
                             double *tile = dv.Bm[buf_read] + (size_t)b * dv.bm_stride + t * 4096;  // (uniform)
