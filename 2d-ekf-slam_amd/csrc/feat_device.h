@@ -19,7 +19,7 @@
 #define FEAT_CORNER_DIST 90000
 #define FEAT_MAX_SEGS EKF_FEAT_MAX_SEGS
 #define FEAT_MAX_POINTS EKF_FEAT_MAX_POINTS
-#define FEAT_ROW_PAD 1664 /* a theta row of 1601 cells padded to 26 steps of 64 */
+#define FEAT_ROW_PAD 1792 /* a theta row of 1601 cells padded to 7 steps of 256 (the look at a whole row, four cells per lane) = 28 steps of 64 (the walk) */
 
 struct FeatDev {
     int S, P;  // scans in this launch, readings stride per scan

@@ -37,7 +37,7 @@ __device__ __forceinline__ int wave_min_i32(int x) {
 // LDS of one scan.  The tail's tables are structure-of-arrays so that a lane can own a group / a line / a segment pair and
 // reach any other one by index; integer fields that several lanes fold into (the merge of groups) are LDS atomics.
 struct FeatLds {
-    unsigned row[2][FEAT_ROW_PAD];  // the theta row being scanned and the one being voted
+    alignas(16) unsigned row[2][FEAT_ROW_PAD];  // the theta row being scanned and the one being voted
     int pk_idx[FEAT_NUM_PEAKS], pk_val[FEAT_NUM_PEAKS];
     // peak groups (houghtransform.h:40-49), one per index
     int g_maxR[FEAT_NUM_PEAKS], g_minR[FEAT_NUM_PEAKS], g_maxT[FEAT_NUM_PEAKS], g_minT[FEAT_NUM_PEAKS];
@@ -347,17 +347,75 @@ __global__ __launch_bounds__(256) void k_features(FeatDev dv) {
         for (int k = 0; k < 4; k++) sval[k] = v0, sidx[k] = 0;
         minval = v0;
     }
+    // (round 6) the voting waves keep their readings in registers: a thread of waves 1..3 owns readings tid - 64 and tid + 128 (at most
+    // FEAT_MAX_POINTS = 384 = 2 x 192) for all 180 rows -- vote_row fetched range / x / y from memory again for every row, a trip through
+    // the vector memory path in front of each row's votes.  Same expression, same order of operations per vote.
+    static_assert(FEAT_MAX_POINTS <= 2 * 192, "two readings per voting thread");
+    double vx[2] = {0, 0}, vy[2] = {0, 0};
+    bool von[2] = {false, false};
+    if (!w0) {
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int p = tid - 64 + 192 * q;
+            if (p < n) von[q] = !(range[p] > FEAT_MAX_DIST), vx[q] = lx[p], vy[q] = ly[p];
+        }
+    }
+    // ... and the row's cos / sin one row ahead: they came by a vector load in front of every row's votes (the whole latency of a trip
+    // to L2 on the row's critical path, 180 times)
+    float cs_next = dv.cos_t[1], sn_next = dv.sin_t[1];
+    auto vote_row_regs = [&](int t) {
+#pragma clang fp contract(off)
+        const double ct = (double)cs_next, st = (double)sn_next;
+        if (t + 1 < FEAT_THETA_SIZE) cs_next = dv.cos_t[t + 1], sn_next = dv.sin_t[t + 1];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            if (!von[q]) continue;
+            const double v = vx[q] * ct + vy[q] * st;
+            int radius = (int)round(v);
+            radius /= FEAT_DISTANCE;
+            radius += FEAT_ADDITION;
+            if (radius >= 0 && radius < FEAT_RADIUS_SIZE) atomicAdd(&L.row[t & 1][radius], 1u);
+            else atomicAdd(&L.dropped, 1);
+        }
+    };
     for (int t = 0; t < FEAT_THETA_SIZE; t++) {
         if (!w0) {
-            if (t + 1 < FEAT_THETA_SIZE) vote_row(t + 1, tid - 64, 192);
+            if (t + 1 < FEAT_THETA_SIZE) vote_row_regs(t + 1);
         } else {
             // getPeaks over row t, houghtransform.cpp:264-279, 64 cells per step
             unsigned *row = L.row[t & 1];
             unsigned char *gout = dv.grid ? dv.grid + ((size_t)s * FEAT_THETA_SIZE + t) * FEAT_RADIUS_SIZE : nullptr;
-            for (int base = 0; base < FEAT_ROW_PAD; base += 64) {
+            // (round 6) Most rows hold no cell that beats the lowest peak (some 490 insertions per scan, 200 of them in the first two rows):
+            // the wave looks at the row four cells per lane first -- seven 16-byte LDS reads, a running maximum, ONE ballot -- and walks it
+            // in cell order only if some cell can qualify (minval only rises while a row is walked: a cell that does not beat it now never
+            // will).  The three scanning waves of a CU's three workgroups share a SIMD: the walk's instruction count was the row's time.
+            typedef unsigned feat_u4 __attribute__((ext_vector_type(4)));
+            if (!gout) {
+                unsigned vmax = 0;
+#pragma unroll
+                for (int j = 0; j < FEAT_ROW_PAD / 256; j++) {
+                    const feat_u4 q = *(const feat_u4 *)(row + j * 256 + lane * 4);
+                    const unsigned a = max(q.x & 0xffu, q.y & 0xffu), b2 = max(q.z & 0xffu, q.w & 0xffu);
+                    vmax = max(vmax, max(a, b2));
+                }
+                if (__ballot((int)vmax > minval) == 0) {
+#pragma unroll
+                    for (int j = 0; j < FEAT_ROW_PAD / 256; j++) *(feat_u4 *)(row + j * 256 + lane * 4) = (feat_u4){0u, 0u, 0u, 0u};  // clean for theta t + 2
+                    __syncthreads();
+                    continue;
+                }
+            }
+            // the whole row leaves LDS in one go -- all reads in flight, one wait -- instead of one exposed LDS trip per 64 cells
+            int vrow[FEAT_ROW_PAD / 64];
+#pragma unroll
+            for (int j = 0; j < FEAT_ROW_PAD / 64; j++) vrow[j] = (int)(row[j * 64 + lane] & 0xffu);  // unsigned char votes (the padding holds zeros)
+#pragma unroll
+            for (int j = 0; j < FEAT_ROW_PAD / 64; j++) row[j * 64 + lane] = 0;  // clean for theta t + 2
+#pragma unroll
+            for (int j = 0; j < FEAT_ROW_PAD / 64; j++) {
+                const int base = j * 64;
                 const int r = base + lane;
-                const int v = (r < FEAT_RADIUS_SIZE) ? (int)(row[r] & 0xffu) : 0;  // unsigned char votes
-                row[r] = 0;  // clean for theta t + 2
+                const int v = vrow[j];
                 if (gout && r < FEAT_RADIUS_SIZE) gout[r] = (unsigned char)v;
                 unsigned long long mask = __ballot(v > minval);
                 while (mask) {
