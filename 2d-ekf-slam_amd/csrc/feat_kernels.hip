@@ -37,22 +37,31 @@ __device__ __forceinline__ int wave_min_i32(int x) {
 // LDS of one scan.  The tail's tables are structure-of-arrays so that a lane can own a group / a line / a segment pair and
 // reach any other one by index; integer fields that several lanes fold into (the merge of groups) are LDS atomics.
 struct FeatLds {
-    alignas(16) unsigned row[2][FEAT_ROW_PAD];  // the theta row being scanned and the one being voted
-    int pk_idx[FEAT_NUM_PEAKS], pk_val[FEAT_NUM_PEAKS];
-    // peak groups (houghtransform.h:40-49), one per index
-    int g_maxR[FEAT_NUM_PEAKS], g_minR[FEAT_NUM_PEAKS], g_maxT[FEAT_NUM_PEAKS], g_minT[FEAT_NUM_PEAKS];
-    int g_rad[FEAT_NUM_PEAKS], g_th[FEAT_NUM_PEAKS], g_w[FEAT_NUM_PEAKS], g_n[FEAT_NUM_PEAKS];
-    int merge[FEAT_NUM_PEAKS];      // (values as the reference's `char mergeMatrix[size]` holds them: sign-extended 8 bits)
+    // (round 6) A workgroup alone on its CU takes as long over a scan as three side by side (one wave walks, the others wait: latency, not
+    // throughput), so scans per second = workgroups per CU, and that is LDS: members that are never live together share their bytes --
+    // 51.7 KB -> 30.7 KB, five workgroups per CU instead of three.
+    union {
+        alignas(16) unsigned row[2][FEAT_ROW_PAD];  // rows phase: the theta row being scanned and the one being voted
+        struct {                                    // feat_segments: a pool of list nodes (featuredetector.h:45-52), one list per line, newest first
+            double p_sx[FEAT_MAX_POINTS], p_sy[FEAT_MAX_POINTS], p_ex[FEAT_MAX_POINTS], p_ey[FEAT_MAX_POINTS];
+            short p_np[FEAT_MAX_POINTS], p_next[FEAT_MAX_POINTS];
+        };
+    };
+    union {
+        struct {  // end of the rows phase .. feat_lines: the peaks, then the peak groups (houghtransform.h:40-49), one per index
+            int pk_idx[FEAT_NUM_PEAKS], pk_val[FEAT_NUM_PEAKS];
+            int g_maxR[FEAT_NUM_PEAKS], g_minR[FEAT_NUM_PEAKS], g_maxT[FEAT_NUM_PEAKS], g_minT[FEAT_NUM_PEAKS];
+            int g_rad[FEAT_NUM_PEAKS], g_th[FEAT_NUM_PEAKS], g_w[FEAT_NUM_PEAKS], g_n[FEAT_NUM_PEAKS];
+            int merge[FEAT_NUM_PEAKS];  // (values as the reference's `char mergeMatrix[size]` holds them: sign-extended 8 bits)
+        };
+        double segs[FEAT_MAX_SEGS][7];  // end of feat_segments .. feat_corners
+    };
     int n_groups, n_lines;
     double lines[FEAT_NUM_PEAKS][3];  // radius, theta, weight
     float sn[FEAT_NUM_PEAKS], cs[FEAT_NUM_PEAKS];  // of the lines, later of the segments
-    // segments: a pool of list nodes (featuredetector.h:45-52), one list per line, newest first
     short assign[FEAT_MAX_POINTS];    // the line a reading belongs to, -1 = none
-    double p_sx[FEAT_MAX_POINTS], p_sy[FEAT_MAX_POINTS], p_ex[FEAT_MAX_POINTS], p_ey[FEAT_MAX_POINTS];
-    short p_np[FEAT_MAX_POINTS], p_next[FEAT_MAX_POINTS];
     int n_pool;
     short head[FEAT_NUM_PEAKS];
-    double segs[FEAT_MAX_SEGS][7];
     int dropped;
 };
 
