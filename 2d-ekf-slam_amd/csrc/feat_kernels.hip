@@ -90,9 +90,19 @@ __device__ void feat_lines(FeatLds &L, int lane) {  // houghtransform.cpp:56-236
 #pragma unroll
     for (int k = 0; k < 4; k++) maxR[k] = minR[k] = maxT[k] = minT[k] = rad[k] = th[k] = w[k] = np_[k] = 0;
     int ng = 0;
-    for (int i = 0; i < FEAT_NUM_PEAKS; i++) {
-        const int cell = f_uni(L.pk_idx[i]);
-        const int cr = cell % FEAT_RADIUS_SIZE, ct = cell / FEAT_RADIUS_SIZE, cw = f_uni(L.pk_val[i]);
+    // (round 6) the peaks come out of registers (position lane + 64 q in register q, read by readlane) instead of two dependent LDS reads in
+    // front of every one of the 200 iterations of this sequential loop
+    int pki[4], pkv[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int pos = lane + 64 * q;
+        pki[q] = pos < FEAT_NUM_PEAKS ? L.pk_idx[pos] : 0, pkv[q] = pos < FEAT_NUM_PEAKS ? L.pk_val[pos] : 0;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+    for (int ii = 0; ii < 64 && q * 64 + ii < FEAT_NUM_PEAKS; ii++) {
+        const int cell = __builtin_amdgcn_readlane(pki[q], ii);
+        const int cr = cell % FEAT_RADIUS_SIZE, ct = cell / FEAT_RADIUS_SIZE, cw = __builtin_amdgcn_readlane(pkv[q], ii);
         if (cr <= 0) continue;
         bool merged = false;
 #pragma unroll
@@ -391,69 +401,65 @@ __global__ __launch_bounds__(256) void k_features(FeatDev dv) {
         if (!w0) {
             if (t + 1 < FEAT_THETA_SIZE) vote_row_regs(t + 1);
         } else {
-            // getPeaks over row t, houghtransform.cpp:264-279, 64 cells per step
+            // getPeaks over row t, houghtransform.cpp:264-279
+            // (round 6) The wave holds the row four consecutive cells per lane (cell 256 j + 4 lane + c in component c of register j: seven
+            // 16-byte LDS reads, all in flight at once) and walks it 256 cells per step: ONE ballot per step finds the lanes that hold a cell
+            // beating the lowest peak, and only those lanes' cells are looked at one by one, in cell order (lane, then component).  Cells that
+            // beat the lowest peak are rare (some 490 insertions per scan, 200 of them in the first two rows) but spread over most rows, and
+            // the walk of 64 cells per step paid 28 ballots, compares and branches on every one of those rows: the scanning wave was the
+            // rows phase's critical path (200 of its 205 us; the voting waves waited at the barrier for 180 of them).
             unsigned *row = L.row[t & 1];
             unsigned char *gout = dv.grid ? dv.grid + ((size_t)s * FEAT_THETA_SIZE + t) * FEAT_RADIUS_SIZE : nullptr;
-            // (round 6) Most rows hold no cell that beats the lowest peak (some 490 insertions per scan, 200 of them in the first two rows):
-            // the wave looks at the row four cells per lane first -- seven 16-byte LDS reads, a running maximum, ONE ballot -- and walks it
-            // in cell order only if some cell can qualify (minval only rises while a row is walked: a cell that does not beat it now never
-            // will).  The three scanning waves of a CU's three workgroups share a SIMD: the walk's instruction count was the row's time.
             typedef unsigned feat_u4 __attribute__((ext_vector_type(4)));
-            if (!gout) {
-                unsigned vmax = 0;
+            constexpr int NJ = FEAT_ROW_PAD / 256;
+            feat_u4 q[NJ];
 #pragma unroll
-                for (int j = 0; j < FEAT_ROW_PAD / 256; j++) {
-                    const feat_u4 q = *(const feat_u4 *)(row + j * 256 + lane * 4);
-                    const unsigned a = max(q.x & 0xffu, q.y & 0xffu), b2 = max(q.z & 0xffu, q.w & 0xffu);
-                    vmax = max(vmax, max(a, b2));
-                }
-                if (__ballot((int)vmax > minval) == 0) {
+            for (int j = 0; j < NJ; j++) q[j] = *(const feat_u4 *)(row + j * 256 + lane * 4) & 0xffu;  // unsigned char votes (the padding holds zeros)
 #pragma unroll
-                    for (int j = 0; j < FEAT_ROW_PAD / 256; j++) *(feat_u4 *)(row + j * 256 + lane * 4) = (feat_u4){0u, 0u, 0u, 0u};  // clean for theta t + 2
-                    __syncthreads();
-                    continue;
-                }
+            for (int j = 0; j < NJ; j++) *(feat_u4 *)(row + j * 256 + lane * 4) = (feat_u4){0u, 0u, 0u, 0u};  // clean for theta t + 2
+            if (gout) {
+#pragma unroll
+                for (int j = 0; j < NJ; j++)
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        const int r = j * 256 + lane * 4 + c;
+                        if (r < FEAT_RADIUS_SIZE) gout[r] = (unsigned char)q[j][c];
+                    }
             }
-            // the whole row leaves LDS in one go -- all reads in flight, one wait -- instead of one exposed LDS trip per 64 cells
-            int vrow[FEAT_ROW_PAD / 64];
 #pragma unroll
-            for (int j = 0; j < FEAT_ROW_PAD / 64; j++) vrow[j] = (int)(row[j * 64 + lane] & 0xffu);  // unsigned char votes (the padding holds zeros)
-#pragma unroll
-            for (int j = 0; j < FEAT_ROW_PAD / 64; j++) row[j * 64 + lane] = 0;  // clean for theta t + 2
-#pragma unroll
-            for (int j = 0; j < FEAT_ROW_PAD / 64; j++) {
-                const int base = j * 64;
-                const int r = base + lane;
-                const int v = vrow[j];
-                if (gout && r < FEAT_RADIUS_SIZE) gout[r] = (unsigned char)v;
-                unsigned long long mask = __ballot(v > minval);
+            for (int j = 0; j < NJ; j++) {
+                const int vm = (int)max(max(q[j].x, q[j].y), max(q[j].z, q[j].w));
+                unsigned long long mask = __ballot(vm > minval);
                 while (mask) {
-                    const int bpos = __builtin_ctzll(mask);
-                    const int vb = __builtin_amdgcn_readlane(v, bpos);
-                    if (vb > minval) {  // :270 (minval = houghGrid[peaks[mindex]])
-                        const int cell = t * FEAT_RADIUS_SIZE + base + bpos;
-                        const int ln = mindex & 63, kk = mindex >> 6;
-                        if (lane == ln) {
+                    const int bl = __builtin_ctzll(mask);
 #pragma unroll
-                            for (int k = 0; k < 4; k++)
-                                if (k == kk) sval[k] = vb, sidx[k] = cell;  // :271
-                        }
-                        // :274-276: a running strict minimum from position 0 = the FIRST position of the lowest value, if that
-                        // is lower than the value just inserted; else mindex stays
-                        int key = 0x7fffffff;
+                    for (int c = 0; c < 4; c++) {
+                        const int vb = __builtin_amdgcn_readlane((int)q[j][c], bl);
+                        if (vb > minval) {  // :270 (minval = houghGrid[peaks[mindex]])
+                            const int cell = t * FEAT_RADIUS_SIZE + j * 256 + bl * 4 + c;
+                            const int ln = mindex & 63, kk = mindex >> 6;
+                            if (lane == ln) {
 #pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                            const int pos = lane + 64 * k;
-                            const int kx = (sval[k] << 8) | pos;
-                            if (pos < FEAT_NUM_PEAKS && kx < key) key = kx;
+                                for (int k = 0; k < 4; k++)
+                                    if (k == kk) sval[k] = vb, sidx[k] = cell;  // :271
+                            }
+                            // :274-276: a running strict minimum from position 0 = the FIRST position of the lowest value, if that
+                            // is lower than the value just inserted; else mindex stays
+                            int key = 0x7fffffff;
+#pragma unroll
+                            for (int k = 0; k < 4; k++) {
+                                const int pos = lane + 64 * k;
+                                const int kx = (sval[k] << 8) | pos;
+                                if (pos < FEAT_NUM_PEAKS && kx < key) key = kx;
+                            }
+                            key = wave_min_i32(key);
+                            const int gmin = key >> 8, gpos = key & 255;
+                            if (gmin < vb) mindex = gpos, minval = gmin;
+                            else minval = vb;
                         }
-                        key = wave_min_i32(key);
-                        const int gmin = key >> 8, gpos = key & 255;
-                        if (gmin < vb) mindex = gpos, minval = gmin;
-                        else minval = vb;
                     }
                     mask &= mask - 1;
-                    mask &= __ballot(v > minval);
+                    mask &= __ballot(vm > minval);  // (the lowest peak may have risen past the other lanes' cells)
                 }
             }
         }
